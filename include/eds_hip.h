@@ -1,0 +1,185 @@
+/* =============================================================================
+ * eds_hip.h — C ABI of libeds_hip.so: the MI355X (gfx950) event-to-model
+ * photometric tracker of EDS.
+ *
+ * Drop-in boundary for the hot path of uzh-rpg/slam-eds:
+ *   eds::tracking::Tracker::optimize            reference src/tracking/Tracker.cpp:104-241
+ *   eds::tracking::PhotometricError::operator() reference src/tracking/PhotometricError.hpp:124-182
+ * The reference exposes this path as a plain C++ class (Tracker.hpp:36-114, no
+ * FFI).  This header is what a binding of that class would call; the C++ shim
+ * `slam-eds_amd/csrc/Tracker.hpp` keeps the reference's member signatures on
+ * top of it.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all host buffers are caller-owned, fp64,
+ *    row-major, and only need to live for the duration of the call (the library
+ *    copies to HBM) — unlike the reference functor, which keeps raw pointers
+ *    into KeyFrame vectors (PhotometricError.hpp:79-83).
+ *  - every function returns EDS_OK (0) or a negative eds_status; on failure
+ *    in/out pose arguments are left at their input values (Tracker.cpp:217-240).
+ *  - a handle owns one HIP stream and is not re-entrant; distinct handles may be
+ *    used concurrently.  A handle holds `batch` independent alignments (slots).
+ *  - quaternions are stored x,y,z,w (Eigen coeffs(), Tracker.cpp:192);
+ *    velocity is [linear(3), angular(3)] (PhotometricError.hpp:114-122);
+ *    SE(3) tangents are [upsilon(3), omega(3)] (reference src/sophus/se3.hpp:406-428).
+ * ============================================================================= */
+#ifndef EDS_HIP_H_
+#define EDS_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDS_HIP_ABI_VERSION 1
+#define EDS_MAX_LEVELS 8
+
+typedef enum eds_status {
+    EDS_OK = 0,
+    EDS_ERR_INVALID = -1,       /* bad argument / size (reference: assert only, PhotometricError.hpp:70-73) */
+    EDS_ERR_HIP = -2,           /* HIP runtime failure; see eds_last_error() */
+    EDS_ERR_NOT_USABLE = -3,    /* solve ended with a non-usable solution (Tracker.cpp:236-239 returns false) */
+    EDS_ERR_STATE = -4,         /* keyframe / event frame not set */
+    EDS_ERR_NO_DEVICE = -5      /* no gfx950 device visible: there is NO CPU fallback */
+} eds_status;
+
+/* how the brightness-increment frame is sampled */
+typedef enum eds_sampling {
+    EDS_SAMPLE_BICUBIC = 0,     /* ceres::BiCubicInterpolator, what the reference does (PhotometricError.hpp:110-111,172) */
+    EDS_SAMPLE_BILINEAR = 1     /* 4-tap variant named by the north-star spec */
+} eds_sampling;
+
+/* which problem `optimize` solves */
+typedef enum eds_solver {
+    EDS_SOLVER_GN6 = 0,         /* pose-only SE(3) Gauss-Newton, velocity fixed: T <- exp(xi) T */
+    EDS_SOLVER_LM6 = 1,         /* same with DSO-style damping + accept/reject (template: reference CoarseTracker.cpp:545-664) */
+    EDS_SOLVER_REF12 = 2        /* the reference problem: 12 local parameters (t, quaternion, unit velocity),
+                                   Ceres trust-region LM semantics (Tracker.cpp:108-143,192-202) */
+} eds_solver;
+
+/* where the iteration loop runs */
+typedef enum eds_exec {
+    EDS_EXEC_HOST = 0,          /* residual/Jacobian kernel + reduction kernel per iteration, small solve on the host */
+    EDS_EXEC_DEVICE = 1         /* whole iteration loop on the GPU (one persistent workgroup per alignment) */
+} eds_exec;
+
+typedef enum eds_loss {         /* reference tracking/Config.hpp:36 — applied per residual block */
+    EDS_LOSS_NONE = 0, EDS_LOSS_HUBER = 1, EDS_LOSS_CAUCHY = 2
+} eds_loss;
+
+typedef enum eds_loss_param_method {   /* reference Tracker.hpp:34 */
+    EDS_LP_CONSTANT = 0, EDS_LP_MAD = 1, EDS_LP_STD = 2
+} eds_loss_param_method;
+
+/* Mirrors eds::tracking::Config / SolverOptions (reference tracking/Config.hpp:40-58). */
+typedef struct eds_trk_cfg {
+    int32_t device;                 /* HIP device ordinal */
+    int32_t sampling;               /* eds_sampling */
+    int32_t solver;                 /* eds_solver */
+    int32_t exec;                   /* eds_exec */
+    int32_t num_blocks;             /* options.num_threads: number of residual blocks, each with its own model norm
+                                       (Tracker.cpp:178-195; PhotometricError.hpp:132-152) */
+    int32_t loss_type;              /* eds_loss (REF12: per block, Tracker.cpp:146-161) */
+    double  loss_param;             /* config.loss_params[0] */
+    double  huber_tau;              /* per-point Huber threshold for GN6/LM6 (extension, cf. CoarseTracker.cpp:445); 0 = off */
+    double  lambda0;                /* LM6 initial damping (CoarseTracker.cpp:561 uses 0.01) */
+    int32_t num_levels;             /* entries used in max_num_iterations */
+    int32_t max_num_iterations[EDS_MAX_LEVELS];   /* options.max_num_iterations[id] (Tracker.cpp:139) */
+    double  function_tolerance;     /* YAML (Tracker.cpp:140) */
+    double  gradient_tolerance;     /* 1e-8 (Tracker.cpp:142) */
+    double  parameter_tolerance;    /* 1e-6 (Tracker.cpp:143) */
+    int32_t nc;                     /* 1: PhotometricErrorNC residual (PhotometricErrorNC.hpp:124-192) — reserved */
+    int32_t reserved[7];
+} eds_trk_cfg;
+
+/* Mirrors eds::tracking::TrackerInfo (reference tracking/Config.hpp:60-68) + diagnostics. */
+typedef struct eds_trk_info {
+    double   meas_time_us;          /* wall time of the solve (Tracker.cpp:209) */
+    uint32_t num_points;            /* number of residuals (Tracker.cpp:210) */
+    int32_t  num_iterations;        /* successful + unsuccessful steps (Tracker.cpp:211) */
+    double   time_seconds;          /* solver-reported time (Tracker.cpp:212) */
+    uint8_t  success;               /* IsSolutionUsable (Tracker.cpp:213) */
+    uint8_t  pad_[3];
+    int32_t  termination;           /* 0 convergence, 1 no convergence (max iterations), 2 failure */
+    int32_t  num_successful_steps;
+    int32_t  num_unsuccessful_steps;
+    double   initial_cost;
+    double   final_cost;
+    double   device_time_us;        /* GPU time between the handle's stream events */
+} eds_trk_info;
+
+typedef struct eds_trk eds_trk;     /* opaque */
+
+/* ---- library ---------------------------------------------------------------------------- */
+int         eds_abi_version(void);
+int         eds_device_count(void);
+const char* eds_last_error(void);               /* thread-local message of the last failure */
+void        eds_trk_cfg_default(eds_trk_cfg* cfg);
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* Replaces Tracker::Tracker(config) (Tracker.cpp:40-47).  Allocates HBM for `batch`
+ * alignments of up to `max_points` points on H x W frames; every slot starts at
+ * p = 0, q = identity, v = normalize(0.001 * 1_6) like the reference constructor. */
+int  eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points, int H, int W, eds_trk** out);
+void eds_trk_destroy(eds_trk* h);
+int  eds_trk_set_config(eds_trk* h, const eds_trk_cfg* cfg);    /* Tracker::config is a public member (Tracker.hpp:40) */
+int  eds_trk_get_config(const eds_trk* h, eds_trk_cfg* cfg);
+
+/* ---- inputs ----------------------------------------------------------------------------- */
+/* Replaces the pointers PhotometricError::Create receives (Tracker.cpp:189-191):
+ * norm_xy, grad_xy are N x 2 AoS (cv::Point2d layout), idp and w have N entries,
+ * intrinsics come from kf->K_ref (Tracker.cpp:165-166).  Converted to SoA in HBM. */
+int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, const double* grad_xy,
+                         const double* idp, const double* w, double fx, double fy, double cx, double cy);
+/* The reference re-reads the inverse depths on every optimize (Tracker.cpp:167). */
+int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp);
+/* Replaces `const std::vector<double>* event_frame` (Tracker.hpp:80): H*W row-major. */
+int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
+int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
+/* Tracker::reset / set / optimize overloads seed px,qx,vx (Tracker.cpp:49-102). */
+int eds_trk_set_state(eds_trk* h, int slot, const double p[3], const double q_xyzw[4], const double v[6]);
+int eds_trk_get_state(eds_trk* h, int slot, double p[3], double q_xyzw[4], double v[6]);
+
+/* ---- evaluation (one residual/Jacobian pass + reduction) ------------------------------------ */
+/* Evaluates slot `slot` at (p,q,v).  ncols = 6: SE(3) left-perturbation Jacobian
+ * [d/d upsilon, d/d omega]; ncols = 12: Ceres local coordinates [t, quaternion-local, velocity-local].
+ * r: N raw residuals (what Tracker.cpp:223-230 stores); J: N x ncols row-major;
+ * JtJ: ncols x ncols; Jtr: ncols; cost: 1/2 sum r^2 (no loss).  Any output may be NULL. */
+int eds_trk_eval(eds_trk* h, int slot, const double p[3], const double q_xyzw[4], const double v[6], int ncols,
+                 double* r, double* J, double* JtJ, double* Jtr, double* cost);
+
+/* ---- solve ------------------------------------------------------------------------------ */
+/* Replaces Tracker::optimize(id, event_frame, T_kf_ef, method) (Tracker.cpp:104-241) for one slot.
+ * p,q,v are in/out; `level` indexes max_num_iterations.  Residuals at the solution are kept for
+ * eds_trk_get_residuals / eds_trk_loss_param. */
+int eds_trk_optimize(eds_trk* h, int slot, int level, double p[3], double q_xyzw[4], double v[6], eds_trk_info* info);
+/* Batched form: solves slots [first, first+count) from their stored states, asynchronously on the
+ * handle's stream; eds_trk_sync waits.  Results via eds_trk_get_state / eds_trk_get_info. */
+int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count);
+int eds_trk_sync(eds_trk* h);
+int eds_trk_get_info(eds_trk* h, int slot, eds_trk_info* info);
+/* Per-iteration trace of the last 6-DoF solve of a slot: increments (iters x 6), cost at the
+ * candidate (iters), accepted flags (iters).  Returns the number of iterations (<= max_iters) or <0. */
+int eds_trk_get_trace(eds_trk* h, int slot, int max_iters, double* increments, double* costs, int32_t* accepted);
+
+/* ---- outputs ---------------------------------------------------------------------------- */
+/* kf->residuals after the solve (Tracker.cpp:223-230), N entries. */
+int eds_trk_get_residuals(eds_trk* h, int slot, double* r);
+/* Tracker::getLossParams (Tracker.cpp:281-317) on the stored residuals; `tau` in/out
+ * (CONSTANT leaves it).  Like the reference, MAD partially reorders the stored residuals. */
+int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
+int eds_trk_timer_start(eds_trk* h);
+int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the stream */
+/* Launches the residual/Jacobian kernel (and optionally the reduction kernel) over slots
+ * [first, first+count) `reps` times back-to-back at the stored states and reports the mean
+ * duration per launch in ms, measured with HIP events on the handle's stream. */
+int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDS_HIP_H_ */

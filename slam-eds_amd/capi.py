@@ -1,0 +1,288 @@
+"""ctypes binding of the C-ABI library ``csrc/libeds_hip.so`` (header: ``include/eds_hip.h``).
+
+This is plumbing only: every number is produced by the HIP kernels behind the C ABI.
+There is no CPU fallback — if the library is missing or no GPU is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libeds_hip.so")
+
+# enums of include/eds_hip.h
+EDS_OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOT_USABLE, ERR_STATE, ERR_NO_DEVICE = -1, -2, -3, -4, -5
+SAMPLE_BICUBIC, SAMPLE_BILINEAR = 0, 1
+SOLVER_GN6, SOLVER_LM6, SOLVER_REF12 = 0, 1, 2
+EXEC_HOST, EXEC_DEVICE = 0, 1
+LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2
+LP_CONSTANT, LP_MAD, LP_STD = 0, 1, 2
+MAX_LEVELS = 8
+
+# every symbol include/eds_hip.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "eds_abi_version", "eds_device_count", "eds_last_error", "eds_trk_cfg_default",
+    "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
+    "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
+    "eds_trk_set_state", "eds_trk_get_state", "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
+    "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
+    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
+)
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class Cfg(C.Structure):
+    """``eds_trk_cfg`` — mirrors eds::tracking::Config (reference tracking/Config.hpp:40-58)."""
+    _fields_ = [("device", C.c_int32), ("sampling", C.c_int32), ("solver", C.c_int32), ("exec", C.c_int32),
+                ("num_blocks", C.c_int32), ("loss_type", C.c_int32), ("loss_param", C.c_double),
+                ("huber_tau", C.c_double), ("lambda0", C.c_double), ("num_levels", C.c_int32),
+                ("max_num_iterations", C.c_int32 * MAX_LEVELS), ("function_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("nc", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class Info(C.Structure):
+    """``eds_trk_info`` — mirrors eds::tracking::TrackerInfo (reference tracking/Config.hpp:60-68)."""
+    _fields_ = [("meas_time_us", C.c_double), ("num_points", C.c_uint32), ("num_iterations", C.c_int32),
+                ("time_seconds", C.c_double), ("success", C.c_uint8), ("pad_", C.c_uint8 * 3),
+                ("termination", C.c_int32), ("num_successful_steps", C.c_int32),
+                ("num_unsuccessful_steps", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("device_time_us", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
+class EdsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libeds_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile libeds_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "eds_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j4", "-s", "libeds_hip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads the library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EdsError(ERR_NO_DEVICE, f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        L = C.CDLL(LIB_PATH)
+        L.eds_last_error.restype = C.c_char_p
+        L.eds_trk_create.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.eds_trk_destroy.argtypes = [C.c_void_p]
+        L.eds_trk_destroy.restype = None
+        L.eds_trk_cfg_default.argtypes = [C.POINTER(Cfg)]
+        L.eds_trk_cfg_default.restype = None
+        L.eds_trk_set_config.argtypes = [C.c_void_p, C.POINTER(Cfg)]
+        L.eds_trk_get_config.argtypes = [C.c_void_p, C.POINTER(Cfg)]
+        L.eds_trk_set_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
+                                           C.c_double, C.c_double]
+        L.eds_trk_set_idepth.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        L.eds_trk_set_event_frame.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.eds_trk_set_event_frame_f32.argtypes = [C.c_void_p, C.c_int, _fp]
+        L.eds_trk_set_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_get_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_eval.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.eds_trk_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Info)]
+        L.eds_trk_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.eds_trk_sync.argtypes = [C.c_void_p]
+        L.eds_trk_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(Info)]
+        L.eds_trk_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip]
+        L.eds_trk_get_residuals.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.eds_trk_loss_param.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        L.eds_trk_timer_start.argtypes = [C.c_void_p]
+        L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
+        L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().eds_last_error() or b"").decode()
+
+
+def _check(rc):
+    if rc != EDS_OK:
+        raise EdsError(rc, last_error())
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def default_config(**kw) -> Cfg:
+    cfg = Cfg()
+    lib().eds_trk_cfg_default(C.byref(cfg))
+    for k, v in kw.items():
+        if k == "max_num_iterations":
+            v = [int(v)] * MAX_LEVELS if np.isscalar(v) else list(v) + [list(v)[-1]] * (MAX_LEVELS - len(v))
+            cfg.max_num_iterations = (C.c_int32 * MAX_LEVELS)(*v[:MAX_LEVELS])
+        else:
+            setattr(cfg, k, v)
+    return cfg
+
+
+class Handle:
+    """RAII wrapper of ``eds_trk*``: ``batch`` alignment slots on one GPU / one HIP stream."""
+
+    def __init__(self, cfg: Cfg, batch: int, max_points: int, H: int, W: int):
+        self._h = C.c_void_p()
+        self.batch, self.max_points, self.H, self.W = int(batch), int(max_points), int(H), int(W)
+        _check(lib().eds_trk_create(C.byref(cfg), self.batch, self.max_points, self.H, self.W, C.byref(self._h)))
+        self._N = [0] * self.batch
+
+    def close(self):
+        if self._h:
+            lib().eds_trk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration -------------------------------------------------------------------
+    def set_config(self, cfg: Cfg):
+        _check(lib().eds_trk_set_config(self._h, C.byref(cfg)))
+
+    def get_config(self) -> Cfg:
+        cfg = Cfg()
+        _check(lib().eds_trk_get_config(self._h, C.byref(cfg)))
+        return cfg
+
+    # -- inputs --------------------------------------------------------------------------
+    def set_keyframe(self, slot, norm_coord, grad, idp, weights, fx, fy, cx, cy):
+        nc, g, d, w = _f64(norm_coord), _f64(grad), _f64(idp), _f64(weights)
+        N = int(d.shape[0])
+        if nc.shape != (N, 2) or g.shape != (N, 2) or w.shape != (N,):
+            raise EdsError(ERR_INVALID, "keyframe arrays have inconsistent shapes")
+        _check(lib().eds_trk_set_keyframe(self._h, slot, N, _p(nc), _p(g), _p(d), _p(w), fx, fy, cx, cy))
+        self._N[slot] = N
+
+    def set_alignment(self, slot, al):
+        """Convenience: upload an ``Alignment`` (synth.py) and seed its start state."""
+        self.set_keyframe(slot, al.norm_coord, al.grad, al.idp, al.weights, al.fx, al.fy, al.cx, al.cy)
+        self.set_event_frame(slot, al.frame)
+        self.set_state(slot, al.p0, al.q0, al.v0)
+
+    def set_idepth(self, slot, idp):
+        d = _f64(idp)
+        _check(lib().eds_trk_set_idepth(self._h, slot, int(d.shape[0]), _p(d)))
+
+    def set_event_frame(self, slot, frame):
+        fr = np.asarray(frame)
+        if fr.size != self.H * self.W:
+            raise EdsError(ERR_INVALID, "event frame size != H*W")
+        if fr.dtype == np.float32:
+            fr = np.ascontiguousarray(fr)
+            _check(lib().eds_trk_set_event_frame_f32(self._h, slot, fr.ctypes.data_as(_fp)))
+        else:
+            fr = _f64(fr)
+            _check(lib().eds_trk_set_event_frame(self._h, slot, _p(fr)))
+
+    def set_state(self, slot, p=None, q=None, v=None):
+        p = None if p is None else _f64(p)
+        q = None if q is None else _f64(q)
+        v = None if v is None else _f64(v)
+        _check(lib().eds_trk_set_state(self._h, slot, _p(p), _p(q), _p(v)))
+
+    def get_state(self, slot):
+        p, q, v = np.zeros(3), np.zeros(4), np.zeros(6)
+        _check(lib().eds_trk_get_state(self._h, slot, _p(p), _p(q), _p(v)))
+        return p, q, v
+
+    # -- evaluation / solve --------------------------------------------------------------
+    def eval(self, slot, p, q, v, ncols=6, want_jacobian=True):
+        N = self._N[slot]
+        p, q, v = _f64(p), _f64(q), _f64(v)
+        r = np.zeros(N)
+        J = np.zeros((N, ncols)) if want_jacobian else None
+        JtJ, Jtr, cost = np.zeros((ncols, ncols)), np.zeros(ncols), C.c_double(0.0)
+        _check(lib().eds_trk_eval(self._h, slot, _p(p), _p(q), _p(v), ncols, _p(r), _p(J), _p(JtJ), _p(Jtr),
+                                  C.cast(C.byref(cost), _dp)))
+        return dict(r=r, J=J, JtJ=JtJ, Jtr=Jtr, cost=cost.value)
+
+    def optimize(self, slot, level=0, p=None, q=None, v=None):
+        """Tracker::optimize for one slot.  Returns (p, q, v, info dict); raises EdsError(ERR_NOT_USABLE)."""
+        sp, sq, sv = self.get_state(slot)
+        p = sp if p is None else _f64(p).copy()
+        q = sq if q is None else _f64(q).copy()
+        v = sv if v is None else _f64(v).copy()
+        info = Info()
+        _check(lib().eds_trk_optimize(self._h, slot, level, _p(p), _p(q), _p(v), C.byref(info)))
+        return p, q, v, info.as_dict()
+
+    def optimize_batch(self, level=0, first=0, count=None, sync=True):
+        count = self.batch - first if count is None else count
+        _check(lib().eds_trk_optimize_batch(self._h, level, first, count))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _check(lib().eds_trk_sync(self._h))
+
+    def info(self, slot):
+        info = Info()
+        _check(lib().eds_trk_get_info(self._h, slot, C.byref(info)))
+        return info.as_dict()
+
+    def trace(self, slot, max_iters=128):
+        inc, cost, acc = np.zeros((max_iters, 6)), np.zeros(max_iters), np.zeros(max_iters, dtype=np.int32)
+        n = lib().eds_trk_get_trace(self._h, slot, max_iters, _p(inc), _p(cost), acc.ctypes.data_as(_ip))
+        if n < 0:
+            _check(n)
+        return dict(increments=inc[:n], costs=cost[:n], accepted=acc[:n])
+
+    def residuals(self, slot):
+        r = np.zeros(self._N[slot])
+        _check(lib().eds_trk_get_residuals(self._h, slot, _p(r)))
+        return r
+
+    def loss_param(self, slot, method, current=0.0):
+        tau = C.c_double(current)
+        _check(lib().eds_trk_loss_param(self._h, slot, int(method), C.cast(C.byref(tau), _dp)))
+        return tau.value
+
+    # -- measurement ---------------------------------------------------------------------
+    def timer_start(self):
+        _check(lib().eds_trk_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float(0.0)
+        _check(lib().eds_trk_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def bench_eval(self, first, count, ncols=6, with_reduction=False, reps=20) -> float:
+        ms = C.c_float(0.0)
+        _check(lib().eds_trk_bench_eval(self._h, first, count, ncols, int(with_reduction), reps, C.byref(ms)))
+        return ms.value
+
+
+def device_count() -> int:
+    return int(lib().eds_device_count())

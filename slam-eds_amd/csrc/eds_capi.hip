@@ -1,0 +1,760 @@
+// C ABI of libeds_hip.so (include/eds_hip.h): handle management, host<->HBM staging and the
+// host-driven solve loop (EDS_EXEC_HOST).  The persistent on-device loop lives in eds_fused.hip.
+//
+// Replaces, for the hot path only, reference src/tracking/Tracker.cpp:40-102 (state handling),
+// :104-241 (optimize) and :281-317 (getLossParams).  There is deliberately NO CPU fallback:
+// without a HIP device every entry point fails with EDS_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/eds_hip.h"
+#include "eds_fused.hpp"
+#include "eds_handle.hpp"
+#include "eds_kernels.hpp"
+#include "eds_math.hpp"
+#include "eds_solver.hpp"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) { g_last_error = msg; return code; }
+
+#define EDS_HIP_TRY(expr)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(EDS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+}  // namespace
+
+namespace {
+
+int effective_blocks(const eds_trk* h) {
+    int nb = h->cfg.num_blocks;
+    if (nb < 1) nb = 1;
+    if (nb > EDS_MAX_BLOCKS) nb = EDS_MAX_BLOCKS;
+    return nb;
+}
+int level_iters(const eds_trk* h, int level) {
+    if (level < 0) level = 0;
+    if (level >= EDS_MAX_LEVELS) level = EDS_MAX_LEVELS - 1;
+    return h->cfg.max_num_iterations[level];
+}
+
+int check_slot(const eds_trk* h, int slot) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (slot < 0 || slot >= h->B) return fail(EDS_ERR_INVALID, "slot out of range");
+    return EDS_OK;
+}
+
+// constants of a slot's pose block that do not depend on (p,q,v)
+void fill_static(const eds_trk* h, int slot) {
+    const Slot& s = h->slots[slot];
+    double* pb = h->h_pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int nb = effective_blocks(h);
+    for (int i = 0; i < 4; ++i) pb[EDS_PB_K + i] = s.K[i];
+    pb[EDS_PB_HUBER] = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
+    pb[EDS_PB_NB] = nb;
+    pb[EDS_PB_NE] = s.N / nb;
+    pb[EDS_PB_N] = s.N;
+}
+
+void fill_pose(const eds_trk* h, int slot, const double* p, const double* q, const double* v) {
+    fill_static(h, slot);
+    edsm::fill_pose_block(p, q, v, h->h_G + (size_t)slot * EDS_MAX_BLOCKS * 36, effective_blocks(h),
+                          h->h_pose + (size_t)slot * EDS_POSE_STRIDE);
+}
+
+int upload_pose(eds_trk* h, int first, int count) {
+    EDS_HIP_TRY(hipMemcpyAsync(h->dpose + (size_t)first * EDS_POSE_STRIDE, h->h_pose + (size_t)first * EDS_POSE_STRIDE,
+                               sizeof(double) * EDS_POSE_STRIDE * count, hipMemcpyHostToDevice, h->st));
+    return EDS_OK;
+}
+
+int max_points(const eds_trk* h, int first, int count) {
+    int m = 0;
+    for (int s = first; s < first + count; ++s) m = std::max(m, h->slots[s].N);
+    return m;
+}
+
+// geometry of the reduction grid for `count` slots with at most N points each
+void reduce_geometry(int N, int nb_red, int* cpb, int* nseg) {
+    const int ne = N / nb_red;
+    const int last = ne + (N - nb_red * ne);
+    *cpb = std::max(1, (last + EDS_TPB - 1) / EDS_TPB);
+    *nseg = nb_red * (*cpb);
+}
+
+// One residual/Jacobian pass + reduction over slots [first, first+count) at the poses currently
+// in h_pose; brings the partial sums back to h_part.
+int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bool with_reduction, bool fetch) {
+    const EdsArrays A = h->arrays();
+    const int N = max_points(h, first, count);
+    if (N <= 0) return fail(EDS_ERR_STATE, "no keyframe set");
+    const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
+    int rc = upload_pose(h, first, count);
+    if (rc) return rc;
+    if (refresh_model && ncols == 6) eds_launch_model(A, first, count, nchunk, h->st);
+    eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
+    if (with_reduction) {
+        const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
+        int cpb, nseg;
+        reduce_geometry(N, nb_red, &cpb, &nseg);
+        if (nseg > h->max_seg) return fail(EDS_ERR_INVALID, "reduction grid exceeds allocation");
+        eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st);
+        if (fetch)
+            EDS_HIP_TRY(hipMemcpyAsync(h->h_part + (size_t)first * h->max_seg * EDS_RED_K,
+                                       h->dpart + (size_t)first * h->max_seg * EDS_RED_K,
+                                       sizeof(double) * h->max_seg * EDS_RED_K * count, hipMemcpyDeviceToHost, h->st));
+    }
+    EDS_HIP_TRY(hipGetLastError());
+    if (fetch) EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    return EDS_OK;
+}
+
+// sums of a slot after run_pass (host side, fp64)
+void gather6(const eds_trk* h, int slot, edss::Sums6* S) {
+    int cpb, nseg;
+    reduce_geometry(h->slots[slot].N, 1, &cpb, &nseg);
+    // NB: the grid was sized for the max N of the range; segments beyond this slot's own are all-zero
+    double rec[EDS_RED_N6];
+    for (int i = 0; i < EDS_RED_N6; ++i) rec[i] = 0.0;
+    const double* base = h->h_part + (size_t)slot * h->max_seg * EDS_RED_K;
+    for (int s = 0; s < nseg; ++s)
+        for (int i = 0; i < EDS_RED_N6; ++i) rec[i] += base[(size_t)s * EDS_RED_K + i];
+    edss::unpack6(rec, S);
+}
+void gather12(const eds_trk* h, int slot, int range_max_N, edss::Sums12* S) {
+    const int nb = effective_blocks(h);
+    int cpb, nseg;
+    reduce_geometry(range_max_N, nb, &cpb, &nseg);
+    S->nb = nb;
+    const double* base = h->h_part + (size_t)slot * h->max_seg * EDS_RED_K;
+    for (int k = 0; k < nb; ++k)
+        for (int c = 0; c < cpb; ++c) edss::unpack12_add(base + (size_t)(k * cpb + c) * EDS_RED_K, S, k, c == 0);
+}
+
+int fetch_residuals(eds_trk* h, int first, int count) {
+    EDS_HIP_TRY(hipMemcpyAsync(h->h_r + (size_t)first * h->Np, h->dr + (size_t)first * h->Np,
+                               sizeof(float) * h->Np * count, hipMemcpyDeviceToHost, h->st));
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    for (int s = first; s < first + count; ++s) {
+        Slot& sl = h->slots[s];
+        sl.residuals.resize(sl.N);
+        const float* r = h->h_r + (size_t)s * h->Np;
+        for (int i = 0; i < sl.N; ++i) sl.residuals[i] = r[i];
+    }
+    return EDS_OK;
+}
+
+void store_trace(Slot& sl, const edss::Solver6& sv) {
+    sl.ntrace = sv.ntrace;
+    sl.tr_xi.assign(&sv.tr_xi[0][0], &sv.tr_xi[0][0] + 6 * sv.ntrace);
+    sl.tr_cost.assign(sv.tr_cost, sv.tr_cost + sv.ntrace);
+    sl.tr_acc.assign(sv.tr_acc, sv.tr_acc + sv.ntrace);
+}
+
+// Host-driven lockstep solve of slots [first, first+count).
+int solve_host(eds_trk* h, int level, int first, int count) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int iters = level_iters(h, level);
+    const bool ref12 = h->cfg.solver == EDS_SOLVER_REF12;
+    for (int s = first; s < first + count; ++s)
+        if (!h->slots[s].has_kf || !h->slots[s].has_frame) return fail(EDS_ERR_STATE, "keyframe or event frame not set");
+    const int rangeN = max_points(h, first, count);
+    std::vector<char> active(count, 1);
+    int nactive = count, rc = EDS_OK;
+    bool first_pass = true;
+    if (!ref12) {
+        std::vector<edss::Solver6> sv(count);
+        for (int i = 0; i < count; ++i) {
+            Slot& sl = h->slots[first + i];
+            sv[i].init(h->cfg.solver == EDS_SOLVER_LM6, iters, h->cfg.lambda0, sl.p, sl.q);
+            fill_pose(h, first + i, sv[i].cp, sv[i].cq, sl.v);
+        }
+        while (nactive > 0) {
+            if ((rc = run_pass(h, first, count, 6, first_pass, true, true))) return rc;
+            first_pass = false;
+            for (int i = 0; i < count; ++i) {
+                if (!active[i]) continue;
+                edss::Sums6 S;
+                gather6(h, first + i, &S);
+                sv[i].on_eval(S);
+                if (sv[i].done) { active[i] = 0; --nactive; }
+                else fill_pose(h, first + i, sv[i].cp, sv[i].cq, h->slots[first + i].v);
+            }
+        }
+        if ((rc = fetch_residuals(h, first, count))) return rc;
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int i = 0; i < count; ++i) {
+            Slot& sl = h->slots[first + i];
+            const bool ok = !sv[i].failed;
+            if (ok) { std::memcpy(sl.p, sv[i].p, sizeof(sl.p)); std::memcpy(sl.q, sv[i].q, sizeof(sl.q)); }
+            store_trace(sl, sv[i]);
+            sl.res_on_device = false; sl.trace_on_device = false;
+            eds_trk_info& in = sl.info;
+            std::memset(&in, 0, sizeof(in));
+            in.meas_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+            in.time_seconds = in.meas_time_us * 1e-6;
+            in.num_points = sl.N;
+            in.num_iterations = sv[i].iter;
+            in.success = ok;
+            in.termination = ok ? edss::TERM_NO_CONVERGENCE : edss::TERM_FAILURE;
+            in.num_successful_steps = 0;
+            for (int k = 0; k < sv[i].ntrace; ++k) in.num_successful_steps += sv[i].tr_acc[k];
+            in.num_unsuccessful_steps = sv[i].ntrace - in.num_successful_steps;
+            in.initial_cost = 0.5 * sv[i].initial_cost;
+            in.final_cost = 0.5 * sv[i].final_cost;
+        }
+        return EDS_OK;
+    }
+    // reference problem: Ceres-style LM over 12 local parameters
+    std::vector<edss::Solver12> sv(count);
+    std::vector<edss::Sums12>* S = new (std::nothrow) std::vector<edss::Sums12>(1);
+    if (!S) return fail(EDS_ERR_INVALID, "out of memory");
+    for (int i = 0; i < count; ++i) {
+        Slot& sl = h->slots[first + i];
+        sv[i].init(iters, h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,
+                   h->cfg.parameter_tolerance, sl.p, sl.q, sl.v);
+        fill_pose(h, first + i, sv[i].cp, sv[i].cq, sv[i].cv);
+    }
+    while (nactive > 0) {
+        if ((rc = run_pass(h, first, count, 12, false, true, true))) { delete S; return rc; }
+        for (int i = 0; i < count; ++i) {
+            if (!active[i]) continue;
+            gather12(h, first + i, rangeN, &(*S)[0]);
+            sv[i].on_eval((*S)[0]);
+            if (sv[i].done) { active[i] = 0; --nactive; }
+            else fill_pose(h, first + i, sv[i].cp, sv[i].cq, sv[i].cv);
+        }
+    }
+    delete S;
+    if ((rc = fetch_residuals(h, first, count))) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int i = 0; i < count; ++i) {
+        Slot& sl = h->slots[first + i];
+        const bool ok = sv[i].termination != edss::TERM_FAILURE;
+        if (ok) {
+            std::memcpy(sl.p, sv[i].best_p, sizeof(sl.p)); std::memcpy(sl.q, sv[i].best_q, sizeof(sl.q));
+            std::memcpy(sl.v, sv[i].best_v, sizeof(sl.v));
+        } else {
+            sl.residuals.clear();
+        }
+        sl.ntrace = 0;
+        sl.res_on_device = false; sl.trace_on_device = false;
+        eds_trk_info& in = sl.info;
+        std::memset(&in, 0, sizeof(in));
+        in.meas_time_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        in.time_seconds = in.meas_time_us * 1e-6;
+        in.num_points = sl.N;
+        in.num_successful_steps = sv[i].num_successful;
+        in.num_unsuccessful_steps = sv[i].num_unsuccessful;
+        in.num_iterations = sv[i].num_successful + sv[i].num_unsuccessful;   // Tracker.cpp:211
+        in.success = ok;
+        in.termination = sv[i].termination;
+        in.initial_cost = sv[i].initial_cost;
+        in.final_cost = sv[i].minimum_cost;
+    }
+    return EDS_OK;
+}
+
+// residuals of a device-mode solve stay in HBM until somebody asks for them
+int materialise_residuals(eds_trk* h, int slot) {
+    Slot& s = h->slots[slot];
+    if (!s.res_on_device) return EDS_OK;
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    int rc = fetch_residuals(h, slot, 1);
+    if (rc) return rc;
+    s.res_on_device = false;
+    return EDS_OK;
+}
+
+void free_all(eds_trk* h) {
+    if (!h) return;
+    hipSetDevice(h->dev);
+    void* dptrs[] = {h->dX, h->dY, h->dZ, h->dpose, h->dG, h->dpart, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
+                     h->dmhat, h->dframe, h->dr, h->dJ};
+    for (void* p : dptrs) if (p) hipFree(p);
+    eds_fused_free(&h->fused);
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f64, h->h_f32, h->h_r};
+    for (void* p : hptrs) if (p) hipHostFree(p);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->st) hipStreamDestroy(h->st);
+    delete h;
+}
+
+}  // namespace
+
+int eds_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
+int eds_internal_solve_host(eds_trk* h, int level, int first, int count) { return solve_host(h, level, first, count); }
+
+extern "C" {
+
+int eds_abi_version(void) { return EDS_HIP_ABI_VERSION; }
+
+int eds_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* eds_last_error(void) { return g_last_error.c_str(); }
+
+void eds_trk_cfg_default(eds_trk_cfg* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0;
+    cfg->sampling = EDS_SAMPLE_BICUBIC;
+    cfg->solver = EDS_SOLVER_LM6;
+    cfg->exec = EDS_EXEC_DEVICE;
+    cfg->num_blocks = 1;
+    cfg->loss_type = EDS_LOSS_NONE;
+    cfg->loss_param = 1.0;
+    cfg->huber_tau = 0.0;
+    cfg->lambda0 = 0.01;
+    cfg->num_levels = 1;
+    for (int i = 0; i < EDS_MAX_LEVELS; ++i) cfg->max_num_iterations[i] = 10;
+    cfg->function_tolerance = 1e-6;
+    cfg->gradient_tolerance = 1e-8;
+    cfg->parameter_tolerance = 1e-6;
+}
+
+int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, int W, eds_trk** out) {
+    if (!cfg || !out) return fail(EDS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (batch < 1 || max_points_ < 1 || H < 4 || W < 4) return fail(EDS_ERR_INVALID, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(EDS_ERR_NO_DEVICE, "no HIP device visible; libeds_hip has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(EDS_ERR_INVALID, "device ordinal out of range");
+    eds_trk* h = new (std::nothrow) eds_trk();
+    if (!h) return fail(EDS_ERR_INVALID, "out of memory");
+    h->cfg = *cfg;
+    h->B = batch; h->Nmax = max_points_; h->H = H; h->W = W; h->dev = cfg->device;
+    h->Np = ((max_points_ + EDS_POINT_ALIGN - 1) / EDS_POINT_ALIGN) * EDS_POINT_ALIGN;
+    h->max_seg = h->Np / EDS_TPB + 2 * EDS_MAX_BLOCKS + 2;
+    h->slots.resize(batch);
+    for (Slot& s : h->slots) {                       // Tracker ctor, Tracker.cpp:43-46
+        const double c = 0.001 / std::sqrt(6.0 * 0.001 * 0.001);
+        for (int i = 0; i < 6; ++i) s.v[i] = c;
+        std::memset(&s.info, 0, sizeof(s.info));
+    }
+    const size_t BN = (size_t)batch * h->Np;
+#define EDS_ALLOC(ptr, bytes)                                                                  \
+    do {                                                                                       \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                    \
+        if (e_ != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } \
+    } while (0)
+#define EDS_HALLOC(ptr, bytes)                                                                 \
+    do {                                                                                       \
+        hipError_t e_ = hipHostMalloc((void**)&(ptr), (bytes), hipHostMallocDefault);          \
+        if (e_ != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e_)); } \
+    } while (0)
+    hipError_t e = hipSetDevice(h->dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("stream/event: ") + hipGetErrorString(e)); }
+    EDS_ALLOC(h->dX, BN * 8); EDS_ALLOC(h->dY, BN * 8); EDS_ALLOC(h->dZ, BN * 8);
+    EDS_ALLOC(h->dx, BN * 4); EDS_ALLOC(h->dy, BN * 4); EDS_ALLOC(h->drho, BN * 4);
+    EDS_ALLOC(h->dgx, BN * 4); EDS_ALLOC(h->dgy, BN * 4); EDS_ALLOC(h->dw, BN * 4);
+    EDS_ALLOC(h->dmhat, BN * 4); EDS_ALLOC(h->dr, BN * 4); EDS_ALLOC(h->dJ, BN * 4 * 12);
+    EDS_ALLOC(h->dframe, (size_t)batch * H * W * 4);
+    EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);
+    EDS_ALLOC(h->dG, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
+    EDS_ALLOC(h->dpart, (size_t)batch * h->max_seg * EDS_RED_K * 8);
+    EDS_HALLOC(h->h_pose, (size_t)batch * EDS_POSE_STRIDE * 8);
+    EDS_HALLOC(h->h_part, (size_t)batch * h->max_seg * EDS_RED_K * 8);
+    EDS_HALLOC(h->h_G, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
+    EDS_HALLOC(h->h_f64, (size_t)h->Np * 3 * 8);
+    h->h_f32_elems = std::max((size_t)H * W, (size_t)h->Np * 12);
+    EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
+    EDS_HALLOC(h->h_r, BN * 4);
+    std::memset(h->h_pose, 0, (size_t)batch * EDS_POSE_STRIDE * 8);
+    std::memset(h->h_G, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
+    hipMemsetAsync(h->dX, 0, BN * 8, h->st); hipMemsetAsync(h->dY, 0, BN * 8, h->st);
+    {   // Z = 1 keeps padded lanes finite
+        std::vector<double> ones(h->Np, 1.0);
+        for (int b = 0; b < batch; ++b) hipMemcpy(h->dZ + (size_t)b * h->Np, ones.data(), (size_t)h->Np * 8, hipMemcpyHostToDevice);
+    }
+    float* f32s[] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw, h->dmhat, h->dr};
+    for (float* p : f32s) hipMemsetAsync(p, 0, BN * 4, h->st);
+    hipMemsetAsync(h->dJ, 0, BN * 4 * 12, h->st);
+    hipMemsetAsync(h->dframe, 0, (size_t)batch * H * W * 4, h->st);
+    hipMemsetAsync(h->dpose, 0, (size_t)batch * EDS_POSE_STRIDE * 8, h->st);
+    hipMemsetAsync(h->dG, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8, h->st);
+    hipMemsetAsync(h->dpart, 0, (size_t)batch * h->max_seg * EDS_RED_K * 8, h->st);
+    int rc = eds_fused_alloc(&h->fused, batch);
+    if (rc != 0) { free_all(h); return fail(EDS_ERR_HIP, "fused buffers: hipMalloc failed"); }
+    e = hipStreamSynchronize(h->st);
+    if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("init: ") + hipGetErrorString(e)); }
+    *out = h;
+    return EDS_OK;
+#undef EDS_ALLOC
+#undef EDS_HALLOC
+}
+
+void eds_trk_destroy(eds_trk* h) { free_all(h); }
+
+int eds_trk_set_config(eds_trk* h, const eds_trk_cfg* cfg) {
+    if (!h || !cfg) return fail(EDS_ERR_INVALID, "null argument");
+    if (cfg->device != h->cfg.device) return fail(EDS_ERR_INVALID, "device cannot change after create");
+    const bool blocks_changed = cfg->num_blocks != h->cfg.num_blocks;
+    h->cfg = *cfg;
+    if (blocks_changed) {               // Gram matrices are per residual block
+        for (int s = 0; s < h->B; ++s) {
+            if (!h->slots[s].has_kf) continue;
+            fill_static(h, s);
+            int rc = upload_pose(h, s, 1);
+            if (rc) return rc;
+            eds_launch_gram(h->arrays(), s, effective_blocks(h), h->st);
+        }
+        EDS_HIP_TRY(hipMemcpyAsync(h->h_G, h->dG, (size_t)h->B * EDS_MAX_BLOCKS * 36 * 8, hipMemcpyDeviceToHost, h->st));
+        EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    }
+    return EDS_OK;
+}
+
+int eds_trk_get_config(const eds_trk* h, eds_trk_cfg* cfg) {
+    if (!h || !cfg) return fail(EDS_ERR_INVALID, "null argument");
+    *cfg = h->cfg;
+    return EDS_OK;
+}
+
+static int upload_points(eds_trk* h, int slot, int N, const double* norm_xy, const double* grad_xy, const double* idp,
+                         const double* w) {
+    const size_t off = (size_t)slot * h->Np;
+    // back-projection kp = (x/rho', y/rho', 1/rho'), rho' = idp + 1e-5 (PhotometricError.hpp:95-106)
+    double* X = h->h_f64; double* Y = X + h->Np; double* Z = Y + h->Np;
+    float* f = h->h_f32;
+    for (int i = 0; i < h->Np; ++i) {
+        if (i < N) {
+            const double z = 1.0 / (idp[i] + 1e-5);
+            X[i] = norm_xy[2 * i] * z; Y[i] = norm_xy[2 * i + 1] * z; Z[i] = z;
+        } else { X[i] = 0.0; Y[i] = 0.0; Z[i] = 1.0; }
+    }
+    EDS_HIP_TRY(hipMemcpyAsync(h->dX + off, X, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
+    EDS_HIP_TRY(hipMemcpyAsync(h->dY + off, Y, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
+    EDS_HIP_TRY(hipMemcpyAsync(h->dZ + off, Z, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
+    const int Np = h->Np;
+    for (int i = 0; i < Np; ++i) {
+        const bool in = i < N;
+        f[0 * Np + i] = in ? (float)norm_xy[2 * i] : 0.f;
+        f[1 * Np + i] = in ? (float)norm_xy[2 * i + 1] : 0.f;
+        f[2 * Np + i] = in ? (float)idp[i] : 0.f;
+        if (grad_xy) { f[3 * Np + i] = in ? (float)grad_xy[2 * i] : 0.f; f[4 * Np + i] = in ? (float)grad_xy[2 * i + 1] : 0.f; }
+        if (w) f[5 * Np + i] = in ? (float)w[i] : 0.f;
+    }
+    float* dst[6] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw};
+    for (int k = 0; k < 6; ++k) {
+        if ((k == 3 || k == 4) && !grad_xy) continue;
+        if (k == 5 && !w) continue;
+        EDS_HIP_TRY(hipMemcpyAsync(dst[k] + off, f + (size_t)k * Np, (size_t)Np * 4, hipMemcpyHostToDevice, h->st));
+    }
+    return EDS_OK;
+}
+
+static int refresh_gram(eds_trk* h, int slot) {
+    fill_static(h, slot);
+    int rc = upload_pose(h, slot, 1);
+    if (rc) return rc;
+    eds_launch_gram(h->arrays(), slot, effective_blocks(h), h->st);
+    EDS_HIP_TRY(hipGetLastError());
+    const size_t off = (size_t)slot * EDS_MAX_BLOCKS * 36;
+    EDS_HIP_TRY(hipMemcpyAsync(h->h_G + off, h->dG + off, (size_t)EDS_MAX_BLOCKS * 36 * 8, hipMemcpyDeviceToHost, h->st));
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    return EDS_OK;
+}
+
+int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, const double* grad_xy, const double* idp,
+                         const double* w, double fx, double fy, double cx, double cy) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (N < 1 || N > h->Nmax) return fail(EDS_ERR_INVALID, "N out of range for this handle");
+    if (!norm_xy || !grad_xy || !idp || !w) return fail(EDS_ERR_INVALID, "null keyframe array");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    Slot& s = h->slots[slot];
+    s.N = N; s.K[0] = fx; s.K[1] = fy; s.K[2] = cx; s.K[3] = cy;
+    if ((rc = upload_points(h, slot, N, norm_xy, grad_xy, idp, w))) return rc;
+    if ((rc = refresh_gram(h, slot))) return rc;
+    s.has_kf = true;
+    s.residuals.clear();
+    return EDS_OK;
+}
+
+int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    Slot& s = h->slots[slot];
+    if (!s.has_kf) return fail(EDS_ERR_STATE, "keyframe not set");
+    if (N != s.N || !idp) return fail(EDS_ERR_INVALID, "idp size mismatch");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    // need x,y back: they are resident as fp32 only, so re-read the fp64 X/Z ratio-free form from the device
+    std::vector<double> X(h->Np), Y(h->Np), Z(h->Np), nxy((size_t)2 * N);
+    const size_t off = (size_t)slot * h->Np;
+    EDS_HIP_TRY(hipMemcpy(X.data(), h->dX + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
+    EDS_HIP_TRY(hipMemcpy(Y.data(), h->dY + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
+    EDS_HIP_TRY(hipMemcpy(Z.data(), h->dZ + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) { nxy[2 * i] = X[i] / Z[i]; nxy[2 * i + 1] = Y[i] / Z[i]; }
+    if ((rc = upload_points(h, slot, N, nxy.data(), nullptr, idp, nullptr))) return rc;
+    return refresh_gram(h, slot);
+}
+
+int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!frame) return fail(EDS_ERR_INVALID, "null frame");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    const size_t n = (size_t)h->H * h->W;
+    for (size_t i = 0; i < n; ++i) h->h_f32[i] = (float)frame[i];
+    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    h->slots[slot].has_frame = true;
+    return EDS_OK;
+}
+
+int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!frame) return fail(EDS_ERR_INVALID, "null frame");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    const size_t n = (size_t)h->H * h->W;
+    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, frame, n * 4, hipMemcpyHostToDevice, h->st));
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    h->slots[slot].has_frame = true;
+    return EDS_OK;
+}
+
+int eds_trk_set_state(eds_trk* h, int slot, const double p[3], const double q[4], const double v[6]) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    Slot& s = h->slots[slot];
+    if (p) std::memcpy(s.p, p, sizeof(s.p));
+    if (q) std::memcpy(s.q, q, sizeof(s.q));
+    if (v) std::memcpy(s.v, v, sizeof(s.v));
+    return EDS_OK;
+}
+
+int eds_trk_get_state(eds_trk* h, int slot, double p[3], double q[4], double v[6]) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    const Slot& s = h->slots[slot];
+    if (p) std::memcpy(p, s.p, sizeof(s.p));
+    if (q) std::memcpy(q, s.q, sizeof(s.q));
+    if (v) std::memcpy(v, s.v, sizeof(s.v));
+    return EDS_OK;
+}
+
+int eds_trk_eval(eds_trk* h, int slot, const double p[3], const double q[4], const double v[6], int ncols, double* r,
+                 double* J, double* JtJ, double* Jtr, double* cost) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (ncols != 6 && ncols != 12) return fail(EDS_ERR_INVALID, "ncols must be 6 or 12");
+    if (!p || !q || !v) return fail(EDS_ERR_INVALID, "null state");
+    Slot& s = h->slots[slot];
+    if (!s.has_kf || !s.has_frame) return fail(EDS_ERR_STATE, "keyframe or event frame not set");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    fill_pose(h, slot, p, q, v);
+    if ((rc = run_pass(h, slot, 1, ncols, true, true, true))) return rc;
+    const int N = s.N;
+    if (r) {
+        EDS_HIP_TRY(hipMemcpy(h->h_r + (size_t)slot * h->Np, h->dr + (size_t)slot * h->Np, (size_t)N * 4, hipMemcpyDeviceToHost));
+        const float* src = h->h_r + (size_t)slot * h->Np;
+        for (int i = 0; i < N; ++i) r[i] = src[i];
+    }
+    if (J) {
+        const size_t plane = (size_t)h->B * h->Np;
+        for (int k = 0; k < ncols; ++k) {
+            EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dJ + k * plane + (size_t)slot * h->Np, (size_t)N * 4, hipMemcpyDeviceToHost));
+            for (int i = 0; i < N; ++i) J[(size_t)i * ncols + k] = h->h_f32[i];
+        }
+    }
+    if (ncols == 6) {
+        edss::Sums6 S;
+        gather6(h, slot, &S);
+        if (JtJ) std::memcpy(JtJ, S.H, sizeof(S.H));
+        if (Jtr) std::memcpy(Jtr, S.b, sizeof(S.b));
+        if (cost) *cost = 0.5 * S.cost;
+    } else {
+        edss::Sums12* S = new edss::Sums12();
+        gather12(h, slot, N, S);
+        if (JtJ) { for (int i = 0; i < 144; ++i) { JtJ[i] = 0; for (int k = 0; k < S->nb; ++k) JtJ[i] += S->H[k][i]; } }
+        if (Jtr) { for (int i = 0; i < 12; ++i) { Jtr[i] = 0; for (int k = 0; k < S->nb; ++k) Jtr[i] += S->g[k][i]; } }
+        if (cost) { double c = 0; for (int k = 0; k < S->nb; ++k) c += S->s[k]; *cost = 0.5 * c; }
+        delete S;
+    }
+    return EDS_OK;
+}
+
+static int solve_range(eds_trk* h, int level, int first, int count) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (first < 0 || count < 1 || first + count > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    if (h->cfg.exec == EDS_EXEC_DEVICE) return eds_fused_solve(h, level, first, count);
+    return solve_host(h, level, first, count);
+}
+
+int eds_trk_optimize(eds_trk* h, int slot, int level, double p[3], double q[4], double v[6], eds_trk_info* info) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    Slot& s = h->slots[slot];
+    double sp[3], sq[4], svv[6];
+    std::memcpy(sp, s.p, sizeof(sp)); std::memcpy(sq, s.q, sizeof(sq)); std::memcpy(svv, s.v, sizeof(svv));
+    if (p) std::memcpy(s.p, p, sizeof(s.p));
+    if (q) std::memcpy(s.q, q, sizeof(s.q));
+    if (v) std::memcpy(s.v, v, sizeof(s.v));
+    rc = solve_range(h, level, slot, 1);
+    if (rc == EDS_OK && h->cfg.exec == EDS_EXEC_DEVICE) rc = eds_trk_sync(h);
+    if (rc != EDS_OK) {                 // leave everything at its pre-call value
+        std::memcpy(s.p, sp, sizeof(sp)); std::memcpy(s.q, sq, sizeof(sq)); std::memcpy(s.v, svv, sizeof(svv));
+        return rc;
+    }
+    if (info) *info = s.info;
+    if (!s.info.success) {              // Tracker.cpp:236-239: nothing is updated
+        std::memcpy(s.p, sp, sizeof(sp)); std::memcpy(s.q, sq, sizeof(sq)); std::memcpy(s.v, svv, sizeof(svv));
+        return fail(EDS_ERR_NOT_USABLE, "solution not usable");
+    }
+    if (p) std::memcpy(p, s.p, sizeof(s.p));
+    if (q) std::memcpy(q, s.q, sizeof(s.q));
+    if (v) std::memcpy(v, s.v, sizeof(s.v));
+    return EDS_OK;
+}
+
+int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count) { return solve_range(h, level, first, count); }
+
+int eds_trk_sync(eds_trk* h) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    if (h->cfg.exec == EDS_EXEC_DEVICE) return eds_fused_collect(h);
+    return EDS_OK;
+}
+
+int eds_trk_get_info(eds_trk* h, int slot, eds_trk_info* info) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!info) return fail(EDS_ERR_INVALID, "null info");
+    *info = h->slots[slot].info;
+    return EDS_OK;
+}
+
+int eds_trk_get_trace(eds_trk* h, int slot, int max_iters, double* increments, double* costs, int32_t* accepted) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (h->slots[slot].trace_on_device && (rc = eds_fused_fetch_trace(h, slot))) return rc;
+    const Slot& s = h->slots[slot];
+    const int n = std::min(max_iters, s.ntrace);
+    for (int i = 0; i < n; ++i) {
+        if (increments) std::memcpy(increments + 6 * i, &s.tr_xi[6 * i], 6 * sizeof(double));
+        if (costs) costs[i] = 0.5 * s.tr_cost[i];
+        if (accepted) accepted[i] = s.tr_acc[i];
+    }
+    return n;
+}
+
+int eds_trk_get_residuals(eds_trk* h, int slot, double* r) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!r) return fail(EDS_ERR_INVALID, "null output");
+    if ((rc = materialise_residuals(h, slot))) return rc;
+    const Slot& s = h->slots[slot];
+    if ((int)s.residuals.size() != s.N) return fail(EDS_ERR_STATE, "no residuals stored (no usable solve yet)");
+    std::memcpy(r, s.residuals.data(), sizeof(double) * s.N);
+    return EDS_OK;
+}
+
+int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!tau) return fail(EDS_ERR_INVALID, "null output");
+    Slot& s = h->slots[slot];
+    if (method == EDS_LP_CONSTANT) return EDS_OK;
+    if ((rc = materialise_residuals(h, slot))) return rc;
+    if ((int)s.residuals.size() != s.N || s.N < 1) return fail(EDS_ERR_STATE, "no residuals stored");
+    std::vector<double>& r = s.residuals;
+    if (method == EDS_LP_MAD) {         // Tracker.cpp:292-305 incl. the in-place partial reorder
+        const size_t n = r.size() / 2;
+        std::nth_element(r.begin(), r.begin() + n, r.end());
+        const double median = r[n];
+        std::vector<double> am(r.size());
+        for (size_t i = 0; i < r.size(); ++i) am[i] = std::fabs(r[i] - median);
+        const size_t m = am.size() / 2;
+        std::nth_element(am.begin(), am.begin() + m, am.end());
+        *tau = 1.345 * (1.4826 * am[m]);
+        return EDS_OK;
+    }
+    if (method == EDS_LP_STD) {         // Tracker.cpp:306-314; mean_std_vector returns the variance (Utils.hpp:272-290)
+        const size_t sz = r.size();
+        if (sz == 1) { *tau = 0.0; return EDS_OK; }
+        double mu = 0.0;
+        for (double x : r) mu += x;
+        mu /= (double)sz;
+        double var = 0.0;
+        for (double x : r) var += (x - mu) * (x - mu) / (double)(sz - 1);
+        *tau = 1.345 * var;
+        return EDS_OK;
+    }
+    return fail(EDS_ERR_INVALID, "unknown loss-param method");
+}
+
+int eds_trk_timer_start(eds_trk* h) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
+    return EDS_OK;
+}
+
+int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(EDS_ERR_INVALID, "null argument");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
+    EDS_HIP_TRY(hipEventSynchronize(h->ev1));
+    EDS_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return EDS_OK;
+}
+
+int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms) {
+    if (!h || !mean_ms) return fail(EDS_ERR_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > h->B || reps < 1) return fail(EDS_ERR_INVALID, "bad range");
+    if (ncols != 6 && ncols != 12) return fail(EDS_ERR_INVALID, "ncols must be 6 or 12");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    for (int s = first; s < first + count; ++s) {
+        const Slot& sl = h->slots[s];
+        if (!sl.has_kf || !sl.has_frame) return fail(EDS_ERR_STATE, "keyframe or event frame not set");
+        fill_pose(h, s, sl.p, sl.q, sl.v);
+    }
+    int rc = run_pass(h, first, count, ncols, true, with_reduction != 0, false);   // warm-up + model
+    if (rc) return rc;
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    const EdsArrays A = h->arrays();
+    const int N = max_points(h, first, count);
+    const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
+    const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
+    int cpb, nseg;
+    reduce_geometry(N, nb_red, &cpb, &nseg);
+    EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
+    for (int i = 0; i < reps; ++i) {
+        eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
+        if (with_reduction) eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st);
+    }
+    EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
+    EDS_HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    EDS_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    EDS_HIP_TRY(hipGetLastError());
+    *mean_ms = ms / (float)reps;
+    return EDS_OK;
+}
+
+}  // extern "C"

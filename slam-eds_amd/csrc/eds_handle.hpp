@@ -1,0 +1,52 @@
+// Private definition of the opaque handle (include/eds_hip.h: `typedef struct eds_trk eds_trk`).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "../../include/eds_hip.h"
+#include "eds_fused.hpp"
+#include "eds_kernels.hpp"
+
+// Host-side state of one alignment slot: what the reference keeps in Tracker members
+// px,qx,vx,info (Tracker.hpp:46-52) and in kf->residuals (KeyFrame.hpp:88).
+struct Slot {
+    int N = 0;
+    bool has_kf = false, has_frame = false;
+    double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[6];
+    double K[4] = {0, 0, 0, 0};
+    eds_trk_info info;
+    std::vector<double> residuals;
+    int ntrace = 0;
+    std::vector<double> tr_xi, tr_cost;
+    std::vector<int32_t> tr_acc;
+    bool res_on_device = false;     // residuals of the last solve still only in HBM
+    bool trace_on_device = false;   // trace of the last solve still only in HBM
+};
+
+
+struct eds_trk {
+    eds_trk_cfg cfg;
+    int B = 0, Nmax = 0, Np = 0, H = 0, W = 0, max_seg = 0, dev = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // device
+    double *dX = nullptr, *dY = nullptr, *dZ = nullptr, *dpose = nullptr, *dG = nullptr, *dpart = nullptr;
+    float *dx = nullptr, *dy = nullptr, *drho = nullptr, *dgx = nullptr, *dgy = nullptr, *dw = nullptr;
+    float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
+    EdsFusedBuffers fused;
+    // pinned host staging
+    double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr, *h_f64 = nullptr;
+    float *h_f32 = nullptr, *h_r = nullptr;
+    size_t h_f32_elems = 0;
+    std::vector<Slot> slots;
+
+    EdsArrays arrays() const {
+        EdsArrays A;
+        A.X = dX; A.Y = dY; A.Z = dZ; A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
+        A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart;
+        A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
+        return A;
+    }
+};
+

@@ -1,0 +1,228 @@
+// Streaming kernels of the event-to-model tracker for gfx950 (MI355X, CDNA4).
+//
+//   eds_gram_kernel     once per keyframe: G_k = A_k^T A_k per residual block (fp64)
+//   eds_model_kernel    once per velocity: mhat_i = a_i.v / n_block(i)
+//   eds_resjac_kernel   the residual / Jacobian pass (reference hot loop
+//                       PhotometricError.hpp:152-176 + the Jet<13> autodiff Ceres wraps around it,
+//                       here in closed form): one lane per point, SoA in, SoA out
+//   eds_reduce_kernel   tall-skinny J^T J / J^T r / sum r^2 reduction: wavefront reduce-scatter,
+//                       LDS across the 4 wavefronts, one fp64 record per workgroup
+//
+// Both bound by HBM, not MFMA (arithmetic intensity ~2 flop/B).  Workgroup -> (slot, chunk)
+// mapping is XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so slot = f(id % 8)
+// keeps all chunks of one alignment (and its 1.2 MB frame) behind ONE XCD's L2.
+#include <hip/hip_runtime.h>
+
+#include "eds_device.hpp"
+#include "eds_kernels.hpp"
+
+using namespace edsd;
+
+// linear workgroup id -> (slot, chunk); all chunks of a slot share id % 8 (one XCD)
+__device__ __forceinline__ bool decode_wg(int first, int count, int nchunk, int& slot, int& chunk) {
+    const int L = blockIdx.x;
+    const int xcd = L & 7, s = L >> 3;
+    const int group = s / nchunk;
+    chunk = s - group * nchunk;
+    const int rel = group * 8 + xcd;
+    slot = first + rel;
+    return rel < count;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EDS_TPB) void eds_gram_kernel(EdsArrays A, int slot) {
+    // grid.x = residual block index k; fp64 accumulation of the 21 unique products
+    const int k = blockIdx.x;
+    const double* pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N], nb = (int)pb[EDS_PB_NB], ne = (int)pb[EDS_PB_NE];
+    const int start = k * ne;
+    const int n = ne + ((k + 1 == nb) ? (N - (k + 1) * ne) : 0);
+    const size_t base = (size_t)slot * A.Np;
+    double acc[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < n; i += EDS_TPB) {
+        const size_t o = base + start + i;
+        float a[6];
+        model_row(A.x[o], A.y[o], A.rho[o], A.gx[o], A.gy[o], a);
+        int c = 0;
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int q = p; q < 6; ++q) acc[c++] += (double)a[p] * (double)a[q];
+    }
+    __shared__ double sh[EDS_TPB][21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) sh[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int s = EDS_TPB / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int i = 0; i < 21; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double* G = A.G + ((size_t)slot * EDS_MAX_BLOCKS + k) * 36;
+        int c = 0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p; q < 6; ++q) { G[6 * p + q] = sh[0][c]; G[6 * q + p] = sh[0][c]; ++c; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EDS_TPB) void eds_model_kernel(EdsArrays A, int first, int count, int nchunk) {
+    int slot, chunk;
+    if (!decode_wg(first, count, nchunk, slot, chunk)) return;
+    const double* pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N], nb = (int)pb[EDS_PB_NB], ne = (int)pb[EDS_PB_NE];
+    const int i = chunk * EDS_TPB + threadIdx.x;
+    if (i >= N) return;
+    const size_t o = (size_t)slot * A.Np + i;
+    float a[6];
+    model_row(A.x[o], A.y[o], A.rho[o], A.gx[o], A.gy[o], a);
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m += a[k] * (float)pb[EDS_PB_V + k];
+    const int blk = block_of(i, ne, nb);
+    A.mhat[o] = m * (float)pb[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk];
+}
+
+// ---------------------------------------------------------------------------------------
+// Residual + Jacobian pass.  NC = 6: SE(3) left-perturbation columns [d/d upsilon, d/d omega]
+// (J = -w [gradE_P, P x gradE_P]; identical to DSO's row, reference CoarseTracker.cpp:311-321).
+// NC = 12: Ceres-local columns of the reference problem [t | quaternion local | velocity local].
+template <int SAMPLING, int NC>
+__global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int first, int count, int nchunk) {
+    int slot, chunk;
+    if (!decode_wg(first, count, nchunk, slot, chunk)) return;
+    const double* __restrict__ pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N];
+    const int i = chunk * EDS_TPB + threadIdx.x;
+    if (i >= N) return;
+    PoseRT ps;
+    load_pose(pb, ps);
+    const size_t o = (size_t)slot * A.Np + i;
+    const float* __restrict__ frame = A.frame + (size_t)slot * A.H * A.W;
+    PointProj pp;
+    project_sample<SAMPLING>(frame, A.H, A.W, ps, A.X[o], A.Y[o], A.Z[o], pp);
+    const float w = A.w[o];
+    const size_t plane = (size_t)A.B * A.Np;
+    float* __restrict__ Jo = A.J + o;
+    if (NC == 6) {
+        A.r[o] = w * (A.mhat[o] - pp.E);
+        Jo[0 * plane] = -w * pp.g0;
+        Jo[1 * plane] = -w * pp.g1;
+        Jo[2 * plane] = -w * pp.g2;
+        Jo[3 * plane] = -w * (pp.Py * pp.g2 - pp.Pz * pp.g1);
+        Jo[4 * plane] = -w * (pp.Pz * pp.g0 - pp.Px * pp.g2);
+        Jo[5 * plane] = -w * (pp.Px * pp.g1 - pp.Py * pp.g0);
+    } else {
+        const int nb = (int)pb[EDS_PB_NB], ne = (int)pb[EDS_PB_NE];
+        const double* __restrict__ bk = pb + EDS_PB_BLK + EDS_PB_BLK_STRIDE * block_of(i, ne, nb);
+        float a[6];
+        model_row(A.x[o], A.y[o], A.rho[o], A.gx[o], A.gy[o], a);
+        float m = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m += a[k] * (float)pb[EDS_PB_V + k];
+        const float inv_n = (float)bk[0];
+        A.r[o] = w * (m * inv_n - pp.E);
+        Jo[0 * plane] = -w * pp.g0;
+        Jo[1 * plane] = -w * pp.g1;
+        Jo[2 * plane] = -w * pp.g2;
+        // quaternion local: -2 w (R X) x gradE_P, with R X = P - t
+        const float rx = pp.Px - (float)ps.t[0], ry = pp.Py - (float)ps.t[1], rz = pp.Pz - (float)ps.t[2];
+        const float w2 = -2.0f * w;
+        Jo[3 * plane] = w2 * (ry * pp.g2 - rz * pp.g1);
+        Jo[4 * plane] = w2 * (rz * pp.g0 - rx * pp.g2);
+        Jo[5 * plane] = w2 * (rx * pp.g1 - ry * pp.g0);
+        // velocity local: w (a/n - m (G v)/n^3) (I - v v^T/|v|^2)/|v|
+        float row[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row[k] = w * (a[k] * inv_n - m * (float)bk[1 + k]);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) s += row[k] * (float)pb[EDS_PB_PV + 6 * k + c];
+            Jo[(6 + c) * plane] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Reduction pass.  Segment s of a slot covers residual block k = s / cpb, points
+// [start_k + c*256, ...) with c = s % cpb, so records never straddle residual blocks
+// (the reference applies its loss per block, Tracker.cpp:146-161,192).
+template <int NC>
+__global__ __launch_bounds__(EDS_TPB) void eds_reduce_kernel(EdsArrays A, int first, int count, int nseg, int nb_red, int cpb) {
+    constexpr int NV = NC * (NC + 1) / 2 + NC + 1;
+    constexpr int K = (NC == 6) ? EDS_RED_K6 : EDS_RED_K12;
+    constexpr int NOUT = (K >= 64) ? K / 64 : 1;
+    int slot, seg;
+    if (!decode_wg(first, count, nseg, slot, seg)) return;
+    const double* __restrict__ pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N];
+    int start = 0, n = N;
+    const int k = seg / cpb, c = seg - k * cpb;
+    if (nb_red > 1) {
+        const int ne = N / nb_red;
+        start = k * ne;
+        n = ne + ((k + 1 == nb_red) ? (N - (k + 1) * ne) : 0);
+    }
+    const int li = c * EDS_TPB + threadIdx.x;
+    float acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) acc[j] = 0.0f;
+    if (li < n) {
+        const size_t o = (size_t)slot * A.Np + start + li;
+        const size_t plane = (size_t)A.B * A.Np;
+        float J[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) J[j] = A.J[o + j * plane];
+        const float r = A.r[o];
+        float hw = 1.0f, ct = r * r;
+        const float tau = (float)pb[EDS_PB_HUBER];
+        if (NC == 6 && tau > 0.0f) {           // per-point Huber (extension; cf. CoarseTracker.cpp:445)
+            const float ar = fabsf(r);
+            if (ar > tau) hw = tau / ar;
+            ct = hw * r * r * (2.0f - hw);
+        }
+        accumulate_normal<NC>(acc, J, r, hw, ct);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    wave_reduce_scatter<K>(acc, lane);
+    __shared__ float sh[EDS_TPB / 64][K];
+#pragma unroll
+    for (int j = 0; j < NOUT; ++j) {
+        if (K >= 64 || lane < 32) sh[wave][wave_red_index<K>(lane, j)] = acc[j];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < EDS_TPB / 64; ++wv) s += (double)sh[wv][threadIdx.x];
+        A.part[((size_t)slot * A.max_seg + seg) * EDS_RED_K + threadIdx.x] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers (host side, same translation unit so the templates are instantiated here)
+static inline int grid_for(int count, int per_slot) { return ((count + 7) / 8) * 8 * per_slot; }
+
+void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st) {
+    hipLaunchKernelGGL(eds_gram_kernel, dim3(nb), dim3(EDS_TPB), 0, st, A, slot);
+}
+void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st) {
+    hipLaunchKernelGGL(eds_model_kernel, dim3(grid_for(count, nchunk)), dim3(EDS_TPB), 0, st, A, first, count, nchunk);
+}
+void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, int count, int nchunk, hipStream_t st) {
+    const dim3 g(grid_for(count, nchunk)), b(EDS_TPB);
+    if (sampling == 0 && ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<0, 6>), g, b, 0, st, A, first, count, nchunk);
+    else if (sampling == 0) hipLaunchKernelGGL((eds_resjac_kernel<0, 12>), g, b, 0, st, A, first, count, nchunk);
+    else if (ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<1, 6>), g, b, 0, st, A, first, count, nchunk);
+    else hipLaunchKernelGGL((eds_resjac_kernel<1, 12>), g, b, 0, st, A, first, count, nchunk);
+}
+void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st) {
+    const dim3 g(grid_for(count, nseg)), b(EDS_TPB);
+    if (ncols == 6) hipLaunchKernelGGL((eds_reduce_kernel<6>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    else hipLaunchKernelGGL((eds_reduce_kernel<12>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+}

@@ -1,0 +1,49 @@
+// HBM data layout of libeds_hip (shared by host code and gfx950 kernels).
+//
+// One handle holds B alignment slots.  Everything per point is structure-of-arrays
+// with a padded point stride Np (multiple of 256) so that a wavefront's 64 lanes
+// read/write 64 consecutive elements of each plane:
+//
+//   X,Y,Z   f64 [B][Np]   back-projected point kp = (x/rho', y/rho', 1/rho'), rho' = idp + 1e-5
+//                         (reference PhotometricError.hpp:95-106).  fp64 because 1e-5 px of
+//                         sub-pixel phase at u ~ 640..1280 needs > 24 mantissa bits.
+//   x,y,rho f32 [B][Np]   normalised coords and RAW inverse depth for the flow model
+//                         (PhotometricError.hpp:114-122,136-137 use idp without eps)
+//   gx,gy,w f32 [B][Np]   log-image gradient and point weight (KeyFrame.hpp:80,90)
+//   mhat    f32 [B][Np]   normalised model a_i.v / n_block  (6-DoF solvers: velocity is fixed)
+//   frame   f32 [B][H*W]  brightness-increment frame, row-major (EventFrame.hpp:59)
+//   r       f32 [B][Np]   residuals of the last pass
+//   J       f32 [12][B][Np]  Jacobian planes (6 used by the pose-only solvers) — column-major
+//                         per point so the residual/Jacobian kernel's stores are coalesced
+//   pose    f64 [B][EDS_POSE_STRIDE]  per-slot constants of one pass, see PoseBlock below
+//   G       f64 [B][EDS_MAX_BLOCKS][36]  A^T A of each residual block (constant per keyframe;
+//                         gives ||m||^2 = v^T G v + 1e-3 and A^T m = G v in O(1))
+//   part    f64 [B][nseg][EDS_RED_K]  per-workgroup partial sums of the reduction kernel
+#pragma once
+#include <stdint.h>
+
+#define EDS_MAX_BLOCKS 16          // upper bound on options.num_threads residual blocks
+#define EDS_POSE_STRIDE 256        // doubles per slot
+#define EDS_POINT_ALIGN 256        // Np is a multiple of this
+#define EDS_TPB 256                // threads per workgroup of the streaming kernels (4 wavefronts)
+
+// offsets (in doubles) inside a slot's pose block
+#define EDS_PB_R 0                 // 9   rotation, row-major (Eigen toRotationMatrix of q, PhotometricError.hpp:163)
+#define EDS_PB_T 9                 // 3   translation px
+#define EDS_PB_K 12                // 4   fx fy cx cy
+#define EDS_PB_V 16                // 6   velocity vx
+#define EDS_PB_Q 22                // 4   quaternion xyzw
+#define EDS_PB_HUBER 26            // 1   per-point Huber threshold (0 = off)
+#define EDS_PB_NB 27               // 1   number of residual blocks
+#define EDS_PB_NE 28               // 1   points per block (N / nb, Tracker.cpp:178)
+#define EDS_PB_N 29                // 1   number of points
+#define EDS_PB_PV 32               // 36  d(unit-norm plus)/d delta = (I - v v^T/|v|^2)/|v|  (PhotometricError.hpp:32-54)
+#define EDS_PB_BLK 68              // 8 per block: inv_n, gvec[6] = G v / n^3, S
+#define EDS_PB_BLK_STRIDE 8
+
+// reduction widths: upper triangle of J^T J + J^T r + sum r^2 (+ count of Huber-active points)
+#define EDS_RED_N6 28              // 21 + 6 + 1
+#define EDS_RED_K6 32
+#define EDS_RED_N12 91             // 78 + 12 + 1
+#define EDS_RED_K12 128
+#define EDS_RED_K 128              // stride of the partial-sum records
