@@ -116,6 +116,8 @@ int         eds_abi_version(void);
 int         eds_device_count(void);
 const char* eds_last_error(void);               /* thread-local message of the last failure */
 void        eds_trk_cfg_default(eds_trk_cfg* cfg);
+int         eds_trk_cfg_size(void);             /* sizeof(eds_trk_cfg)  — lets a binding verify its struct layout */
+int         eds_trk_info_size(void);            /* sizeof(eds_trk_info) */
 
 /* ---- lifetime --------------------------------------------------------------------------- */
 /* Replaces Tracker::Tracker(config) (Tracker.cpp:40-47).  Allocates HBM for `batch`

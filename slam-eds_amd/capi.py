@@ -27,7 +27,8 @@ MAX_LEVELS = 8
 
 # every symbol include/eds_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
-    "eds_abi_version", "eds_device_count", "eds_last_error", "eds_trk_cfg_default",
+    "eds_abi_version", "eds_device_count", "eds_last_error", "eds_trk_cfg_default", "eds_trk_cfg_size",
+    "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
@@ -114,6 +115,8 @@ def lib():
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        if L.eds_trk_cfg_size() != C.sizeof(Cfg) or L.eds_trk_info_size() != C.sizeof(Info):
+            raise EdsError(ERR_INVALID, "ctypes struct layout disagrees with include/eds_hip.h")
         _lib = L
     return _lib
 

@@ -311,6 +311,9 @@ int eds_device_count(void) {
 
 const char* eds_last_error(void) { return g_last_error.c_str(); }
 
+int eds_trk_cfg_size(void) { return (int)sizeof(eds_trk_cfg); }
+int eds_trk_info_size(void) { return (int)sizeof(eds_trk_info); }
+
 void eds_trk_cfg_default(eds_trk_cfg* cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));

@@ -1,0 +1,311 @@
+"""CPU tests of the oracle itself (no GPU).
+
+The reference ships no tests or golden vectors for this path, so the oracle is
+pinned as far as possible by (a) known-answer tests of every third-party piece it restates
+(Ceres bicubic/loss/parameterisations, Sophus exp/log), (b) agreement between two independent
+implementations (C++ forward-mode autodiff vs numpy closed forms) and finite differences,
+(c) agreement of the restated Ceres LM with scipy's independent Levenberg-Marquardt on the
+same residual, and (d) the committed golden fixtures.  Parity with the real reference remains
+UNPINNED and is reported as such.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def al(synth):
+    return synth.make_alignment(21, H=96, W=128, N=300)
+
+
+def _pose(seed=3, ang=0.004, t=0.003):
+    rng = np.random.default_rng(seed)
+    axis = rng.standard_normal(3)
+    axis /= np.linalg.norm(axis)
+    q = np.concatenate([np.sin(ang / 2) * axis, [np.cos(ang / 2)]])
+    return t * rng.standard_normal(3), q
+
+
+# ---------------------------------------------------------------------------------------
+# bicubic (ceres::BiCubicInterpolator over a clamped Grid2D)
+def test_bicubic_interpolates_grid_points(po):
+    rng = np.random.default_rng(0)
+    fr = rng.standard_normal((12, 17))
+    for r, c in ((0, 0), (3, 5), (11, 16), (7, 0), (0, 9)):
+        f, _, _ = po.bicubic(fr, r, c)
+        assert f == pytest.approx(fr[r, c], abs=1e-14)
+
+
+def test_bicubic_reproduces_quadratics_and_gradients(po):
+    # Catmull-Rom reproduces polynomials up to degree 2 exactly (interior)
+    rr, cc = np.mgrid[0:16, 0:20].astype(float)
+    fr = 0.3 + 0.2 * rr - 0.1 * cc + 0.05 * rr * cc + 0.02 * rr * rr - 0.03 * cc * cc
+    for r, c in ((5.25, 7.5), (8.9, 3.1), (2.0, 2.0), (10.49, 15.99)):
+        f, dr, dc = po.bicubic(fr, r, c)
+        assert f == pytest.approx(0.3 + 0.2 * r - 0.1 * c + 0.05 * r * c + 0.02 * r * r - 0.03 * c * c, abs=1e-12)
+        assert dr == pytest.approx(0.2 + 0.05 * c + 0.04 * r, abs=1e-12)
+        assert dc == pytest.approx(-0.1 + 0.05 * r - 0.06 * c, abs=1e-12)
+
+
+def test_bicubic_clamps_like_grid2d(po):
+    fr = np.arange(30.0).reshape(5, 6)
+    # far outside: every tap clamps to the corner pixel -> value of that pixel, zero gradient
+    f, dr, dc = po.bicubic(fr, -10.3, -7.7)
+    assert (f, dr, dc) == (fr[0, 0], 0.0, 0.0)
+    f, dr, dc = po.bicubic(fr, 100.2, 100.9)
+    assert (f, dr, dc) == (fr[4, 5], 0.0, 0.0)
+    # on the border row the row below is replicated
+    f0, _, _ = po.bicubic(fr, 0.0, 2.5)
+    ref = (-fr[0, 1] + 9 * fr[0, 2] + 9 * fr[0, 3] - fr[0, 4]) / 16.0   # Catmull-Rom midpoint
+    assert f0 == pytest.approx(ref, abs=1e-13)
+
+
+def test_bicubic_cpp_matches_numpy(po, npo):
+    rng = np.random.default_rng(5)
+    fr = rng.standard_normal((20, 24))
+    rows = rng.uniform(-3, 23, 200)
+    cols = rng.uniform(-3, 27, 200)
+    f, dr, dc = npo.bicubic(fr, rows, cols)
+    for i in range(200):
+        o = po.bicubic(fr, rows[i], cols[i])
+        assert np.allclose(o, [f[i], dr[i], dc[i]], atol=1e-13)
+    fb, drb, dcb = npo.bilinear(fr, rows, cols)
+    for i in range(0, 200, 7):
+        assert np.allclose(po.bilinear(fr, rows[i], cols[i]), [fb[i], drb[i], dcb[i]], atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------
+# residual + Jacobians: autodiff (C++) vs closed form (numpy) vs finite differences
+@pytest.mark.parametrize("nb", [1, 3, 7])
+@pytest.mark.parametrize("sampling", ["bicubic", "bilinear"])
+def test_jacobians_autodiff_vs_closed_form(po, npo, al, nb, sampling):
+    p, q = _pose()
+    v = al.v_true + 0.1 * np.random.default_rng(1).standard_normal(6)
+    v /= np.linalg.norm(v)
+    o = po.Oracle(al, num_blocks=nb, sampling=po.BICUBIC if sampling == "bicubic" else po.BILINEAR)
+    e = o.eval12(p, q, v)
+    r, J, J6 = npo.jacobians(al, p, q, v, nb, sampling)
+    assert np.abs(e["r_raw"] - r).max() < 1e-13
+    assert np.abs(e["J_local_raw"] - J).max() < 1e-10
+    e6 = o.pose6_eval(p, q, v)
+    assert np.abs(e6["r"] - r).max() < 1e-13
+    assert np.abs(e6["J"] - J6).max() < 1e-10
+    assert np.allclose(e6["H"], J6.T @ J6, rtol=1e-12)
+    assert np.allclose(e6["b"], J6.T @ r, rtol=1e-10, atol=1e-14)
+
+
+def test_jacobians_vs_finite_differences(npo, al):
+    # bicubic is C1 with a discontinuous second derivative at pixel borders, so a handful of points
+    # whose +-h stencil straddles a border carry an O(h) error: compare with a robust statistic.
+    p, q = _pose(ang=0.02, t=0.01)
+    v = al.v_true
+    r, J, J6 = npo.jacobians(al, p, q, v, 2)
+    Jfd = npo.fd_jacobian_local(al, p, q, v, 2, h=1e-6)
+    J6fd = npo.fd_jacobian_se3(al, p, q, v, 2, h=1e-6)
+    scale = np.abs(J).max(axis=0)
+    assert (np.quantile(np.abs(Jfd - J), 0.95, axis=0) <= 1e-6 * np.maximum(scale, 1)).all()
+    assert (np.quantile(np.abs(J6fd - J6), 0.95, axis=0) <= 1e-6 * np.maximum(np.abs(J6).max(axis=0), 1)).all()
+    assert (np.median(np.abs(Jfd - J), axis=0) <= 1e-7 * np.maximum(scale, 1)).all()
+
+
+def test_block_partition_matches_reference_rule(po, npo, synth):
+    # Tracker.cpp:178-195: N / T per block, remainder to the LAST block; N < T leaves leading blocks empty
+    assert npo.block_ranges(10, 3) == [(0, 3), (3, 3), (6, 4)]
+    assert npo.block_ranges(2, 4) == [(0, 0), (0, 0), (0, 0), (0, 2)]
+    al = synth.make_alignment(3, H=48, W=64, N=5)
+    p, q = _pose()
+    o = po.Oracle(al, num_blocks=8)          # more blocks than points
+    e = o.eval12(p, q, al.v_true)
+    r = npo.residual(al, p, q, al.v_true, 8)
+    assert np.abs(e["r_raw"] - r).max() < 1e-13
+
+
+def test_model_is_per_block_normalised(po, al):
+    # the L2 norm of the model term over a block is < 1 by the 1e-3 offset (PhotometricError.hpp:132)
+    zero_frame = type(al)(**{**al.__dict__, "frame": np.zeros_like(al.frame), "weights": np.ones(al.N)})
+    for nb in (1, 4):
+        e = po.Oracle(zero_frame, num_blocks=nb).eval12(al.p0, al.q0, al.v_true, jac=False)
+        ne = al.N // nb
+        for b in range(nb):
+            blk = e["r_raw"][b * ne: (b + 1) * ne if b + 1 < nb else al.N]
+            assert 0.9 < np.sum(blk ** 2) < 1.0
+
+
+# ---------------------------------------------------------------------------------------
+# local parameterisations
+def test_quaternion_plus_is_left_rotation_by_twice_delta(po):
+    q = np.array([0.1, -0.2, 0.05, 0.97])
+    q /= np.linalg.norm(q)
+    d = np.array([0.01, -0.02, 0.015])
+    x2 = po.state_plus(np.concatenate([np.zeros(3), q, np.ones(6)]), np.concatenate([np.zeros(3), d, np.zeros(6)]))
+    R2 = po.quat_to_R(x2[3:7])
+    ang = 2 * np.linalg.norm(d)
+    k = d / np.linalg.norm(d)
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    Rd = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    assert np.allclose(R2, Rd @ po.quat_to_R(q), atol=1e-14)
+    assert np.linalg.norm(x2[3:7]) == pytest.approx(1.0, abs=1e-15)
+
+
+def test_plus_jacobians_vs_finite_differences(po):
+    rng = np.random.default_rng(2)
+    q = rng.standard_normal(4); q /= np.linalg.norm(q)
+    v = rng.standard_normal(6); v /= np.linalg.norm(v)
+    x = np.concatenate([rng.standard_normal(3), q, v])
+    Jq, Jv = po.quat_plus_jacobian(q), po.unit_plus_jacobian(v)
+    h = 1e-7
+    for k in range(12):
+        d = np.zeros(12); d[k] = h
+        fd = (po.state_plus(x, d) - po.state_plus(x, -d)) / (2 * h)
+        if k < 3:
+            e = np.zeros(13); e[k] = 1
+        elif k < 6:
+            e = np.concatenate([np.zeros(3), Jq[:, k - 3], np.zeros(6)])
+        else:
+            e = np.concatenate([np.zeros(7), Jv[:, k - 6]])
+        assert np.allclose(fd, e, atol=1e-8)
+    # unit-norm plus: rank-5 projector (I - v v^T)/|v|
+    assert np.allclose(Jv, np.eye(6) - np.outer(v, v), atol=1e-14)
+    assert np.linalg.matrix_rank(Jv, tol=1e-10) == 5
+
+
+# ---------------------------------------------------------------------------------------
+# robust losses (ceres::HuberLoss / CauchyLoss) — known answers
+def test_loss_functions_known_answers(po):
+    a = 0.5
+    assert np.allclose(po.loss_eval(po.LOSS_HUBER, a, 0.2), [0.2, 1.0, 0.0])          # s <= a^2: identity
+    rho = po.loss_eval(po.LOSS_HUBER, a, 4.0)                                           # 2 a sqrt(s) - a^2
+    assert np.allclose(rho, [2 * a * 2.0 - 0.25, a / 2.0, -(a / 2.0) / 8.0])
+    rho = po.loss_eval(po.LOSS_CAUCHY, a, 1.0)
+    assert np.allclose(rho, [0.25 * np.log(5.0), 1 / 5.0, -4.0 / 25.0])
+    assert np.allclose(po.loss_eval(po.LOSS_NONE, a, 3.0), [3.0, 1.0, 0.0])
+
+
+def test_corrected_problem_gradient_is_gradient_of_robust_cost(po, npo, al):
+    # d/dx [1/2 sum_b rho(s_b)] must equal J_corrected^T r_corrected for both losses
+    p, q = _pose()
+    v = al.v_true
+    for loss in (po.LOSS_HUBER, po.LOSS_CAUCHY):
+        o = po.Oracle(al, num_blocks=4, loss_type=loss, loss_param=0.2)
+        e = o.eval12(p, q, v)
+        g = np.zeros(12)
+        h = 1e-6
+        for k in range(12):
+            d = np.zeros(12); d[k] = h
+            cp = o.eval12(*npo.state_plus(p, q, v, d), jac=False)["cost"]
+            cm = o.eval12(*npo.state_plus(p, q, v, -d), jac=False)["cost"]
+            g[k] = (cp - cm) / (2 * h)
+        assert np.allclose(e["gradient"], g, rtol=2e-4, atol=1e-7)
+        assert np.allclose(e["gradient"], e["J_local"].T @ e["r"], rtol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------
+# trust-region LM restatement
+def test_lm_decreases_cost_and_reports_like_ceres(po, al):
+    o = po.Oracle(al, max_num_iterations=15)
+    s = o.solve_lm(al.p0, al.q0, al.v0)
+    assert s["usable"] and s["termination"] in (po.CONVERGENCE, po.NO_CONVERGENCE)
+    assert s["final_cost"] < s["initial_cost"]
+    assert s["num_iterations"] == s["num_successful_steps"] + s["num_unsuccessful_steps"]
+    assert s["num_iterations"] <= 16 and s["num_successful_steps"] >= 1     # iteration 0 counts as successful
+    assert s["num_residuals"] == al.N
+    assert np.linalg.norm(s["q"]) == pytest.approx(1.0, abs=1e-12)
+    assert np.linalg.norm(s["v"]) == pytest.approx(1.0, abs=1e-12)
+    assert o.eval12(s["p"], s["q"], s["v"], jac=False)["cost"] == pytest.approx(s["final_cost"], rel=1e-12)
+
+
+def test_lm_agrees_with_scipy_levenberg_marquardt(po, npo, synth):
+    # independent solver (MINPACK lmder through scipy) on the same residual in the same local
+    # coordinates, started at the same point: both must reach the same local minimum.
+    from scipy.optimize import least_squares
+    al = synth.make_alignment(5, H=96, W=128, N=300, noise=0.01)
+    o = po.Oracle(al, max_num_iterations=200, function_tolerance=1e-14, parameter_tolerance=1e-12)
+    s = o.solve_lm(al.p0, al.q0, al.v0)
+    assert s["usable"]
+
+    def fun(d):
+        return npo.residual(al, *npo.state_plus(s["p"], s["q"], s["v"], d))
+    sol = least_squares(fun, np.zeros(12), method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    # scipy restarted AT the oracle's solution must not find a noticeably better point (the valley
+    # along the rank-deficient velocity direction is flat, so allow 2e-4 relative)
+    assert 0.5 * np.sum(sol.fun ** 2) >= s["final_cost"] * (1 - 2e-4)
+    assert np.linalg.norm(sol.x[:6]) < 2e-3
+
+
+def test_lm_termination_paths(po, al):
+    s0 = po.Oracle(al, max_num_iterations=0).solve_lm(al.p0, al.q0, al.v0)
+    assert s0["termination"] == po.NO_CONVERGENCE and s0["num_iterations"] == 1
+    assert np.array_equal(s0["p"], al.p0) and np.array_equal(s0["v"], al.v0)
+    s1 = po.Oracle(al, max_num_iterations=50, function_tolerance=0.5).solve_lm(al.p0, al.q0, al.v0)
+    assert s1["termination"] == po.CONVERGENCE and s1["num_iterations"] < 20
+    bad = type(al)(**{**al.__dict__, "frame": np.full_like(al.frame, np.nan)})
+    sb = po.Oracle(bad).solve_lm(al.p0, al.q0, al.v0)
+    assert not sb["usable"] and sb["termination"] == po.FAILURE
+    assert np.array_equal(sb["p"], al.p0) and np.array_equal(sb["q"], al.q0) and np.array_equal(sb["v"], al.v0)
+
+
+# ---------------------------------------------------------------------------------------
+# Sophus-compatible exp / log
+def test_se3_exp_log_roundtrip_and_matrix_exponential(po, npo):
+    rng = np.random.default_rng(4)
+    for scale in (1e-12, 1e-6, 0.1, 1.5):
+        xi = scale * rng.standard_normal(6)
+        t, q = po.se3_exp(xi)
+        T = np.eye(4); T[:3, :3] = po.quat_to_R(q); T[:3, 3] = t
+        assert np.allclose(T, npo.se3_exp_matrix(xi), atol=1e-13)
+        assert np.allclose(po.se3_log(t, q), xi, atol=1e-12 * max(1, scale) + 1e-15)
+    ta, qa = po.se3_exp(np.array([0.1, -0.2, 0.3, 0.02, 0.01, -0.03]))
+    assert po.se3_distance(ta, qa, ta, qa) < 1e-15
+    xi = np.array([1e-3, 0, 0, 0, 2e-3, 0])
+    tb, qb = po.se3_left_update(xi, ta, qa)
+    assert po.se3_distance(tb, qb, ta, qa) == pytest.approx(np.linalg.norm(xi), rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------
+# Tracker::getLossParams quirks
+def test_loss_param_quirks(po):
+    rng = np.random.default_rng(8)
+    r = rng.standard_normal(101) * 0.01
+    tau, reordered = po.loss_param(r, po.LP_MAD)
+    med = np.sort(r)[50]                                    # nth_element(N/2)
+    mad = 1.4826 * np.sort(np.abs(r - med))[50]
+    assert tau == pytest.approx(1.345 * mad, rel=1e-14)
+    assert reordered[50] == med and sorted(reordered) == sorted(r)      # partially reordered in place
+    assert (reordered[:50] <= med).all() and (reordered[51:] >= med).all()
+    tau_std, _ = po.loss_param(r, po.LP_STD)
+    assert tau_std == pytest.approx(1.345 * np.var(r, ddof=1), rel=1e-12)   # variance, not std (Utils.hpp:285-289)
+    assert po.loss_param(r, po.LP_CONSTANT, 0.123)[0] == 0.123
+    r_even = rng.standard_normal(100)
+    assert po.loss_param(r_even, po.LP_MAD)[0] == pytest.approx(
+        1.345 * 1.4826 * np.sort(np.abs(r_even - np.sort(r_even)[50]))[50], rel=1e-14)
+
+
+# ---------------------------------------------------------------------------------------
+# golden fixtures (regression of the oracle; see tests/golden/make_golden.py)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_oracle_reproduces_golden(po, synth, path):
+    g = np.load(path)
+    al = synth.make_alignment(int(g["seed"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]))
+    if "frame" in g.files:                      # small cases carry their inputs: generator must be stable
+        assert np.array_equal(al.frame, g["frame"]) and np.array_equal(al.norm_coord, g["norm_coord"])
+    nb = int(g["num_blocks"])
+    sub = slice(None) if "frame" in g.files else slice(None, None, 8)
+    for sampling, tag in ((po.BICUBIC, "bc"), (po.BILINEAR, "bl")):
+        o = po.Oracle(al, sampling=sampling, num_blocks=nb, max_num_iterations=10)
+        e = o.eval12(g["eval_p"], g["eval_q"], g["eval_v"])
+        assert np.allclose(e["r_raw"], g[f"{tag}_r"], rtol=0, atol=1e-13)
+        assert np.allclose(e["J_local_raw"][sub], g[f"{tag}_J12"], rtol=1e-10, atol=1e-12)
+        e6 = o.pose6_eval(g["eval_p"], g["eval_q"], g["eval_v"])
+        assert np.allclose(e6["J"][sub], g[f"{tag}_J6"], rtol=1e-10, atol=1e-12)
+        assert np.allclose(e6["H"], g[f"{tag}_H6"], rtol=1e-10)
+        lm = o.pose6_lm(al.p0, al.q0, al.v0, iters=10, lambda0=0.01)
+        assert np.array_equal(lm["accepted"], g[f"{tag}_lm6_acc"])
+        assert po.se3_distance(lm["p"], lm["q"], g[f"{tag}_lm6_p"], g[f"{tag}_lm6_q"]) < 1e-9
+        s = po.Oracle(al, sampling=sampling, num_blocks=nb, max_num_iterations=10).solve_lm(al.p0, al.q0, al.v0)
+        ref = g[f"{tag}_ref12_none"]
+        assert po.se3_distance(s["p"], s["q"], ref[0:3], ref[3:7]) < 1e-8
+        assert s["num_iterations"] == int(ref[14]) and s["termination"] == int(ref[16])

@@ -1,0 +1,373 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Stated tolerances (fp32 kernels with fp64 projection / accumulation vs the fp64 oracle):
+    residuals      max |dr|          <= 1e-5 * max |r|
+    Jacobian       rel. Frobenius    <= 1e-4
+    JtJ, Jtr       rel. Frobenius    <= 1e-4
+    SE(3) step     ||log(exp(xi_gpu) exp(xi_ref)^-1)|| <= 1e-4 * max(||xi_ref||, 1e-3)
+    solved pose    SE(3) distance    <= 1e-4  (rotation [rad] / translation [scene units])
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_R, TOL_J, TOL_H, TOL_STEP, TOL_POSE = 1e-5, 1e-4, 1e-4, 1e-4, 1e-4
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+def step_err(po, xi_a, xi_b):
+    ta, qa = po.se3_exp(xi_a)
+    tb, qb = po.se3_exp(xi_b)
+    return po.se3_distance(ta, qa, tb, qb) / max(np.linalg.norm(xi_b), 1e-3)
+
+
+def make_handle(capi, al, batch=1, **kw):
+    cfg = capi.default_config(**kw)
+    h = capi.Handle(cfg, batch, al.N, al.H, al.W)
+    for b in range(batch):
+        h.set_alignment(b, al)
+    return h
+
+
+def eval_pose(synth, seed=3, ang=0.003, t=0.002):
+    rng = np.random.default_rng(seed)
+    return t * rng.standard_normal(3), synth.quat_from_axis_angle(rng.standard_normal(3), ang)
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sampling", [0, 1], ids=["bicubic", "bilinear"])
+@pytest.mark.parametrize("nb", [1, 4])
+@pytest.mark.parametrize("shape", [(48, 64, 37), (120, 160, 256), (480, 640, 2000)], ids=["n37", "n256", "n2000"])
+def test_residual_jacobian_reduction_vs_oracle(gpu, capi, synth, po, sampling, nb, shape):
+    H, W, N = shape
+    al = synth.make_alignment(100 + N, H=H, W=W, N=N)
+    p, q = eval_pose(synth)
+    v = al.v_true
+    o = po.Oracle(al, sampling=sampling, num_blocks=nb)
+    h = make_handle(capi, al, sampling=sampling, num_blocks=nb, exec=capi.EXEC_HOST)
+    g = h.eval(0, p, q, v, ncols=6)
+    e = o.pose6_eval(p, q, v)
+    assert np.abs(g["r"] - e["r"]).max() <= TOL_R * np.abs(e["r"]).max()
+    assert rel(g["J"], e["J"]) <= TOL_J
+    assert rel(g["JtJ"], e["H"]) <= TOL_H and rel(g["Jtr"], e["b"]) <= TOL_H
+    assert g["cost"] == pytest.approx(0.5 * e["cost"], rel=1e-5)
+    assert np.allclose(g["JtJ"], g["JtJ"].T, rtol=0, atol=0)             # exactly symmetric by construction
+    g12 = h.eval(0, p, q, v, ncols=12)
+    e12 = o.eval12(p, q, v)
+    J = e12["J_local_raw"]
+    assert np.abs(g12["r"] - e12["r_raw"]).max() <= TOL_R * np.abs(e12["r_raw"]).max()
+    assert rel(g12["J"], J) <= TOL_J
+    assert rel(g12["JtJ"], J.T @ J) <= TOL_H and rel(g12["Jtr"], J.T @ e12["r_raw"]) <= TOL_H
+    h.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_golden_fixtures(gpu, capi, synth, po, path):
+    g = np.load(path)
+    if "frame" in g.files:        # small cases: inputs come from the fixture itself
+        al = synth.Alignment(H=int(g["H"]), W=int(g["W"]), fx=g["K"][0], fy=g["K"][1], cx=g["K"][2], cy=g["K"][3],
+                             norm_coord=g["norm_coord"], grad=g["grad"], idp=g["idp"], weights=g["weights"],
+                             frame=g["frame"], coord=np.zeros((int(g["N"]), 2)), p0=g["p0"], q0=g["q0"], v0=g["v0"])
+        sub = slice(None)
+    else:
+        al = synth.make_alignment(int(g["seed"]), H=int(g["H"]), W=int(g["W"]), N=int(g["N"]))
+        sub = slice(None, None, 8)
+    nb = int(g["num_blocks"])
+    for sampling, tag in ((0, "bc"), (1, "bl")):
+        h = make_handle(capi, al, sampling=sampling, num_blocks=nb, exec=capi.EXEC_HOST, solver=capi.SOLVER_LM6)
+        e6 = h.eval(0, g["eval_p"], g["eval_q"], g["eval_v"], ncols=6)
+        assert np.abs(e6["r"] - g[f"{tag}_r"]).max() <= TOL_R * np.abs(g[f"{tag}_r"]).max()
+        assert rel(e6["J"][sub], g[f"{tag}_J6"]) <= TOL_J
+        assert rel(e6["JtJ"], g[f"{tag}_H6"]) <= TOL_H and rel(e6["Jtr"], g[f"{tag}_b6"]) <= TOL_H
+        e12 = h.eval(0, g["eval_p"], g["eval_q"], g["eval_v"], ncols=12)
+        assert rel(e12["J"][sub], g[f"{tag}_J12"]) <= TOL_J
+        assert rel(e12["JtJ"], g[f"{tag}_J12tJ12"]) <= TOL_H and rel(e12["Jtr"], g[f"{tag}_J12tr"]) <= TOL_H
+        assert e12["cost"] == pytest.approx(float(g[f"{tag}_cost"]), rel=1e-5)
+        for ex in (capi.EXEC_HOST, capi.EXEC_DEVICE):
+            cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=ex, solver=capi.SOLVER_LM6, max_num_iterations=10)
+            h.set_config(cfg)
+            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            tr = h.trace(0)
+            assert np.array_equal(tr["accepted"], g[f"{tag}_lm6_acc"])
+            assert po.se3_distance(p, q, g[f"{tag}_lm6_p"], g[f"{tag}_lm6_q"]) <= TOL_POSE
+            for k in range(len(tr["increments"])):
+                assert step_err(po, tr["increments"][k], g[f"{tag}_lm6_inc"][k]) <= TOL_STEP
+            cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=ex, solver=capi.SOLVER_GN6, max_num_iterations=2)
+            h.set_config(cfg)
+            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            tr = h.trace(0)
+            assert step_err(po, tr["increments"][0], g[f"{tag}_gn6_inc"][0]) <= TOL_STEP
+        for loss, lname in ((0, "none"), (1, "huber"), (2, "cauchy")):
+            cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=capi.EXEC_HOST, solver=capi.SOLVER_REF12,
+                                      loss_type=loss, loss_param=0.3, max_num_iterations=10)
+            h.set_config(cfg)
+            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            ref = g[f"{tag}_ref12_{lname}"]
+            assert po.se3_distance(p, q, ref[0:3], ref[3:7]) <= TOL_POSE
+            assert np.abs(v - ref[7:13]).max() <= 1e-4
+            assert info["final_cost"] == pytest.approx(ref[13], rel=1e-5)
+            assert info["num_iterations"] == int(ref[14]) and info["num_successful_steps"] == int(ref[15])
+            assert info["termination"] == int(ref[16])
+            if loss == 0:
+                assert h.loss_param(0, capi.LP_MAD) == pytest.approx(float(g[f"{tag}_mad_tau"]), rel=1e-4)
+                assert h.loss_param(0, capi.LP_STD) == pytest.approx(float(g[f"{tag}_std_tau"]), rel=1e-4)
+        h.close()
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("solver", ["lm6", "gn6"])
+@pytest.mark.parametrize("ex", [0, 1], ids=["host", "device"])
+def test_pose_solvers_vs_oracle(gpu, capi, synth, po, solver, ex):
+    al = synth.make_alignment(1234)               # 640x480, 2000 points: the headline configuration
+    o = po.Oracle(al)
+    iters = 10 if solver == "lm6" else 3          # undamped GN is chaotic on this large-residual problem
+    ref = o.pose6_lm(al.p0, al.q0, al.v0, iters=iters, lambda0=0.01) if solver == "lm6" else \
+        o.pose6_gn(al.p0, al.q0, al.v0, iters=iters)
+    h = make_handle(capi, al, exec=ex, solver=capi.SOLVER_LM6 if solver == "lm6" else capi.SOLVER_GN6,
+                    max_num_iterations=iters)
+    p, q, v, info = h.optimize(0)
+    tr = h.trace(0)
+    assert info["success"] and info["num_iterations"] == iters and info["num_points"] == al.N
+    assert len(tr["increments"]) == iters
+    if solver == "lm6":
+        assert np.array_equal(tr["accepted"], ref["accepted"])
+        assert np.allclose(tr["costs"], 0.5 * ref["costs"], rtol=1e-5)
+    assert step_err(po, tr["increments"][0], ref["increments"][0]) <= TOL_STEP
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
+    assert np.array_equal(v, al.v0)               # velocity is held fixed by the pose-only solvers
+    # residuals stored at the solution (Tracker.cpp:223-230) and the adaptive scale (:281-317)
+    r = h.residuals(0)
+    er = o.pose6_eval(p, q, v)["r"]
+    assert np.abs(r - er).max() <= TOL_R * np.abs(er).max()
+    tau_ref, _ = po.loss_param(er, po.LP_MAD)
+    assert h.loss_param(0, capi.LP_MAD) == pytest.approx(tau_ref, rel=1e-4)
+    h.close()
+
+
+@pytest.mark.parametrize("nb,loss", [(1, 0), (2, 1), (8, 2)])
+def test_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss):
+    al = synth.make_alignment(4321, start="ctor")          # v0 = normalize(0.001 * ones), Tracker.cpp:45-46
+    ref = po.Oracle(al, num_blocks=nb, loss_type=loss, loss_param=0.2, max_num_iterations=15).solve_lm(al.p0, al.q0, al.v0)
+    h = make_handle(capi, al, exec=capi.EXEC_HOST, solver=capi.SOLVER_REF12, num_blocks=nb, loss_type=loss,
+                    loss_param=0.2, max_num_iterations=15)
+    p, q, v, info = h.optimize(0)
+    assert info["success"] and ref["usable"]
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
+    assert np.abs(v - ref["v"]).max() <= 1e-4 and np.linalg.norm(v) == pytest.approx(1.0, abs=1e-12)
+    assert info["num_iterations"] == ref["num_iterations"]
+    assert info["num_successful_steps"] == ref["num_successful_steps"]
+    assert info["termination"] == ref["termination"]
+    assert info["initial_cost"] == pytest.approx(ref["initial_cost"], rel=1e-5)
+    assert info["final_cost"] == pytest.approx(ref["final_cost"], rel=1e-5)
+    h.close()
+
+
+def test_per_point_huber_1280x720(gpu, capi, synth, po):
+    """BASELINE.json configs[2]: 1280x720, 8000 points, per-point Huber at tau = 1.345 MAD."""
+    al = synth.make_alignment(2234, H=720, W=1280, N=8000)
+    o = po.Oracle(al)
+    tau, _ = po.loss_param(o.pose6_eval(al.p0, al.q0, al.v0)["r"], po.LP_MAD)
+    p, q = eval_pose(synth, 9)
+    h = make_handle(capi, al, exec=capi.EXEC_HOST, solver=capi.SOLVER_LM6, huber_tau=tau, max_num_iterations=8)
+    g = h.eval(0, p, q, al.v0, ncols=6)
+    e = o.pose6_eval(p, q, al.v0, huber_tau=tau)
+    assert (e["hw"] < 1).sum() > 100                                  # the weights actually bite
+    assert rel(g["JtJ"], e["H"]) <= TOL_H and rel(g["Jtr"], e["b"]) <= TOL_H
+    assert g["cost"] == pytest.approx(0.5 * e["cost"], rel=1e-5)
+    for ex in (capi.EXEC_HOST, capi.EXEC_DEVICE):
+        h.set_config(capi.default_config(exec=ex, solver=capi.SOLVER_LM6, huber_tau=tau, max_num_iterations=8))
+        pg, qg, _, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+        ref = o.pose6_lm(al.p0, al.q0, al.v0, iters=8, lambda0=0.01, huber_tau=tau)
+        assert np.array_equal(h.trace(0)["accepted"], ref["accepted"])
+        assert po.se3_distance(pg, qg, ref["p"], ref["q"]) <= TOL_POSE
+    h.close()
+
+
+# ---------------------------------------------------------------------------------------
+# edge cases the reference's functor would meet (no in-bounds test, Grid2D clamps; PhotometricError.hpp:157-172)
+def test_points_leaving_the_frame_and_borders(gpu, capi, synth, po):
+    al = synth.make_alignment(77, H=60, W=80, N=150)
+    o = po.Oracle(al)
+    cases = [
+        (np.array([0.5, 0.0, 0.0]), al.q0),                                    # everything shifted far right
+        (np.array([0.0, -0.4, 0.0]), al.q0),                                   # ... and up, outside the frame
+        (np.zeros(3), synth.quat_from_axis_angle([0, 1, 0], 0.6)),             # large rotation
+        (np.array([0.0, 0.0, -0.9]), al.q0),                                   # Pz down to 0.1: projections ~10x out
+        (np.array([0.03, 0.02, 0.0]), synth.quat_from_axis_angle([0, 0, 1], 0.2)),
+    ]
+    h = make_handle(capi, al, exec=capi.EXEC_HOST)
+    for p, q in cases:
+        g = h.eval(0, p, q, al.v0, ncols=6)
+        e = o.pose6_eval(p, q, al.v0)
+        assert np.isfinite(g["r"]).all()
+        scale = np.abs(e["r"]).max()
+        assert np.abs(g["r"] - e["r"]).max() <= 2e-5 * scale
+        assert rel(g["JtJ"], e["H"]) <= 1e-3 or np.linalg.norm(e["H"]) < 1e-12
+    h.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 255, 257, 1000])
+def test_ragged_point_counts(gpu, capi, synth, po, N):
+    al = synth.make_alignment(500 + N, H=96, W=128, N=N)
+    p, q = eval_pose(synth, 5)
+    o = po.Oracle(al, num_blocks=3)
+    h = make_handle(capi, al, num_blocks=3, exec=capi.EXEC_HOST)      # N < num_blocks: leading blocks empty
+    g = h.eval(0, p, q, al.v_true, ncols=12)
+    e = o.eval12(p, q, al.v_true)
+    assert np.abs(g["r"] - e["r_raw"]).max() <= TOL_R * max(np.abs(e["r_raw"]).max(), 1e-12)
+    assert rel(g["JtJ"], e["J_local_raw"].T @ e["J_local_raw"]) <= TOL_H
+    g6 = h.eval(0, p, q, al.v_true, ncols=6)
+    assert rel(g6["JtJ"], o.pose6_eval(p, q, al.v_true)["H"]) <= TOL_H
+    h.close()
+
+
+def test_handle_capacity_and_argument_errors(gpu, capi, synth):
+    al = synth.make_alignment(1, H=48, W=64, N=50)
+    cfg = capi.default_config()
+    h = capi.Handle(cfg, 2, 40, 48, 64)
+    with pytest.raises(capi.EdsError) as ei:
+        h.set_keyframe(0, al.norm_coord, al.grad, al.idp, al.weights, al.fx, al.fy, al.cx, al.cy)   # N > capacity
+    assert ei.value.code == capi.ERR_INVALID
+    with pytest.raises(capi.EdsError) as ei:
+        h.optimize(1)                                                # nothing uploaded
+    assert ei.value.code == capi.ERR_STATE
+    with pytest.raises(capi.EdsError):
+        h.set_state(5, al.p0, al.q0, al.v0)                          # slot out of range
+    with pytest.raises(capi.EdsError):
+        capi.Handle(cfg, 0, 10, 48, 64)
+    h.close()
+
+
+def test_failed_solve_leaves_state_untouched(gpu, capi, synth):
+    """Reference: on a non-usable solution px, qx, vx, residuals and loss params stay as they were
+    (Tracker.cpp:217-240)."""
+    al = synth.make_alignment(9, H=48, W=64, N=80)
+    bad = np.full_like(al.frame, np.nan)
+    for solver, ex in ((capi.SOLVER_REF12, capi.EXEC_HOST), (capi.SOLVER_LM6, capi.EXEC_HOST), (capi.SOLVER_LM6, capi.EXEC_DEVICE)):
+        h = make_handle(capi, al, solver=solver, exec=ex)
+        h.set_event_frame(0, bad)
+        p0, q0, v0 = np.array([0.01, 0.02, 0.03]), al.q0.copy(), al.v0.copy()
+        h.set_state(0, p0, q0, v0)
+        p, q, v = p0.copy(), q0.copy(), v0.copy()
+        with pytest.raises(capi.EdsError) as ei:
+            h.optimize(0, p=p, q=q, v=v)
+        assert ei.value.code == capi.ERR_NOT_USABLE
+        sp, sq, sv = h.get_state(0)
+        assert np.array_equal(sp, p0) and np.array_equal(sq, q0) and np.array_equal(sv, v0)
+        assert not h.info(0)["success"]
+        h.close()
+
+
+# ---------------------------------------------------------------------------------------
+# size-independent properties at the full BASELINE.json size
+def test_properties_full_size(gpu, capi, synth):
+    al = synth.make_alignment(1234)
+    p, q = eval_pose(synth, 11)
+    h = make_handle(capi, al, exec=capi.EXEC_HOST)
+    a = h.eval(0, p, q, al.v0, ncols=6)
+    b = h.eval(0, p, q, al.v0, ncols=6)
+    assert np.array_equal(a["r"], b["r"]) and np.array_equal(a["J"], b["J"]) and np.array_equal(a["JtJ"], b["JtJ"])   # idempotent
+    assert np.linalg.eigvalsh(a["JtJ"]).min() > 0                                       # SPD normal matrix
+    # reductions are what they claim to be
+    assert rel(a["JtJ"], a["J"].T @ a["J"]) <= 1e-5 and rel(a["Jtr"], a["J"].T @ a["r"]) <= 1e-5
+    # the residual is affine in the frame and the Jacobian linear: r(2F) - r(F) = r(F) - r(0)
+    h.set_event_frame(0, 2.0 * al.frame); r2 = h.eval(0, p, q, al.v0, ncols=6)
+    h.set_event_frame(0, 0.0 * al.frame); r0 = h.eval(0, p, q, al.v0, ncols=6)
+    assert np.abs((r2["r"] - a["r"]) - (a["r"] - r0["r"])).max() <= 2e-6 * np.abs(a["r"]).max()
+    assert rel(r2["J"], 2.0 * a["J"]) <= 1e-6 and np.abs(r0["J"]).max() == 0.0
+    # point order does not matter for the normal equations (permutation invariance)
+    perm = np.random.default_rng(0).permutation(al.N)
+    alp = type(al)(**{**al.__dict__, "norm_coord": al.norm_coord[perm], "grad": al.grad[perm], "idp": al.idp[perm],
+                      "weights": al.weights[perm]})
+    hp = make_handle(capi, alp, exec=capi.EXEC_HOST)
+    c = hp.eval(0, p, q, al.v0, ncols=6)
+    assert rel(c["JtJ"], a["JtJ"]) <= 1e-5 and np.abs(c["r"] - a["r"][perm]).max() <= 1e-6 * np.abs(a["r"]).max()
+    # weights scale rows: w -> 0.5 w halves r and J
+    alw = type(al)(**{**al.__dict__, "weights": 0.5 * al.weights})
+    hw = make_handle(capi, alw, exec=capi.EXEC_HOST)
+    d = hw.eval(0, p, q, al.v0, ncols=6)
+    assert rel(d["r"], 0.5 * a["r"]) <= 1e-6 and rel(d["JtJ"], 0.25 * a["JtJ"]) <= 1e-5
+    for x in (h, hp, hw):
+        x.close()
+
+
+def test_batch_slots_are_independent_and_match_single(gpu, capi, synth, po):
+    """B alignments in one handle (host lock-step and one persistent workgroup each on the device)
+    give the same answers as solving them one at a time."""
+    als = [synth.make_alignment(5000 + b, H=120, W=160, N=300 + 17 * b) for b in range(12)]
+    Nmax = max(a.N for a in als)
+    for ex in (capi.EXEC_HOST, capi.EXEC_DEVICE):
+        cfg = capi.default_config(exec=ex, solver=capi.SOLVER_LM6, max_num_iterations=6)
+        hb = capi.Handle(cfg, len(als), Nmax, 120, 160)
+        for b, a in enumerate(als):
+            hb.set_alignment(b, a)
+        hb.optimize_batch(0, 0, len(als))
+        for b, a in enumerate(als):
+            ref = po.Oracle(a).pose6_lm(a.p0, a.q0, a.v0, iters=6, lambda0=0.01)
+            p, q, v = hb.get_state(b)
+            assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
+            assert np.array_equal(hb.trace(b)["accepted"], ref["accepted"])
+            assert hb.info(b)["num_points"] == a.N
+        # a sub-range leaves the other slots alone
+        before = [hb.get_state(b) for b in range(len(als))]
+        hb.optimize_batch(0, 3, 4)
+        for b in (0, 1, 2, 7, 8, 11):
+            assert all(np.array_equal(x, y) for x, y in zip(before[b], hb.get_state(b)))
+        hb.close()
+
+
+def test_idepth_update_matches_fresh_upload(gpu, capi, synth, po):
+    """The reference re-reads the inverse depths on every optimize (Tracker.cpp:167)."""
+    al = synth.make_alignment(31, H=96, W=128, N=400)
+    idp2 = al.idp * 1.07
+    p, q = eval_pose(synth, 2)
+    h = make_handle(capi, al, exec=capi.EXEC_HOST)
+    h.set_idepth(0, idp2)
+    al2 = type(al)(**{**al.__dict__, "idp": idp2})
+    e = po.Oracle(al2).pose6_eval(p, q, al.v0)
+    g = h.eval(0, p, q, al.v0, ncols=6)
+    assert np.abs(g["r"] - e["r"]).max() <= TOL_R * np.abs(e["r"]).max() and rel(g["JtJ"], e["H"]) <= TOL_H
+    h.close()
+
+
+def test_tracker_mirror_api(gpu, capi, synth, po):
+    """The Python mirror of eds::tracking::Tracker behaves like Tracker.cpp:74-79,104-260,281-317."""
+    import importlib
+    trk = importlib.import_module("slam-eds_amd.tracker")
+    al = synth.make_alignment(1235, H=240, W=320, N=900, start="ctor")
+    K = np.array([[al.fx, 0, al.cx], [0, al.fy, al.cy], [0, 0, 1.0]])
+    kf = trk.KeyFrame(al.norm_coord, al.grad, al.weights, al.idp, K, al.H, al.W)
+    cfg = trk.Config(loss_type=trk.HUBER, loss_params=[0.3], options=trk.SolverOptions(num_threads=2, max_num_iterations=[12, 6]))
+    t = trk.Tracker(kf, cfg)
+    assert np.allclose(t.getVelocity(), np.full(6, 1 / np.sqrt(6)))                  # ctor seed, Tracker.cpp:45-46
+    T0 = np.eye(4)
+    ok, T = t.optimize(0, al.frame, T0, loss_param_method=trk.MAD)
+    ref = po.Oracle(al, num_blocks=2, loss_type=po.LOSS_HUBER, loss_param=0.3, max_num_iterations=12).solve_lm(al.p0, al.q0, al.v0)
+    assert ok and t.getInfo().success and t.getInfo().num_iterations == ref["num_iterations"]
+    assert po.se3_distance(t.px, t.qx, ref["p"], ref["q"]) <= TOL_POSE
+    assert np.allclose(T @ t.getTransform(), np.eye(4), atol=1e-12)                  # returns the inverse (:220)
+    r_fin = po.Oracle(al, num_blocks=2).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
+    assert t.config.loss_params[0] == pytest.approx(po.loss_param(r_fin, po.LP_MAD)[0], rel=1e-3)   # :233
+    assert kf.residuals.shape == (al.N,)
+    assert np.allclose(t.linearVelocity(), t.vx[:3]) and np.allclose(t.angularVelocity(), t.vx[3:])
+    # set() stores the inverse transform (:74-79)
+    t.set(T)
+    assert np.allclose(t.getTransform(), np.linalg.inv(T), atol=1e-12)
+    # reset overloads (:49-72)
+    t.reset(kf, np.zeros(3), np.array([0, 0, 0, 1.0]), False)
+    assert np.allclose(t.vx, np.full(6, 1 / np.sqrt(6)))
+    t.reset(kf, np.zeros(3), np.array([0, 0, 0, 1.0]), al.v_true)
+    assert np.array_equal(t.vx, al.v_true)
+    # a NaN frame gives ok == False and leaves everything alone
+    px, qx, vx, lp = t.px.copy(), t.qx.copy(), t.vx.copy(), list(t.config.loss_params)
+    ok, T2 = t.optimize(1, np.full_like(al.frame, np.nan), T)
+    assert not ok and T2 is T and np.array_equal(t.px, px) and np.array_equal(t.vx, vx) and t.config.loss_params == lp
+    t.close()
