@@ -142,6 +142,12 @@ int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
 /* Tracker::reset / set / optimize overloads seed px,qx,vx (Tracker.cpp:49-102). */
 int eds_trk_set_state(eds_trk* h, int slot, const double p[3], const double q_xyzw[4], const double v[6]);
 int eds_trk_get_state(eds_trk* h, int slot, double p[3], double q_xyzw[4], double v[6]);
+/* Bulk forms for batches: p is count x 3, q count x 4, v count x 6 (row-major); any may be NULL. */
+int eds_trk_set_states(eds_trk* h, int first, int count, const double* p, const double* q_xyzw, const double* v);
+int eds_trk_get_states(eds_trk* h, int first, int count, double* p, double* q_xyzw, double* v);
+/* Bulk result table of a batch: count x 16 doubles per slot = p[3] q[4] v[6] final_cost iterations success
+ * (the row format gathered across GPUs by the multi-GPU driver). */
+int eds_trk_get_results(eds_trk* h, int first, int count, double* table16);
 
 /* ---- evaluation (one residual/Jacobian pass + reduction) ------------------------------------ */
 /* Evaluates slot `slot` at (p,q,v).  ncols = 6: SE(3) left-perturbation Jacobian

@@ -84,12 +84,9 @@ class BatchTracker:
             self.handle.optimize_batch(level, 0, self.count, sync=sync)
 
     def local_results(self) -> np.ndarray:
-        out = np.zeros((self.count, RESULT_WIDTH))
-        for i in range(self.count):
-            p, q, v = self.handle.get_state(i)
-            info = self.handle.info(i)
-            out[i] = pack_result(p, q, v, info["final_cost"], info["num_iterations"], info["success"])
-        return out
+        if self.count == 0:
+            return np.zeros((0, RESULT_WIDTH))
+        return self.handle.results(0, self.count)
 
     def gather(self, device=None) -> np.ndarray:
         return gather_results(self.local_results(), self.total, device=device)

@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libeds_hip.so")
+LIB_PATH = os.environ.get("EDS_HIP_LIB") or os.path.join(CSRC, "libeds_hip.so")   # env override: diagnostic builds only
 
 # enums of include/eds_hip.h
 EDS_OK = 0
@@ -31,7 +31,8 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
-    "eds_trk_set_state", "eds_trk_get_state", "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
+    "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
+    "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
 )
@@ -104,6 +105,9 @@ def lib():
         L.eds_trk_set_event_frame_f32.argtypes = [C.c_void_p, C.c_int, _fp]
         L.eds_trk_set_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_set_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_get_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_get_results.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         L.eds_trk_eval.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
         L.eds_trk_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Info)]
         L.eds_trk_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -219,6 +223,25 @@ class Handle:
         p, q, v = np.zeros(3), np.zeros(4), np.zeros(6)
         _check(lib().eds_trk_get_state(self._h, slot, _p(p), _p(q), _p(v)))
         return p, q, v
+
+    def set_states(self, first, p=None, q=None, v=None):
+        """Bulk seed of slots [first, first+count): p count x 3, q count x 4, v count x 6."""
+        arrs = [None if a is None else _f64(a) for a in (p, q, v)]
+        count = next(a.shape[0] for a in arrs if a is not None)
+        _check(lib().eds_trk_set_states(self._h, first, count, *[_p(a) for a in arrs]))
+
+    def get_states(self, first=0, count=None):
+        count = self.batch - first if count is None else count
+        p, q, v = np.zeros((count, 3)), np.zeros((count, 4)), np.zeros((count, 6))
+        _check(lib().eds_trk_get_states(self._h, first, count, _p(p), _p(q), _p(v)))
+        return p, q, v
+
+    def results(self, first=0, count=None):
+        """count x 16 table: p[3] q[4] v[6] final_cost iterations success."""
+        count = self.batch - first if count is None else count
+        t = np.zeros((count, 16))
+        _check(lib().eds_trk_get_results(self._h, first, count, _p(t)))
+        return t
 
     # -- evaluation / solve --------------------------------------------------------------
     def eval(self, slot, p, q, v, ncols=6, want_jacobian=True):

@@ -282,11 +282,11 @@ int materialise_residuals(eds_trk* h, int slot) {
 void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
-    void* dptrs[] = {h->dX, h->dY, h->dZ, h->dpose, h->dG, h->dpart, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
+    void* dptrs[] = {h->df0x, h->df0y, h->dcell0, h->dpose, h->dG, h->dpart, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
                      h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
-    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f64, h->h_f32, h->h_r};
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -295,6 +295,25 @@ void free_all(eds_trk* h) {
 }
 
 }  // namespace
+
+// Row-major H x W host frame (double or float) -> the handle's HBM layout in pinned staging:
+// fp32, padded to multiples of 4 with replicated border pixels (= Grid2D's clamp), optionally in
+// 4x4 tiles of one 64-byte sector each (eds_device.hpp FrameView).
+template <class T>
+static void stage_frame(eds_trk* h, const T* frame) {
+    const int H = h->H, W = h->W, Hp = h->Hp, Wp = h->Wp, TW = Wp >> 2;
+    float* dst = h->h_f32;
+    for (int r = 0; r < Hp; ++r) {
+        const T* src = frame + (size_t)std::min(r, H - 1) * W;
+        if (h->tiled) {
+            float* trow = dst + ((size_t)(r >> 2) * TW) * 16 + ((r & 3) << 2);
+            for (int c = 0; c < Wp; ++c) trow[(size_t)(c >> 2) * 16 + (c & 3)] = (float)src[std::min(c, W - 1)];
+        } else {
+            float* drow = dst + (size_t)r * Wp;
+            for (int c = 0; c < Wp; ++c) drow[c] = (float)src[std::min(c, W - 1)];
+        }
+    }
+}
 
 int eds_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count) { return solve_host(h, level, first, count); }
@@ -345,6 +364,9 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (!h) return fail(EDS_ERR_INVALID, "out of memory");
     h->cfg = *cfg;
     h->B = batch; h->Nmax = max_points_; h->H = H; h->W = W; h->dev = cfg->device;
+    h->Hp = (H + 3) & ~3; h->Wp = (W + 3) & ~3;
+    h->tiled = 1;
+    if (const char* e = getenv("EDS_FRAME_LAYOUT")) h->tiled = (std::strcmp(e, "rowmajor") != 0);   // tuning knob
     h->Np = ((max_points_ + EDS_POINT_ALIGN - 1) / EDS_POINT_ALIGN) * EDS_POINT_ALIGN;
     h->max_seg = h->Np / EDS_TPB + 2 * EDS_MAX_BLOCKS + 2;
     h->slots.resize(batch);
@@ -369,32 +391,27 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("stream/event: ") + hipGetErrorString(e)); }
-    EDS_ALLOC(h->dX, BN * 8); EDS_ALLOC(h->dY, BN * 8); EDS_ALLOC(h->dZ, BN * 8);
+    EDS_ALLOC(h->df0x, BN * 4); EDS_ALLOC(h->df0y, BN * 4); EDS_ALLOC(h->dcell0, BN * 4);
     EDS_ALLOC(h->dx, BN * 4); EDS_ALLOC(h->dy, BN * 4); EDS_ALLOC(h->drho, BN * 4);
     EDS_ALLOC(h->dgx, BN * 4); EDS_ALLOC(h->dgy, BN * 4); EDS_ALLOC(h->dw, BN * 4);
     EDS_ALLOC(h->dmhat, BN * 4); EDS_ALLOC(h->dr, BN * 4); EDS_ALLOC(h->dJ, BN * 4 * 12);
-    EDS_ALLOC(h->dframe, (size_t)batch * H * W * 4);
+    EDS_ALLOC(h->dframe, (size_t)batch * h->Hp * h->Wp * 4);
     EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_ALLOC(h->dG, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
     EDS_ALLOC(h->dpart, (size_t)batch * h->max_seg * EDS_RED_K * 8);
     EDS_HALLOC(h->h_pose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_HALLOC(h->h_part, (size_t)batch * h->max_seg * EDS_RED_K * 8);
     EDS_HALLOC(h->h_G, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
-    EDS_HALLOC(h->h_f64, (size_t)h->Np * 3 * 8);
-    h->h_f32_elems = std::max((size_t)H * W, (size_t)h->Np * 12);
+    h->h_f32_elems = std::max((size_t)h->Hp * h->Wp, (size_t)h->Np * 12);
     EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
     EDS_HALLOC(h->h_r, BN * 4);
     std::memset(h->h_pose, 0, (size_t)batch * EDS_POSE_STRIDE * 8);
     std::memset(h->h_G, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
-    hipMemsetAsync(h->dX, 0, BN * 8, h->st); hipMemsetAsync(h->dY, 0, BN * 8, h->st);
-    {   // Z = 1 keeps padded lanes finite
-        std::vector<double> ones(h->Np, 1.0);
-        for (int b = 0; b < batch; ++b) hipMemcpy(h->dZ + (size_t)b * h->Np, ones.data(), (size_t)h->Np * 8, hipMemcpyHostToDevice);
-    }
-    float* f32s[] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw, h->dmhat, h->dr};
+    hipMemsetAsync(h->dcell0, 0, BN * 4, h->st);
+    float* f32s[] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw, h->dmhat, h->dr, h->df0x, h->df0y};
     for (float* p : f32s) hipMemsetAsync(p, 0, BN * 4, h->st);
     hipMemsetAsync(h->dJ, 0, BN * 4 * 12, h->st);
-    hipMemsetAsync(h->dframe, 0, (size_t)batch * H * W * 4, h->st);
+    hipMemsetAsync(h->dframe, 0, (size_t)batch * h->Hp * h->Wp * 4, h->st);
     hipMemsetAsync(h->dpose, 0, (size_t)batch * EDS_POSE_STRIDE * 8, h->st);
     hipMemsetAsync(h->dG, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8, h->st);
     hipMemsetAsync(h->dpart, 0, (size_t)batch * h->max_seg * EDS_RED_K * 8, h->st);
@@ -438,33 +455,34 @@ int eds_trk_get_config(const eds_trk* h, eds_trk_cfg* cfg) {
 static int upload_points(eds_trk* h, int slot, int N, const double* norm_xy, const double* grad_xy, const double* idp,
                          const double* w) {
     const size_t off = (size_t)slot * h->Np;
-    // back-projection kp = (x/rho', y/rho', 1/rho'), rho' = idp + 1e-5 (PhotometricError.hpp:95-106)
-    double* X = h->h_f64; double* Y = X + h->Np; double* Z = Y + h->Np;
+    const Slot& s = h->slots[slot];
     float* f = h->h_f32;
-    for (int i = 0; i < h->Np; ++i) {
-        if (i < N) {
-            const double z = 1.0 / (idp[i] + 1e-5);
-            X[i] = norm_xy[2 * i] * z; Y[i] = norm_xy[2 * i + 1] * z; Z[i] = z;
-        } else { X[i] = 0.0; Y[i] = 0.0; Z[i] = 1.0; }
-    }
-    EDS_HIP_TRY(hipMemcpyAsync(h->dX + off, X, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
-    EDS_HIP_TRY(hipMemcpyAsync(h->dY + off, Y, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
-    EDS_HIP_TRY(hipMemcpyAsync(h->dZ + off, Z, (size_t)h->Np * 8, hipMemcpyHostToDevice, h->st));
     const int Np = h->Np;
+    int* cell = reinterpret_cast<int*>(f + (size_t)8 * Np);
     for (int i = 0; i < Np; ++i) {
         const bool in = i < N;
         f[0 * Np + i] = in ? (float)norm_xy[2 * i] : 0.f;
         f[1 * Np + i] = in ? (float)norm_xy[2 * i + 1] : 0.f;
-        f[2 * Np + i] = in ? (float)idp[i] : 0.f;
+        f[2 * Np + i] = in ? (float)idp[i] : 1.f;
         if (grad_xy) { f[3 * Np + i] = in ? (float)grad_xy[2 * i] : 0.f; f[4 * Np + i] = in ? (float)grad_xy[2 * i + 1] : 0.f; }
         if (w) f[5 * Np + i] = in ? (float)w[i] : 0.f;
+        // the point's own keyframe pixel u0 = fx x + cx, v0 = fy y + cy in fp64, split into an integer
+        // cell and an fp32 fraction: the kernels only ever add a small displacement to it (eds_device.hpp)
+        double u0 = in ? s.K[0] * norm_xy[2 * i] + s.K[2] : 0.0, v0 = in ? s.K[1] * norm_xy[2 * i + 1] + s.K[3] : 0.0;
+        double cu = std::floor(u0), cv = std::floor(v0);
+        if (!(cu > -32000.0)) cu = -32000.0; if (cu > 32000.0) cu = 32000.0;     // far-off points keep the excess in the fraction
+        if (!(cv > -32000.0)) cv = -32000.0; if (cv > 32000.0) cv = 32000.0;
+        f[6 * Np + i] = (float)(u0 - cu);
+        f[7 * Np + i] = (float)(v0 - cv);
+        cell[i] = (int)(((unsigned)(int)cv << 16) | ((unsigned)(int)cu & 0xffffu));
     }
-    float* dst[6] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw};
-    for (int k = 0; k < 6; ++k) {
+    float* dst[8] = {h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw, h->df0x, h->df0y};
+    for (int k = 0; k < 8; ++k) {
         if ((k == 3 || k == 4) && !grad_xy) continue;
         if (k == 5 && !w) continue;
         EDS_HIP_TRY(hipMemcpyAsync(dst[k] + off, f + (size_t)k * Np, (size_t)Np * 4, hipMemcpyHostToDevice, h->st));
     }
+    EDS_HIP_TRY(hipMemcpyAsync(h->dcell0 + off, cell, (size_t)Np * 4, hipMemcpyHostToDevice, h->st));
     return EDS_OK;
 }
 
@@ -503,14 +521,9 @@ int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) {
     if (!s.has_kf) return fail(EDS_ERR_STATE, "keyframe not set");
     if (N != s.N || !idp) return fail(EDS_ERR_INVALID, "idp size mismatch");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    // need x,y back: they are resident as fp32 only, so re-read the fp64 X/Z ratio-free form from the device
-    std::vector<double> X(h->Np), Y(h->Np), Z(h->Np), nxy((size_t)2 * N);
-    const size_t off = (size_t)slot * h->Np;
-    EDS_HIP_TRY(hipMemcpy(X.data(), h->dX + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
-    EDS_HIP_TRY(hipMemcpy(Y.data(), h->dY + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
-    EDS_HIP_TRY(hipMemcpy(Z.data(), h->dZ + off, (size_t)h->Np * 8, hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; ++i) { nxy[2 * i] = X[i] / Z[i]; nxy[2 * i + 1] = Y[i] / Z[i]; }
-    if ((rc = upload_points(h, slot, N, nxy.data(), nullptr, idp, nullptr))) return rc;
+    // only the inverse-depth plane changes (the geometry uses rho' = idp + 1e-5, the model the raw idp)
+    for (int i = 0; i < h->Np; ++i) h->h_f32[i] = i < N ? (float)idp[i] : 1.f;
+    EDS_HIP_TRY(hipMemcpyAsync(h->drho + (size_t)slot * h->Np, h->h_f32, (size_t)h->Np * 4, hipMemcpyHostToDevice, h->st));
     return refresh_gram(h, slot);
 }
 
@@ -519,8 +532,8 @@ int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame) {
     if (rc) return rc;
     if (!frame) return fail(EDS_ERR_INVALID, "null frame");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    const size_t n = (size_t)h->H * h->W;
-    for (size_t i = 0; i < n; ++i) h->h_f32[i] = (float)frame[i];
+    stage_frame(h, frame);
+    const size_t n = (size_t)h->Hp * h->Wp;
     EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
     EDS_HIP_TRY(hipStreamSynchronize(h->st));
     h->slots[slot].has_frame = true;
@@ -532,8 +545,9 @@ int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
     if (rc) return rc;
     if (!frame) return fail(EDS_ERR_INVALID, "null frame");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    const size_t n = (size_t)h->H * h->W;
-    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, frame, n * 4, hipMemcpyHostToDevice, h->st));
+    stage_frame(h, frame);
+    const size_t n = (size_t)h->Hp * h->Wp;
+    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
     EDS_HIP_TRY(hipStreamSynchronize(h->st));
     h->slots[slot].has_frame = true;
     return EDS_OK;
@@ -556,6 +570,49 @@ int eds_trk_get_state(eds_trk* h, int slot, double p[3], double q[4], double v[6
     if (p) std::memcpy(p, s.p, sizeof(s.p));
     if (q) std::memcpy(q, s.q, sizeof(s.q));
     if (v) std::memcpy(v, s.v, sizeof(s.v));
+    return EDS_OK;
+}
+
+static int check_range(const eds_trk* h, int first, int count) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (first < 0 || count < 1 || first + count > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds");
+    return EDS_OK;
+}
+
+int eds_trk_set_states(eds_trk* h, int first, int count, const double* p, const double* q, const double* v) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i) {
+        Slot& s = h->slots[first + i];
+        if (p) std::memcpy(s.p, p + 3 * i, sizeof(s.p));
+        if (q) std::memcpy(s.q, q + 4 * i, sizeof(s.q));
+        if (v) std::memcpy(s.v, v + 6 * i, sizeof(s.v));
+    }
+    return EDS_OK;
+}
+
+int eds_trk_get_states(eds_trk* h, int first, int count, double* p, double* q, double* v) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    for (int i = 0; i < count; ++i) {
+        const Slot& s = h->slots[first + i];
+        if (p) std::memcpy(p + 3 * i, s.p, sizeof(s.p));
+        if (q) std::memcpy(q + 4 * i, s.q, sizeof(s.q));
+        if (v) std::memcpy(v + 6 * i, s.v, sizeof(s.v));
+    }
+    return EDS_OK;
+}
+
+int eds_trk_get_results(eds_trk* h, int first, int count, double* t) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    if (!t) return fail(EDS_ERR_INVALID, "null output");
+    for (int i = 0; i < count; ++i) {
+        const Slot& s = h->slots[first + i];
+        double* o = t + 16 * i;
+        std::memcpy(o, s.p, 24); std::memcpy(o + 3, s.q, 32); std::memcpy(o + 7, s.v, 48);
+        o[13] = s.info.final_cost; o[14] = s.info.num_iterations; o[15] = s.info.success ? 1.0 : 0.0;
+    }
     return EDS_OK;
 }
 

@@ -7,15 +7,15 @@
 
 namespace edsd {
 
-// ---------------------------------------------------------------------------------------
-// Frame sampling.  The frame is fp32 row-major; indices clamp to the border exactly like
-// ceres::Grid2D::GetValue (reference use: PhotometricError.hpp:110-111).
-// ---------------------------------------------------------------------------------------
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-byte load
 typedef float float2u __attribute__((ext_vector_type(2), aligned(4)));
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---------------------------------------------------------------------------------------
+// Frame sampling.  Indices clamp to the border exactly like ceres::Grid2D::GetValue
+// (reference use: PhotometricError.hpp:110-111).
+// ---------------------------------------------------------------------------------------
 // Catmull-Rom cubic Hermite through p1 (x=0), p2 (x=1): value and derivative
 // (ceres CubicHermiteSpline; same spline restated at reference src/utils/globalFuncs.h:192-207).
 __device__ __forceinline__ void hermite(float p0, float p1, float p2, float p3, float x, float& f, float& df) {
@@ -26,22 +26,61 @@ __device__ __forceinline__ void hermite(float p0, float p1, float p2, float p3, 
     df = c + x * (2.0f * b + 3.0f * a * x);
 }
 
+// A frame in HBM.  Two layouts:
+//   row-major  pixel (r,c) at r*Wp + c
+//   tiled      4x4-pixel tiles of 16 floats = ONE 64-byte HBM sector each; tile (r>>2, c>>2) at
+//              ((r>>2)*TW + (c>>2))*16, pixel at + (r&3)*4 + (c&3).
+// A bicubic 4x4 neighbourhood at a random offset spans 4 rows x 1.19 sectors = 4.75 sectors of a
+// row-major frame but only (1 + 3/4)^2 = 3.06 tiles, so the tiled frame cuts the gather traffic
+// (the bound of every pass) by a third and halves the touched cache footprint.
+// The allocation is padded to multiples of 4 with border-replicated pixels, which is exactly what
+// Grid2D's index clamp returns there.
+struct FrameView {
+    const float* __restrict__ base;
+    int H, W;          // logical size (clamp range)
+    int Hp, Wp;        // padded size (multiples of 4)
+    int TW;            // tiles per tile-row = Wp / 4
+    int tiled;
+};
+__device__ __forceinline__ size_t frame_index(const FrameView& f, int r, int c) {
+    return f.tiled ? ((size_t)((r >> 2) * f.TW + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * f.Wp + c);
+}
+
 // Loads the 4x4 neighbourhood rows r0-1..r0+2, cols c0-1..c0+2 (clamped).
-__device__ __forceinline__ void load_patch16(const float* __restrict__ frame, int H, int W, int r0, int c0, float (&p)[16]) {
-    if (c0 >= 1 && c0 + 2 < W && r0 >= 1 && r0 + 2 < H) {           // interior: four 16-byte row segments
-        const float* base = frame + (size_t)(r0 - 1) * W + (c0 - 1);
+__device__ __forceinline__ void load_patch16(const FrameView& f, int r0, int c0, float (&p)[16]) {
+    const bool interior = c0 >= 1 && c0 + 2 < f.Wp && r0 >= 1 && r0 + 2 < f.Hp;
+    if (interior && f.tiled) {                                        // per row two aligned 16-byte tile rows
+        const int ca = c0 - 1, s = ca & 3;
+        const int txa = ca >> 2, txb = (c0 + 2) >> 2;
+        const bool s2 = s & 2, s1 = s & 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4u v = *reinterpret_cast<const float4u*>(base + (size_t)k * W);
+            const int r = r0 - 1 + k;
+            const float* trow = f.base + ((size_t)(r >> 2) * f.TW) * 16 + ((r & 3) << 2);
+            const float4 a = *reinterpret_cast<const float4*>(trow + (size_t)txa * 16);
+            const float4 b = *reinterpret_cast<const float4*>(trow + (size_t)txb * 16);
+            // 8 floats [a.x a.y a.z a.w b.x b.y b.z ..] shifted left by s in {0..3}: two-stage barrel shift
+            const float t0 = s2 ? a.z : a.x, t1 = s2 ? a.w : a.y, t2 = s2 ? b.x : a.z, t3 = s2 ? b.y : a.w, t4 = s2 ? b.z : b.x;
+            p[4 * k + 0] = s1 ? t1 : t0;
+            p[4 * k + 1] = s1 ? t2 : t1;
+            p[4 * k + 2] = s1 ? t3 : t2;
+            p[4 * k + 3] = s1 ? t4 : t3;
+        }
+    } else if (interior) {                                            // row-major: four dword-aligned 16-byte row segments
+        const float* base = f.base + (size_t)(r0 - 1) * f.Wp + (c0 - 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4u v = *reinterpret_cast<const float4u*>(base + (size_t)k * f.Wp);
             p[4 * k + 0] = v.x; p[4 * k + 1] = v.y; p[4 * k + 2] = v.z; p[4 * k + 3] = v.w;
         }
     } else {
+        int rr[4], cc[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float* row = frame + (size_t)clampi(r0 - 1 + k, 0, H - 1) * W;
+        for (int k = 0; k < 4; ++k) { rr[k] = clampi(r0 - 1 + k, 0, f.H - 1); cc[k] = clampi(c0 - 1 + k, 0, f.W - 1); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) p[4 * k + j] = row[clampi(c0 - 1 + j, 0, W - 1)];
-        }
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[4 * k + j] = f.base[frame_index(f, rr[k], cc[j])];
     }
 }
 
@@ -55,17 +94,17 @@ __device__ __forceinline__ void bicubic_patch(const float (&p)[16], float ay, fl
     hermite(d[0], d[1], d[2], d[3], ay, Ecol, unused);
 }
 
-__device__ __forceinline__ void load_patch4(const float* __restrict__ frame, int H, int W, int r0, int c0, float (&p)[4]) {
-    if (c0 >= 0 && c0 + 1 < W && r0 >= 0 && r0 + 1 < H) {
-        const float* base = frame + (size_t)r0 * W + c0;
+__device__ __forceinline__ void load_patch4(const FrameView& f, int r0, int c0, float (&p)[4]) {
+    if (!f.tiled && c0 >= 0 && c0 + 1 < f.Wp && r0 >= 0 && r0 + 1 < f.Hp) {
+        const float* base = f.base + (size_t)r0 * f.Wp + c0;
         const float2u a = *reinterpret_cast<const float2u*>(base);
-        const float2u b = *reinterpret_cast<const float2u*>(base + W);
+        const float2u b = *reinterpret_cast<const float2u*>(base + f.Wp);
         p[0] = a.x; p[1] = a.y; p[2] = b.x; p[3] = b.y;
     } else {
-        const float* ra = frame + (size_t)clampi(r0, 0, H - 1) * W;
-        const float* rb = frame + (size_t)clampi(r0 + 1, 0, H - 1) * W;
-        const int ca = clampi(c0, 0, W - 1), cb = clampi(c0 + 1, 0, W - 1);
-        p[0] = ra[ca]; p[1] = ra[cb]; p[2] = rb[ca]; p[3] = rb[cb];
+        const int ra = clampi(r0, 0, f.H - 1), rb = clampi(r0 + 1, 0, f.H - 1);
+        const int ca = clampi(c0, 0, f.W - 1), cb = clampi(c0 + 1, 0, f.W - 1);
+        p[0] = f.base[frame_index(f, ra, ca)]; p[1] = f.base[frame_index(f, ra, cb)];
+        p[2] = f.base[frame_index(f, rb, ca)]; p[3] = f.base[frame_index(f, rb, cb)];
     }
 }
 __device__ __forceinline__ void bilinear_patch(const float (&p)[4], float ay, float ax, float& E, float& Erow, float& Ecol) {
@@ -75,51 +114,69 @@ __device__ __forceinline__ void bilinear_patch(const float (&p)[4], float ay, fl
     Ecol = (1.0f - ay) * (p[1] - p[0]) + ay * (p[3] - p[2]);
 }
 
-// Splits a projected pixel coordinate (fp64) into the integer cell and the fp32 phase,
-// robust to NaN/inf/behind-camera projections (the reference has no in-bounds test,
-// PhotometricError.hpp:157-172: Grid2D simply clamps).
-__device__ __forceinline__ void split_coord(double u, int size, int& cell, float& phase) {
-    const double lo = -8.0, hi = (double)size + 8.0;
-    if (u >= lo && u <= hi) {
-        const double fu = floor(u);
-        cell = (int)fu;
-        phase = (float)(u - fu);
-    } else {                       // far outside (or NaN): every tap clamps to one border pixel
-        cell = (u > hi) ? size + 8 : -8;
-        phase = 0.0f;
-    }
+// ---------------------------------------------------------------------------------------
+// Per-point geometry in fp32 — WITHOUT the 1e-4 px sub-pixel noise a naive fp32 projection has at
+// u ~ 640..1280.  The reference computes P = R kp + t, u = fx Px/Pz + cx in fp64
+// (PhotometricError.hpp:157-168).  Here everything is expressed through the SMALL displacement
+//     d = (R - I) m + t rho'          m = (x, y, 1),  rho' = idp + 1e-5,   P = (m + d) / rho'
+// (R - I comes from the quaternion without cancellation, eds_math.hpp), so that
+//     u - u0 = fx (d0 - x d2) / (1 + d2),   u0 = fx x + cx  (the point's own keyframe pixel)
+// is a few pixels known to ~1e-7 relative, and u0 is carried as integer cell + fp32 fraction
+// computed once in fp64 when the keyframe is uploaded.  Measured against the fp64 oracle this
+// keeps residuals within 2e-7 of max|r| (tests/test_parity_gpu.py) at half the fp64 issue cost.
+// ---------------------------------------------------------------------------------------
+struct PoseF {                     // wave-uniform (SGPRs)
+    float D[9], t[3], fx, fy;
+};
+// Forces a wave-uniform value into an SGPR (values read from LDS otherwise occupy a VGPR per lane).
+__device__ __forceinline__ float uniformf(float x) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+// pb: a slot's pose block (doubles) in global memory or LDS
+__device__ __forceinline__ void load_pose(const double* pb, PoseF& ps) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ps.D[i] = uniformf((float)pb[EDS_PB_D + i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ps.t[i] = uniformf((float)pb[EDS_PB_T + i]);
+    ps.fx = uniformf((float)pb[EDS_PB_K]);
+    ps.fy = uniformf((float)pb[EDS_PB_K + 1]);
 }
 
-template <int SAMPLING>
-__device__ __forceinline__ void sample_frame(const float* __restrict__ frame, int H, int W, double vrow, double ucol,
-                                             float& E, float& Erow, float& Ecol) {
+struct PointKf {                   // per-point keyframe constants (SoA in HBM, registers in the persistent kernel)
+    float x, y, rhop;              // normalised coords, idp + 1e-5
+    float f0x, f0y;                // fractional part of the keyframe pixel (u0, v0)
+    int cell0;                     // integer part, packed (row << 16) | (col & 0xffff)
+};
+struct PointGeom {
+    float Px, Py, Pz, iz, un, vn;
     int r0, c0;
     float ay, ax;
-    split_coord(vrow, H, r0, ay);
-    split_coord(ucol, W, c0, ax);
-    if (SAMPLING == 0) {
-        float p[16];
-        load_patch16(frame, H, W, r0, c0, p);
-        bicubic_patch(p, ay, ax, E, Erow, Ecol);
-    } else {
-        float p[4];
-        load_patch4(frame, H, W, r0, c0, p);
-        bilinear_patch(p, ay, ax, E, Erow, Ecol);
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// Per-point geometry.  P = R kp + t in fp64 (sub-pixel phase needs it), the rest in fp32.
-// ---------------------------------------------------------------------------------------
-struct PoseRT {                    // wave-uniform, lives in SGPRs
-    double R[9], t[3], fx, fy, cx, cy;
 };
-__device__ __forceinline__ void load_pose(const double* __restrict__ pb, PoseRT& ps) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) ps.R[i] = pb[EDS_PB_R + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ps.t[i] = pb[EDS_PB_T + i];
-    ps.fx = pb[EDS_PB_K]; ps.fy = pb[EDS_PB_K + 1]; ps.cx = pb[EDS_PB_K + 2]; ps.cy = pb[EDS_PB_K + 3];
+__device__ __forceinline__ void split_rel(float s, int base, int& cell, float& phase) {
+    // s = keyframe fraction + displacement [px]; robust to NaN / inf / huge (the reference has no
+    // in-bounds test, PhotometricError.hpp:157-172: Grid2D simply clamps)
+    const float fl = floorf(s);
+    const bool sane = fabsf(s) < 60000.0f;
+    cell = base + (sane ? (int)fl : (s > 0.0f ? 60000 : -60000));
+    phase = sane ? s - fl : 0.0f;
+}
+__device__ __forceinline__ void project_point(const PoseF& ps, const PointKf& k, PointGeom& g) {
+    const float d0 = ps.D[0] * k.x + ps.D[1] * k.y + ps.D[2] + ps.t[0] * k.rhop;
+    const float d1 = ps.D[3] * k.x + ps.D[4] * k.y + ps.D[5] + ps.t[1] * k.rhop;
+    const float d2 = ps.D[6] * k.x + ps.D[7] * k.y + ps.D[8] + ps.t[2] * k.rhop;
+    const float s = 1.0f + d2;                   // Pz rho'
+    const float is = 1.0f / s;
+    const float Z = 1.0f / k.rhop;
+    g.un = (k.x + d0) * is;
+    g.vn = (k.y + d1) * is;
+    g.Px = (k.x + d0) * Z;
+    g.Py = (k.y + d1) * Z;
+    g.Pz = s * Z;
+    g.iz = k.rhop * is;
+    const float du = ps.fx * (d0 - k.x * d2) * is;      // u - u0   (column, PhotometricError.hpp:167)
+    const float dv = ps.fy * (d1 - k.y * d2) * is;      // v - v0   (row,    PhotometricError.hpp:168)
+    split_rel(k.f0x + du, (int)(short)(k.cell0 & 0xffff), g.c0, g.ax);
+    split_rel(k.f0y + dv, k.cell0 >> 16, g.r0, g.ay);
 }
 
 struct PointProj {
@@ -127,27 +184,42 @@ struct PointProj {
     float g0, g1, g2;              // dE/dP  (gradE_P of SURVEY §8a)
     float E;
 };
-
-// Projects, samples and forms dE/dP for one point.
-template <int SAMPLING>
-__device__ __forceinline__ void project_sample(const float* __restrict__ frame, int H, int W, const PoseRT& ps,
-                                               double X, double Y, double Z, PointProj& o) {
-    const double Px = ps.R[0] * X + ps.R[1] * Y + ps.R[2] * Z + ps.t[0];
-    const double Py = ps.R[3] * X + ps.R[4] * Y + ps.R[5] * Z + ps.t[1];
-    const double Pz = ps.R[6] * X + ps.R[7] * Y + ps.R[8] * Z + ps.t[2];
-    const double iz = 1.0 / Pz;
-    const double un = Px * iz, vn = Py * iz;
-    const double u = ps.fx * un + ps.cx;       // column  (PhotometricError.hpp:167)
-    const double v = ps.fy * vn + ps.cy;       // row     (PhotometricError.hpp:168)
-    float E, Er, Ec;
-    sample_frame<SAMPLING>(frame, H, W, v, u, E, Er, Ec);
-    const float izf = (float)iz, unf = (float)un, vnf = (float)vn;
-    const float dx = (float)ps.fx * Ec, dy = (float)ps.fy * Er;
-    o.g0 = dx * izf;
-    o.g1 = dy * izf;
-    o.g2 = -(dx * unf + dy * vnf) * izf;
-    o.Px = (float)Px; o.Py = (float)Py; o.Pz = (float)Pz;
+// dE/dP from the sampled frame derivatives.
+__device__ __forceinline__ void finish_point(const PoseF& ps, const PointGeom& g, float E, float Er, float Ec, PointProj& o) {
+    const float dx = ps.fx * Ec, dy = ps.fy * Er;
+    o.g0 = dx * g.iz;
+    o.g1 = dy * g.iz;
+    o.g2 = -(dx * g.un + dy * g.vn) * g.iz;
+    o.Px = g.Px; o.Py = g.Py; o.Pz = g.Pz;
     o.E = E;
+}
+
+// Projects, samples (straight from HBM / L2) and forms dE/dP for one point.
+template <int SAMPLING>
+__device__ __forceinline__ void project_sample(const FrameView& frame, const PoseF& ps, const PointKf& k, PointProj& o) {
+    PointGeom g;
+    project_point(ps, k, g);
+    float E, Er, Ec;
+    if (SAMPLING == 0) {
+        float p[16];
+        load_patch16(frame, g.r0, g.c0, p);
+        bicubic_patch(p, g.ay, g.ax, E, Er, Ec);
+    } else {
+        float p[4];
+        load_patch4(frame, g.r0, g.c0, p);
+        bilinear_patch(p, g.ay, g.ax, E, Er, Ec);
+    }
+    finish_point(ps, g, E, Er, Ec, o);
+}
+
+// SE(3) left-perturbation row: J = -w [gradE_P, P x gradE_P]  (= DSO's row, CoarseTracker.cpp:311-321)
+__device__ __forceinline__ void jacobian6(const PointProj& pp, float w, float (&J)[6]) {
+    J[0] = -w * pp.g0;
+    J[1] = -w * pp.g1;
+    J[2] = -w * pp.g2;
+    J[3] = -w * (pp.Py * pp.g2 - pp.Pz * pp.g1);
+    J[4] = -w * (pp.Pz * pp.g0 - pp.Px * pp.g2);
+    J[5] = -w * (pp.Px * pp.g1 - pp.Py * pp.g0);
 }
 
 // a_i = -(gx df0/dv + gy df1/dv): the row of the linear model m = A v

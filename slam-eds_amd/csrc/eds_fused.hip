@@ -4,20 +4,23 @@
 // two orders of magnitude below a launch + PCIe round trip — so the iteration loop itself has
 // to live on the GPU.  One workgroup owns one alignment:
 //
-//   every lane   strides over the alignment's points: project (fp64), sample the frame (bicubic
-//                4x4 taps or bilinear 2x2, through L1/L2), form r and the 1x6 SE(3) row in
-//                registers and fold them straight into 28 running sums (J is never written)
+//   every lane   keeps its points' keyframe constants in REGISTERS for the whole solve (PPT points
+//                per lane), projects them in fp32 through the small-displacement form of
+//                eds_device.hpp, samples the frame (bicubic 4x4 / bilinear 2x2) from an LDS-resident
+//                patch cache (HBM only when a point changes cell), forms r and the 1x6 SE(3) row in
+//                registers and folds them straight into 28 running sums (J is never written)
 //   wavefront    reduce-scatter butterfly (eds_device.hpp), LDS across the wavefronts
-//   lane 0       unpacks the sums (fp64), runs the SAME edss::Solver6 state machine the host
-//                mode runs (eds_solver.hpp): damped 6x6 Cholesky, exp(xi) T, accept / reject
+//   lane 0       runs the SAME edss::Solver6 state machine the host mode runs (eds_solver.hpp):
+//                damped 6x6 Cholesky in fp64, exp(xi) T, accept / reject
 //
 // and loops until the solver reports done; the last pass stores the residuals at the accepted
 // pose (what reference Tracker.cpp:223-230 writes to kf->residuals).  Independent alignments
-// run on different CUs, B >> 256 fills the chip.  The bound is the frame gather (HBM on first
-// touch, L2 afterwards) plus VALU; there is no MFMA-shaped work here.
+// run on different CUs, B >> 256 fills the chip.  No MFMA-shaped work exists on this path.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "eds_device.hpp"
@@ -29,8 +32,19 @@
 using namespace edsd;
 
 #define EDS_FUSED_MAX_WAVES 16
+#define EDS_CACHE_CAP 2048         // points whose frame patch stays resident in LDS across passes
 
-template <int SAMPLING>
+// LDS-resident patch cache.  Every pass of an alignment samples the SAME frame at poses that differ
+// by a fraction of a pixel, so the 4x4 (bicubic) / 2x2 (bilinear) neighbourhood of a point only
+// changes when its integer cell does.  2 048 points x 16 taps x 4 B = 128 KB of the CU's 160 KB LDS
+// hold every patch of the headline configuration; passes after the first then read the frame from
+// LDS instead of re-gathering ~200 B of 64-B HBM sectors per point.  Tap-major layout
+// ([tap][point]) keeps a wavefront's 64 lanes on 64 consecutive banks.  A point is always handled
+// by the same lane, so the cache needs no synchronisation.
+//
+// PPT > 0: each lane owns points tid, tid + nthr, ... (PPT of them, N <= PPT * nthr) and keeps their
+// constants in registers; PPT == 0: any N, constants re-read from HBM/L2 every pass.
+template <int SAMPLING, int PPT, bool CACHE>
 __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
@@ -39,16 +53,22 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
     __shared__ edss::Solver6 sv;
-    __shared__ double s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * EDS_MAX_BLOCKS];
+    __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];
-    __shared__ double s_rec[EDS_RED_K6];
+    __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
+    constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
+    constexpr int NREG = PPT > 0 ? PPT : 1;
+    __shared__ float s_patch[CACHE ? NTAP : 1][CACHE ? EDS_CACHE_CAP : 1];
+    __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    const float* __restrict__ frame = A.frame + (size_t)slot * A.H * A.W;
+    FrameView frame;
+    frame.base = A.frame + (size_t)slot * A.Hp * A.Wp;
+    frame.H = A.H; frame.W = A.W; frame.Hp = A.Hp; frame.Wp = A.Wp; frame.TW = A.Wp >> 2; frame.tiled = A.tiled;
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];
@@ -59,43 +79,101 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
     }
     __syncthreads();
 
-    // normalised model for the fixed velocity: mhat_i = a_i.v / n_block(i)
+    // per-point constants: registers (PPT > 0) — loaded once, coalesced — and the normalised model
+    // for the fixed velocity, mhat_i = a_i.v / n_block(i)
+    PointKf kf[NREG];
+    float kw[NREG], kmh[NREG];
     {
         float vf[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vf[k] = (float)s_pose[EDS_PB_V + k];
-        for (int i = tid; i < N; i += nthr) {
-            const size_t o = base + i;
+        const int reps = PPT > 0 ? PPT : (N + nthr - 1) / nthr;
+        for (int j = 0; j < reps; ++j) {
+            const int i = tid + j * nthr;
+            const bool in_range = i < N;
+            const size_t o = base + (in_range ? i : 0);
+            const float x = A.x[o], y = A.y[o], rho = A.rho[o];
             float a[6];
-            model_row(A.x[o], A.y[o], A.rho[o], A.gx[o], A.gy[o], a);
+            model_row(x, y, rho, A.gx[o], A.gy[o], a);
             float m = 0.0f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) m += a[k] * vf[k];
-            A.mhat[o] = m * (float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * block_of(i, ne, nb)];
+            const float mh = m * (float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * block_of(in_range ? i : 0, ne, nb)];
+            if (PPT > 0) {
+#pragma unroll
+                for (int jj = 0; jj < NREG; ++jj) {
+                    if (jj == j) {          // j is a compile-time constant after unrolling
+                        kf[jj].x = x; kf[jj].y = y; kf[jj].rhop = rho + 1e-5f;
+                        kf[jj].f0x = A.f0x[o]; kf[jj].f0y = A.f0y[o]; kf[jj].cell0 = A.cell0[o];
+                        kw[jj] = in_range ? A.w[o] : 0.0f;      // w = 0 silences out-of-range lanes
+                        kmh[jj] = mh;
+                    }
+                }
+            } else if (in_range) {
+                A.mhat[o] = mh;
+            }
+            if (CACHE && i < EDS_CACHE_CAP) s_cell[i] = 0x7fffffff;       // no cell cached yet
         }
     }
     const float tau = (float)huber_tau;
 
+#ifdef EDS_FUSED_STAMPS
+    unsigned long long stamp_acc[3] = {0, 0, 0}, stamp_t = 0;
+#define EDS_STAMP(k)                                                             \
+    do {                                                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();            \
+        if ((k) > 0) stamp_acc[(k) > 0 ? (k)-1 : 0] += now_ - stamp_t;           \
+        stamp_t = now_;                                                          \
+    } while (0)
+#else
+#define EDS_STAMP(k) do { } while (0)
+#endif
     for (;;) {
+        EDS_STAMP(0);
         const int state = s_state;
-        PoseRT ps;
+        PoseF ps;
         load_pose(s_pose, ps);
         float acc[EDS_RED_K6];
 #pragma unroll
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
-        for (int i = tid; i < N; i += nthr) {
+        const int reps = PPT > 0 ? PPT : (N + nthr - 1) / nthr;
+#pragma unroll
+        for (int j = 0; j < reps; ++j) {
+            const int i = tid + j * nthr;
+            if (PPT == 0 && i >= N) break;
             const size_t o = base + i;
+            PointKf k;
+            float w, mhat;
+            if (PPT > 0) { k = kf[j < NREG ? j : 0]; w = kw[j < NREG ? j : 0]; mhat = kmh[j < NREG ? j : 0]; }
+            else {
+                k.x = A.x[o]; k.y = A.y[o]; k.rhop = A.rho[o] + 1e-5f; k.f0x = A.f0x[o]; k.f0y = A.f0y[o]; k.cell0 = A.cell0[o];
+                w = A.w[o]; mhat = A.mhat[o];
+            }
+            PointGeom pg;
+            project_point(ps, k, pg);
+            float tap[NTAP];
+            const bool cached = CACHE && i < EDS_CACHE_CAP;
+            const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
+            if (cached && s_cell[i] == key) {
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) tap[t] = s_patch[t][i];
+            } else {
+                if (SAMPLING == 0) load_patch16(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[16]>(tap));
+                else load_patch4(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[4]>(tap));
+                if (cached) {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[t];
+                    s_cell[i] = key;
+                }
+            }
+            float E, Er, Ec;
+            if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
+            else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
             PointProj pp;
-            project_sample<SAMPLING>(frame, A.H, A.W, ps, A.X[o], A.Y[o], A.Z[o], pp);
-            const float w = A.w[o];
-            const float r = w * (A.mhat[o] - pp.E);
+            finish_point(ps, pg, E, Er, Ec, pp);
+            const float r = w * (mhat - pp.E);
             float J[6];
-            J[0] = -w * pp.g0;
-            J[1] = -w * pp.g1;
-            J[2] = -w * pp.g2;
-            J[3] = -w * (pp.Py * pp.g2 - pp.Pz * pp.g1);
-            J[4] = -w * (pp.Pz * pp.g0 - pp.Px * pp.g2);
-            J[5] = -w * (pp.Px * pp.g1 - pp.Py * pp.g0);
+            jacobian6(pp, w, J);
             float hw = 1.0f, ct = r * r;
             if (tau > 0.0f) {
                 const float ar = fabsf(r);
@@ -103,32 +181,46 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
                 ct = hw * r * r * (2.0f - hw);
             }
             accumulate_normal<6>(acc, J, r, hw, ct);
-            if (state == 1) A.r[o] = r;
+            if (state == 1 && i < N) A.r[o] = r;
         }
+        EDS_STAMP(1);
         wave_reduce_scatter<EDS_RED_K6>(acc, lane);
         if (lane < 32) s_red[wave][wave_red_index<EDS_RED_K6>(lane, 0)] = acc[0];
         __syncthreads();
-        if (tid < EDS_RED_N6) {
+        if (tid < EDS_RED_N6) {          // cross-wavefront sum in fp64, unpacked straight into the solver's input
             double s = 0.0;
             for (int wv = 0; wv < nwave; ++wv) s += (double)s_red[wv][tid];
-            s_rec[tid] = s;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            edss::Sums6 S;
-            edss::unpack6(s_rec, &S);
-            sv.on_eval(S);
-            if (sv.done) {
-                s_state = 2;
+            if (tid < 21) {
+                int a = 0, rem = tid;           // record index -> (a, b) of the upper triangle
+                while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+                const int b = a + rem;
+                s_sums.H[6 * a + b] = s;
+                s_sums.H[6 * b + a] = s;
+            } else if (tid < 27) {
+                s_sums.b[tid - 21] = s;
             } else {
-                edsm::quat_to_R(sv.cq, s_pose + EDS_PB_R);
-                for (int i = 0; i < 3; ++i) s_pose[EDS_PB_T + i] = sv.cp[i];
-                s_state = sv.final_pass ? 1 : 0;
+                s_sums.cost = s;
             }
         }
         __syncthreads();
+        EDS_STAMP(2);
+        if (tid == 0) {
+            sv.on_eval(s_sums);
+            if (sv.done) {
+                s_state = 2;
+            } else {
+                edsm::fill_pose_rt(sv.cp, sv.cq, s_pose);
+                s_state = sv.final_pass ? 1 : 0;
+            }
+        }
+        EDS_STAMP(3);
+        __syncthreads();
         if (s_state == 2) break;
     }
+#ifdef EDS_FUSED_STAMPS
+    // diagnostic build only: cycles of lane 0 in [point loop | reduction | solver] into the pad words
+    if (tid == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
+#endif
 
     if (tid == 0) {
         EdsFusedOut& O = out[slot];
@@ -171,14 +263,6 @@ void eds_fused_free(EdsFusedBuffers* fb) {
     *fb = EdsFusedBuffers();
 }
 
-static int pick_block_threads(int count, int N) {
-    // few alignments: spend a whole CU's wave slots on each (latency); many: smaller workgroups so
-    // several alignments share a CU and one's serial 6x6 solve hides behind the others' passes
-    int t = (count >= 512) ? 256 : (count >= 128 ? 512 : 1024);
-    while (t > 64 && t / 2 >= N) t /= 2;
-    return t;
-}
-
 int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (h->cfg.solver == EDS_SOLVER_REF12) return eds_internal_solve_host(h, level, first, count);
     EdsFusedBuffers& fb = h->fused;
@@ -198,17 +282,32 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     hipError_t e = hipMemcpyAsync(fb.d_in + first, fb.h_in + first, sizeof(EdsFusedIn) * count, hipMemcpyHostToDevice, h->st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     const EdsArrays A = h->arrays();
-    const int threads = pick_block_threads(count, maxN);
+    // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
+    // the points-per-lane variant is picked from the largest N of the range
+    int threads = 1024;
+    if (const char* ev = getenv("EDS_FUSED_THREADS")) {              // tuning knob (multiple of 64, <= 1024)
+        const int v = atoi(ev);
+        if (v >= 64 && v <= 1024 && v % 64 == 0) threads = v;
+    }
+    while (threads > 64 && threads / 2 >= maxN) threads /= 2;
+    int ppt = (maxN + threads - 1) / threads;
+    ppt = ppt <= 1 ? 1 : (ppt <= 2 ? 2 : (ppt <= 4 ? 4 : 0));
+    if (const char* ev = getenv("EDS_FUSED_PPT")) ppt = atoi(ev) > 0 && atoi(ev) * threads >= maxN ? atoi(ev) : 0;   // tuning knob
     const double tau = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
     const int damped = h->cfg.solver == EDS_SOLVER_LM6;
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
     hipEventRecord(h->ev0, h->st);
-    if (h->cfg.sampling == EDS_SAMPLE_BICUBIC)
-        hipLaunchKernelGGL((eds_fused6_kernel<0>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first,
-                           iters, damped, h->cfg.lambda0, tau, nb);
-    else
-        hipLaunchKernelGGL((eds_fused6_kernel<1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first,
-                           iters, damped, h->cfg.lambda0, tau, nb);
+#define EDS_LAUNCH_FUSED(S, P)                                                                                              \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, true>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+                       iters, damped, h->cfg.lambda0, tau, nb)
+    const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
+    switch (ppt) {
+        case 1: if (bicubic) EDS_LAUNCH_FUSED(0, 1); else EDS_LAUNCH_FUSED(1, 1); break;
+        case 2: if (bicubic) EDS_LAUNCH_FUSED(0, 2); else EDS_LAUNCH_FUSED(1, 2); break;
+        case 4: if (bicubic) EDS_LAUNCH_FUSED(0, 4); else EDS_LAUNCH_FUSED(1, 4); break;
+        default: if (bicubic) EDS_LAUNCH_FUSED(0, 0); else EDS_LAUNCH_FUSED(1, 0); break;
+    }
+#undef EDS_LAUNCH_FUSED
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
@@ -249,6 +348,16 @@ int eds_fused_collect(eds_trk* h) {
         in.initial_cost = 0.5 * O.initial_cost;
         in.final_cost = 0.5 * O.final_cost;
     }
+#ifdef EDS_FUSED_STAMPS
+    {
+        double a[3] = {0, 0, 0};
+        for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s)
+            for (int k = 0; k < 3; ++k) a[k] += fb.h_out[s].pad[k];
+        const double n = fb.pending_count, passes = fb.h_out[fb.pending_first].iterations + 2.0;
+        fprintf(stderr, "[stamps] lane-0 cycles per pass: points %.0f  reduce %.0f  solver %.0f  (mean over %d slots, %g passes)\n",
+                a[0] / n / passes, a[1] / n / passes, a[2] / n / passes, fb.pending_count, passes);
+    }
+#endif
     fb.pending_count = 0;
     return EDS_OK;
 }

@@ -28,24 +28,29 @@ struct Slot {
 struct eds_trk {
     eds_trk_cfg cfg;
     int B = 0, Nmax = 0, Np = 0, H = 0, W = 0, max_seg = 0, dev = 0;
+    int Hp = 0, Wp = 0, tiled = 1;      // frame allocation (eds_device.hpp FrameView)
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // device
-    double *dX = nullptr, *dY = nullptr, *dZ = nullptr, *dpose = nullptr, *dG = nullptr, *dpart = nullptr;
+    double *dpose = nullptr, *dG = nullptr, *dpart = nullptr;
     float *dx = nullptr, *dy = nullptr, *drho = nullptr, *dgx = nullptr, *dgy = nullptr, *dw = nullptr;
+    float *df0x = nullptr, *df0y = nullptr;
+    int* dcell0 = nullptr;
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
     EdsFusedBuffers fused;
     // pinned host staging
-    double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr, *h_f64 = nullptr;
+    double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr;
     float *h_f32 = nullptr, *h_r = nullptr;
     size_t h_f32_elems = 0;
     std::vector<Slot> slots;
 
     EdsArrays arrays() const {
         EdsArrays A;
-        A.X = dX; A.Y = dY; A.Z = dZ; A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
+        A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
+        A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
+        A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;
     }
 };

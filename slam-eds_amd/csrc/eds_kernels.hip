@@ -18,6 +18,13 @@
 
 using namespace edsd;
 
+__device__ __forceinline__ FrameView frame_view(const EdsArrays& A, int slot) {
+    FrameView f;
+    f.base = A.frame + (size_t)slot * A.Hp * A.Wp;
+    f.H = A.H; f.W = A.W; f.Hp = A.Hp; f.Wp = A.Wp; f.TW = A.Wp >> 2; f.tiled = A.tiled;
+    return f;
+}
+
 // linear workgroup id -> (slot, chunk); all chunks of a slot share id % 8 (one XCD)
 __device__ __forceinline__ bool decode_wg(int first, int count, int nchunk, int& slot, int& chunk) {
     const int L = blockIdx.x;
@@ -98,12 +105,15 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
     const int N = (int)pb[EDS_PB_N];
     const int i = chunk * EDS_TPB + threadIdx.x;
     if (i >= N) return;
-    PoseRT ps;
+    PoseF ps;
     load_pose(pb, ps);
     const size_t o = (size_t)slot * A.Np + i;
-    const float* __restrict__ frame = A.frame + (size_t)slot * A.H * A.W;
+    const FrameView frame = frame_view(A, slot);
+    PointKf kf;
+    kf.x = A.x[o]; kf.y = A.y[o]; kf.rhop = A.rho[o] + 1e-5f;   // rho' = idp + eps (PhotometricError.hpp:100,200)
+    kf.f0x = A.f0x[o]; kf.f0y = A.f0y[o]; kf.cell0 = A.cell0[o];
     PointProj pp;
-    project_sample<SAMPLING>(frame, A.H, A.W, ps, A.X[o], A.Y[o], A.Z[o], pp);
+    project_sample<SAMPLING>(frame, ps, kf, pp);
     const float w = A.w[o];
     const size_t plane = (size_t)A.B * A.Np;
     float* __restrict__ Jo = A.J + o;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
         Jo[1 * plane] = -w * pp.g1;
         Jo[2 * plane] = -w * pp.g2;
         // quaternion local: -2 w (R X) x gradE_P, with R X = P - t
-        const float rx = pp.Px - (float)ps.t[0], ry = pp.Py - (float)ps.t[1], rz = pp.Pz - (float)ps.t[2];
+        const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
         const float w2 = -2.0f * w;
         Jo[3 * plane] = w2 * (ry * pp.g2 - rz * pp.g1);
         Jo[4 * plane] = w2 * (rz * pp.g0 - rx * pp.g2);

@@ -5,12 +5,12 @@
 #include "eds_layout.hpp"
 
 struct EdsArrays {
-    // keyframe SoA  [B][Np]
-    const double* X; const double* Y; const double* Z;
-    const float* x; const float* y; const float* rho;
-    const float* gx; const float* gy; const float* w;
-    float* mhat;
-    // frames [B][H*W]
+    // keyframe SoA  [B][Np]  (see eds_device.hpp PointKf)
+    const float* x; const float* y; const float* rho;      // normalised coords, raw inverse depth
+    const float* gx; const float* gy; const float* w;      // log-image gradient, point weight
+    const float* f0x; const float* f0y; const int* cell0;  // keyframe pixel u0 = fx x + cx split into cell + fraction
+    float* mhat;                                            // normalised model (pose-only solvers)
+    // frames [B][Hp*Wp]
     const float* frame;
     // per-slot constants
     double* pose;        // [B][EDS_POSE_STRIDE]
@@ -20,6 +20,7 @@ struct EdsArrays {
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
     int B, Np, H, W, max_seg;
+    int Hp, Wp, tiled;   // frame allocation: padded to multiples of 4; 4x4-tiled or row-major (eds_device.hpp FrameView)
 };
 
 void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st);

@@ -40,6 +40,8 @@
 #define EDS_PB_PV 32               // 36  d(unit-norm plus)/d delta = (I - v v^T/|v|^2)/|v|  (PhotometricError.hpp:32-54)
 #define EDS_PB_BLK 68              // 8 per block: inv_n, gvec[6] = G v / n^3, S
 #define EDS_PB_BLK_STRIDE 8
+#define EDS_PB_D 200               // 9   R - I, formed WITHOUT cancellation from the quaternion: the kernels work on the
+                                   //     small displacement (R - I) m + t rho' so that fp32 resolves 1e-6 px (eds_device.hpp)
 
 // reduction widths: upper triangle of J^T J + J^T r + sum r^2 (+ count of Huber-active points)
 #define EDS_RED_N6 28              // 21 + 6 + 1

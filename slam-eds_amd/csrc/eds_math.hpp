@@ -1,6 +1,9 @@
 // Small fp64 geometry / linear algebra used on BOTH sides of the PCIe bus: the host
 // solver (EDS_EXEC_HOST) and the single "solver lane" of the persistent device kernel
 // (EDS_EXEC_DEVICE) run exactly this code, so the two execution modes take identical steps.
+// Everything is written with compile-time extents and fully unrolled loops so that on the GPU
+// all temporaries live in VGPRs (no scratch): the solver lane is the serial section of every
+// iteration and must stay a few microseconds.
 //
 // Semantics follow the types the reference keeps unchanged:
 //   * Eigen::Quaterniond (x,y,z,w storage) -> toRotationMatrix  (PhotometricError.hpp:163)
@@ -17,6 +20,11 @@
 #define EDS_HD __host__ __device__ inline
 #else
 #define EDS_HD inline
+#endif
+#if defined(__clang__)
+#define EDS_UNROLL _Pragma("unroll")
+#else
+#define EDS_UNROLL
 #endif
 
 namespace edsm {
@@ -42,50 +50,55 @@ EDS_HD void quat_mul(const double* a, const double* b, double* out) {
 
 // T <- exp(xi) * T with T = (t, q).  Sophus closed form incl. its small-angle branch.
 EDS_HD void se3_left_update(const double* xi, double* t, double* q) {
-    const double* ups = xi;
-    const double* om = xi + 3;
-    const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+    const double u0 = xi[0], u1 = xi[1], u2 = xi[2], o0 = xi[3], o1 = xi[4], o2 = xi[5];
+    const double th2 = o0 * o0 + o1 * o1 + o2 * o2;
     const double th = sqrt(th2);
-    double imag, real;
-    if (th < 1e-10) {
+    const bool tiny = th < 1e-10;
+    double imag, real, c1, c2;
+    if (tiny) {
         const double th4 = th2 * th2;
         imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
         real = 1.0 - 0.5 * th2 + (1.0 / 384.0) * th4;
+        c1 = 0.0; c2 = 0.0;
     } else {
-        imag = sin(0.5 * th) / th;
-        real = cos(0.5 * th);
+        // one half-angle sincos feeds everything: sin(th) = 2 sh ch, 1 - cos(th) = 2 sh^2
+        // (same cancellation in th - sin(th) as the Sophus expression; it only scales O(th^2) terms)
+        double sh, ch;
+        sincos(0.5 * th, &sh, &ch);
+        const double inv_th = 1.0 / th, inv_th2 = inv_th * inv_th;
+        imag = sh * inv_th;
+        real = ch;
+        c1 = 2.0 * sh * sh * inv_th2;
+        c2 = (th - 2.0 * sh * ch) * (inv_th2 * inv_th);
     }
-    double dq[4] = {imag * om[0], imag * om[1], imag * om[2], real};
+    double dq[4] = {imag * o0, imag * o1, imag * o2, real};
     double Rd[9];
     quat_to_R(dq, Rd);
-    // V = I + c1 [om]x + c2 [om]x^2  (or R itself below epsilon)
+    // V = I + c1 [om]x + c2 [om]x^2  (Sophus uses R itself below epsilon)
     double V[9];
-    if (th < 1e-10) {
+    if (tiny) {
+        EDS_UNROLL
         for (int i = 0; i < 9; ++i) V[i] = Rd[i];
     } else {
-        const double c1 = (1.0 - cos(th)) / th2, c2 = (th - sin(th)) / (th2 * th);
-        const double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double o2 = 0;
-                for (int k = 0; k < 3; ++k) o2 += O[3 * i + k] * O[3 * k + j];
-                V[3 * i + j] = (i == j ? 1.0 : 0.0) + c1 * O[3 * i + j] + c2 * o2;
-            }
+        // [om]x^2 = om om^T - |om|^2 I
+        V[0] = 1.0 + c2 * (o0 * o0 - th2); V[1] = -c1 * o2 + c2 * (o0 * o1);   V[2] = c1 * o1 + c2 * (o0 * o2);
+        V[3] = c1 * o2 + c2 * (o1 * o0);   V[4] = 1.0 + c2 * (o1 * o1 - th2); V[5] = -c1 * o0 + c2 * (o1 * o2);
+        V[6] = -c1 * o1 + c2 * (o2 * o0);  V[7] = c1 * o0 + c2 * (o2 * o1);   V[8] = 1.0 + c2 * (o2 * o2 - th2);
     }
-    double nt[3];
-    for (int i = 0; i < 3; ++i)
-        nt[i] = Rd[3 * i] * t[0] + Rd[3 * i + 1] * t[1] + Rd[3 * i + 2] * t[2] +
-                V[3 * i] * ups[0] + V[3 * i + 1] * ups[1] + V[3 * i + 2] * ups[2];
-    for (int i = 0; i < 3; ++i) t[i] = nt[i];
+    const double t0 = t[0], t1 = t[1], t2 = t[2];
+    t[0] = Rd[0] * t0 + Rd[1] * t1 + Rd[2] * t2 + V[0] * u0 + V[1] * u1 + V[2] * u2;
+    t[1] = Rd[3] * t0 + Rd[4] * t1 + Rd[5] * t2 + V[3] * u0 + V[4] * u1 + V[5] * u2;
+    t[2] = Rd[6] * t0 + Rd[7] * t1 + Rd[8] * t2 + V[6] * u0 + V[7] * u1 + V[8] * u2;
     double nq[4];
     quat_mul(dq, q, nq);
-    const double nn = sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
-    for (int i = 0; i < 4; ++i) q[i] = nq[i] / nn;
+    const double inv = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    q[0] = nq[0] * inv; q[1] = nq[1] * inv; q[2] = nq[2] * inv; q[3] = nq[3] * inv;
 }
 
 // Ceres Plus over (p additive | EigenQuaternionParameterization | UnitNormVectorAddition).
 EDS_HD void state_plus12(const double* p, const double* q, const double* v, const double* d,
                          double* po, double* qo, double* vo) {
+    EDS_UNROLL
     for (int i = 0; i < 3; ++i) po[i] = p[i] + d[i];
     const double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     if (nd > 0.0) {
@@ -93,44 +106,86 @@ EDS_HD void state_plus12(const double* p, const double* q, const double* v, cons
         const double qd[4] = {s * d[3], s * d[4], s * d[5], cos(nd)};
         double nq[4];
         quat_mul(qd, q, nq);
+        EDS_UNROLL
         for (int i = 0; i < 4; ++i) qo[i] = nq[i];
     } else {
+        EDS_UNROLL
         for (int i = 0; i < 4; ++i) qo[i] = q[i];
     }
     double s2 = 0.0, tmp[6];
+    EDS_UNROLL
     for (int i = 0; i < 6; ++i) { tmp[i] = v[i] + d[6 + i]; s2 += tmp[i] * tmp[i]; }
     const double inv = 1.0 / sqrt(s2);
+    EDS_UNROLL
     for (int i = 0; i < 6; ++i) vo[i] = tmp[i] * inv;
 }
 
-// Dense SPD solve A x = b (n <= 12) by Cholesky; false if A is not numerically PD.
-EDS_HD bool cholesky_solve(int n, const double* A, const double* b, double* x) {
-    double L[144], y[12];
-    for (int i = 0; i < n; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i * n + j];
-            for (int k = 0; k < j; ++k) s -= L[i * n + k] * L[j * n + k];
-            if (i == j) {
-                if (!(s > 0.0) || !(s < 1e300)) return false;
-                L[i * n + i] = sqrt(s);
-            } else {
-                L[i * n + j] = s / L[j * n + j];
-            }
+// In-place Cholesky solve on a PACKED lower triangle (row i, col j <= i at i(i+1)/2 + j):
+// on entry L holds the lower triangle of an SPD matrix and b the right-hand side, on exit L holds
+// its Cholesky factor and b the solution.  Returns false if the matrix is not numerically PD.
+#define EDS_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+template <int N>
+EDS_HD bool chol_solve_packed(double* L, double* b) {
+    bool ok = true;
+    double id[N];                           // 1 / L_jj: fp64 divisions are ~20 instructions on the GPU, multiplies are one
+    EDS_UNROLL
+    for (int j = 0; j < N; ++j) {
+        double d = L[EDS_TRI(j, j)];
+        EDS_UNROLL
+        for (int k = 0; k < j; ++k) d -= L[EDS_TRI(j, k)] * L[EDS_TRI(j, k)];
+        ok = ok && (d > 0.0) && (d < 1e300);
+        const double ljj = sqrt(d);
+        const double inv = 1.0 / ljj;
+        id[j] = inv;
+        L[EDS_TRI(j, j)] = ljj;
+        EDS_UNROLL
+        for (int i = j + 1; i < N; ++i) {
+            double s = L[EDS_TRI(i, j)];
+            EDS_UNROLL
+            for (int k = 0; k < j; ++k) s -= L[EDS_TRI(i, k)] * L[EDS_TRI(j, k)];
+            L[EDS_TRI(i, j)] = s * inv;
         }
     }
-    for (int i = 0; i < n; ++i) {
+    if (!ok) return false;
+    EDS_UNROLL
+    for (int i = 0; i < N; ++i) {           // L y = b
         double s = b[i];
-        for (int k = 0; k < i; ++k) s -= L[i * n + k] * y[k];
-        y[i] = s / L[i * n + i];
+        EDS_UNROLL
+        for (int k = 0; k < i; ++k) s -= L[EDS_TRI(i, k)] * b[k];
+        b[i] = s * id[i];
     }
-    for (int i = n - 1; i >= 0; --i) {
-        double s = y[i];
-        for (int k = i + 1; k < n; ++k) s -= L[k * n + i] * x[k];
-        x[i] = s / L[i * n + i];
+    EDS_UNROLL
+    for (int i = N - 1; i >= 0; --i) {      // L^T x = y
+        double s = b[i];
+        EDS_UNROLL
+        for (int k = i + 1; k < N; ++k) s -= L[EDS_TRI(k, i)] * b[k];
+        b[i] = s * id[i];
     }
-    for (int i = 0; i < n; ++i)
-        if (!(x[i] == x[i]) || !(fabs(x[i]) < 1e300)) return false;
-    return true;
+    double chk = 0.0;
+    EDS_UNROLL
+    for (int i = 0; i < N; ++i) chk += b[i];
+    return (chk == chk) && (fabs(chk) < 1e300);
+}
+
+// Dense SPD solve A x = b for a full row-major A (n = 6 or 12 take the unrolled path).
+template <int N>
+EDS_HD bool cholesky_solve_n(const double* A, const double* b, double* x) {
+    double L[N * (N + 1) / 2], y[N];
+    EDS_UNROLL
+    for (int i = 0; i < N; ++i) {
+        EDS_UNROLL
+        for (int j = 0; j <= i; ++j) L[EDS_TRI(i, j)] = A[i * N + j];
+        y[i] = b[i];
+    }
+    const bool ok = chol_solve_packed<N>(L, y);
+    EDS_UNROLL
+    for (int i = 0; i < N; ++i) x[i] = y[i];
+    return ok;
+}
+EDS_HD bool cholesky_solve(int n, const double* A, const double* b, double* x) {
+    if (n == 6) return cholesky_solve_n<6>(A, b, x);
+    if (n == 12) return cholesky_solve_n<12>(A, b, x);
+    return false;
 }
 
 // Fills the per-pass constants of a slot's pose block from (p, q, v) and the per-block
@@ -138,8 +193,26 @@ EDS_HD bool cholesky_solve(int n, const double* A, const double* b, double* x) {
 // (n^2 = v^T G v + 1e-3: PhotometricError.hpp:132-149 in closed form), and the local
 // Jacobian of the unit-norm velocity plus.  The intrinsics/point-count entries are
 // written by set_keyframe and left alone here.
+// R - I straight from the quaternion (no 1 - (...) cancellation): exact to fp64 even for tiny rotations.
+EDS_HD void quat_to_RmI(const double* q, double* D) {
+    const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
+    const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
+    const double txx = tx * q[0], txy = ty * q[0], txz = tz * q[0];
+    const double tyy = ty * q[1], tyz = tz * q[1], tzz = tz * q[2];
+    D[0] = -(tyy + tzz); D[1] = txy - twz;    D[2] = txz + twy;
+    D[3] = txy + twz;    D[4] = -(txx + tzz); D[5] = tyz - twx;
+    D[6] = txz - twy;    D[7] = tyz + twx;    D[8] = -(txx + tyy);
+}
+// Rotation part of a pose block (R and R - I) + translation: what changes from pass to pass.
+EDS_HD void fill_pose_rt(const double* p, const double* q, double* pb) {
+    quat_to_R(q, pb + EDS_PB_R);
+    quat_to_RmI(q, pb + EDS_PB_D);
+    for (int i = 0; i < 3; ++i) pb[EDS_PB_T + i] = p[i];
+}
+
 EDS_HD void fill_pose_block(const double* p, const double* q, const double* v, const double* G, int nb, double* pb) {
     quat_to_R(q, pb + EDS_PB_R);
+    quat_to_RmI(q, pb + EDS_PB_D);
     for (int i = 0; i < 3; ++i) pb[EDS_PB_T + i] = p[i];
     for (int i = 0; i < 6; ++i) pb[EDS_PB_V + i] = v[i];
     for (int i = 0; i < 4; ++i) pb[EDS_PB_Q + i] = q[i];
@@ -150,17 +223,17 @@ EDS_HD void fill_pose_block(const double* p, const double* q, const double* v, c
         for (int j = 0; j < 6; ++j) pb[EDS_PB_PV + 6 * i + j] = ((i == j ? 1.0 : 0.0) - v[i] * v[j] / vv) / vn;
     for (int k = 0; k < nb; ++k) {
         const double* Gk = G + 36 * k;
-        double Gv[6], S = 1e-3;
+        double S = 1e-3;
+        double* o = pb + EDS_PB_BLK + EDS_PB_BLK_STRIDE * k;
         for (int i = 0; i < 6; ++i) {
             double s = 0.0;
             for (int j = 0; j < 6; ++j) s += Gk[6 * i + j] * v[j];
-            Gv[i] = s;
+            o[1 + i] = s;
             S += v[i] * s;
         }
         const double n = sqrt(S);
-        double* o = pb + EDS_PB_BLK + EDS_PB_BLK_STRIDE * k;
         o[0] = 1.0 / n;
-        for (int i = 0; i < 6; ++i) o[1 + i] = Gv[i] / (n * n * n);
+        for (int i = 0; i < 6; ++i) o[1 + i] = o[1 + i] / (n * n * n);
         o[7] = S;
     }
 }

@@ -63,13 +63,27 @@ struct Solver6 {
     }
     // Solves from `cur`, writes the next candidate.  Returns false if the system is not PD.
     EDS_HD bool propose() {
-        double Hl[36], nb[6];
-        for (int i = 0; i < 36; ++i) Hl[i] = cur.H[i];
-        for (int i = 0; i < 6; ++i) { Hl[7 * i] *= (1.0 + lambda); nb[i] = -cur.b[i]; }
-        if (!edsm::cholesky_solve(6, Hl, nb, xi)) return false;
-        for (int i = 0; i < 3; ++i) cp[i] = p[i];
-        for (int i = 0; i < 4; ++i) cq[i] = q[i];
-        edsm::se3_left_update(xi, cp, cq);
+        double L[21], x[6];
+        EDS_UNROLL
+        for (int i = 0; i < 6; ++i) {
+            EDS_UNROLL
+            for (int j = 0; j < i; ++j) L[EDS_TRI(i, j)] = cur.H[6 * i + j];
+            L[EDS_TRI(i, i)] = cur.H[7 * i] * (1.0 + lambda);
+            x[i] = -cur.b[i];
+        }
+        if (!edsm::chol_solve_packed<6>(L, x)) return false;
+        double tp[3], tq[4];
+        EDS_UNROLL
+        for (int i = 0; i < 6; ++i) xi[i] = x[i];
+        EDS_UNROLL
+        for (int i = 0; i < 3; ++i) tp[i] = p[i];
+        EDS_UNROLL
+        for (int i = 0; i < 4; ++i) tq[i] = q[i];
+        edsm::se3_left_update(x, tp, tq);
+        EDS_UNROLL
+        for (int i = 0; i < 3; ++i) cp[i] = tp[i];
+        EDS_UNROLL
+        for (int i = 0; i < 4; ++i) cq[i] = tq[i];
         return true;
     }
     EDS_HD void record(double cost, int acc) {

@@ -302,10 +302,10 @@ def test_oracle_reproduces_golden(po, synth, path):
         e6 = o.pose6_eval(g["eval_p"], g["eval_q"], g["eval_v"])
         assert np.allclose(e6["J"][sub], g[f"{tag}_J6"], rtol=1e-10, atol=1e-12)
         assert np.allclose(e6["H"], g[f"{tag}_H6"], rtol=1e-10)
-        lm = o.pose6_lm(al.p0, al.q0, al.v0, iters=10, lambda0=0.01)
+        lm = o.pose6_lm(g["start_p"], g["start_q"], al.v0, iters=10, lambda0=0.01)
         assert np.array_equal(lm["accepted"], g[f"{tag}_lm6_acc"])
         assert po.se3_distance(lm["p"], lm["q"], g[f"{tag}_lm6_p"], g[f"{tag}_lm6_q"]) < 1e-9
-        s = po.Oracle(al, sampling=sampling, num_blocks=nb, max_num_iterations=10).solve_lm(al.p0, al.q0, al.v0)
+        s = po.Oracle(al, sampling=sampling, num_blocks=nb, max_num_iterations=10).solve_lm(g["start_p"], g["start_q"], al.v0)
         ref = g[f"{tag}_ref12_none"]
         assert po.se3_distance(s["p"], s["q"], ref[0:3], ref[3:7]) < 1e-8
         assert s["num_iterations"] == int(ref[14]) and s["termination"] == int(ref[16])

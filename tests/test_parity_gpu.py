@@ -94,7 +94,7 @@ def test_golden_fixtures(gpu, capi, synth, po, path):
         for ex in (capi.EXEC_HOST, capi.EXEC_DEVICE):
             cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=ex, solver=capi.SOLVER_LM6, max_num_iterations=10)
             h.set_config(cfg)
-            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            p, q, v, info = h.optimize(0, p=g["start_p"], q=g["start_q"], v=al.v0)
             tr = h.trace(0)
             assert np.array_equal(tr["accepted"], g[f"{tag}_lm6_acc"])
             assert po.se3_distance(p, q, g[f"{tag}_lm6_p"], g[f"{tag}_lm6_q"]) <= TOL_POSE
@@ -102,14 +102,14 @@ def test_golden_fixtures(gpu, capi, synth, po, path):
                 assert step_err(po, tr["increments"][k], g[f"{tag}_lm6_inc"][k]) <= TOL_STEP
             cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=ex, solver=capi.SOLVER_GN6, max_num_iterations=2)
             h.set_config(cfg)
-            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            p, q, v, info = h.optimize(0, p=g["start_p"], q=g["start_q"], v=al.v0)
             tr = h.trace(0)
             assert step_err(po, tr["increments"][0], g[f"{tag}_gn6_inc"][0]) <= TOL_STEP
         for loss, lname in ((0, "none"), (1, "huber"), (2, "cauchy")):
             cfg = capi.default_config(sampling=sampling, num_blocks=nb, exec=capi.EXEC_HOST, solver=capi.SOLVER_REF12,
                                       loss_type=loss, loss_param=0.3, max_num_iterations=10)
             h.set_config(cfg)
-            p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+            p, q, v, info = h.optimize(0, p=g["start_p"], q=g["start_q"], v=al.v0)
             ref = g[f"{tag}_ref12_{lname}"]
             assert po.se3_distance(p, q, ref[0:3], ref[3:7]) <= TOL_POSE
             assert np.abs(v - ref[7:13]).max() <= 1e-4
