@@ -57,6 +57,27 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_prefix, a):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_*.json, produced by
+    tools/profile.sh + tools/summarise_profile.py in separate --pmc runs) — only when they were taken on
+    exactly this workload; otherwise None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        c = t.get("bench_config", {})
+        if (c.get("alignments_per_gpu"), c.get("points"), c.get("iterations"), c.get("solver"), c.get("sampling"), c.get("exec")) != \
+                (a.batch, a.points, a.iters, a.solver, a.sampling, a.exec_) or c.get("frame") != [a.height, a.width]:
+            continue
+        for k, v in t.get("kernels", {}).items():
+            if k.startswith(kernel_prefix) and v.get("raw_hbm_bytes"):
+                best = {"bytes": v["raw_hbm_bytes"], "source": os.path.relpath(f, ROOT)}
+    return best
+
+
 def cpu_baseline(als, iters, sampling, budget_s):
     """Oracle (test infrastructure) timed as the CPU baseline: same LM6 iterations, all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -165,6 +186,9 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": B * N * passes * per_pt,
                     "note": f"{per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch (J never materialised)"}
+            t = pmc_traffic("eds_fused6_kernel", a)
+            if t:
+                roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
         both_ms = h.bench_eval(0, B, ncols=6, with_reduction=True, reps=20)
         ach_rj = B * N * BYTES_RESJAC[a.sampling] / (rj_ms * 1e-3) / 1e9
@@ -172,6 +196,9 @@ def main():
                    "frac": ach_rj / HBM_PEAK_GBS, "traffic": None, "kernel_ms": rj_ms,
                    "point_evals_per_s": B * N / (rj_ms * 1e-3),
                    "resjac_plus_reduce_ms": both_ms}
+        t = pmc_traffic("eds_resjac_kernel", a)
+        if t:
+            roof_rj["traffic"], roof_rj["traffic_source"] = t["bytes"], t["source"]
         if roof is None:
             roof = roof_rj
         pose_err = float(np.median([np.linalg.norm(table[b, 0:3] - als[b % distinct].p_true) for b in range(min(B, distinct))]))

@@ -44,8 +44,8 @@ using namespace edsd;
 //
 // PPT > 0: each lane owns points tid, tid + nthr, ... (PPT of them, N <= PPT * nthr) and keeps their
 // constants in registers; PPT == 0: any N, constants re-read from HBM/L2 every pass.
-template <int SAMPLING, int PPT, bool CACHE>
-__global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
+template <int SAMPLING, int PPT, int MAXT>
+__global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
                                                           double huber_tau, int nb) {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     constexpr int NREG = PPT > 0 ? PPT : 1;
+    constexpr bool CACHE = true;
     __shared__ float s_patch[CACHE ? NTAP : 1][CACHE ? EDS_CACHE_CAP : 1];
     __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
         sv.init(damped, iters, lambda0, I.p, I.q);
         s_state = sv.final_pass ? 1 : 0;
     }
+    for (int k = tid; k < EDS_FUSED_MAX_WAVES * EDS_RED_K6; k += nthr) (&s_red[0][0])[k] = 0.0f;   // rows of absent wavefronts stay 0
     __syncthreads();
 
     // per-point constants: registers (PPT > 0) — loaded once, coalesced — and the normalised model
@@ -136,36 +138,8 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
         float acc[EDS_RED_K6];
 #pragma unroll
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
-        const int reps = PPT > 0 ? PPT : (N + nthr - 1) / nthr;
-#pragma unroll
-        for (int j = 0; j < reps; ++j) {
-            const int i = tid + j * nthr;
-            if (PPT == 0 && i >= N) break;
-            const size_t o = base + i;
-            PointKf k;
-            float w, mhat;
-            if (PPT > 0) { k = kf[j < NREG ? j : 0]; w = kw[j < NREG ? j : 0]; mhat = kmh[j < NREG ? j : 0]; }
-            else {
-                k.x = A.x[o]; k.y = A.y[o]; k.rhop = A.rho[o] + 1e-5f; k.f0x = A.f0x[o]; k.f0y = A.f0y[o]; k.cell0 = A.cell0[o];
-                w = A.w[o]; mhat = A.mhat[o];
-            }
-            PointGeom pg;
-            project_point(ps, k, pg);
-            float tap[NTAP];
-            const bool cached = CACHE && i < EDS_CACHE_CAP;
-            const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
-            if (cached && s_cell[i] == key) {
-#pragma unroll
-                for (int t = 0; t < NTAP; ++t) tap[t] = s_patch[t][i];
-            } else {
-                if (SAMPLING == 0) load_patch16(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[16]>(tap));
-                else load_patch4(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[4]>(tap));
-                if (cached) {
-#pragma unroll
-                    for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[t];
-                    s_cell[i] = key;
-                }
-            }
+        // Consumes one point: sample from its (register-resident) taps, residual, 1x6 row, running sums.
+        auto consume = [&](const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, int i) {
             float E, Er, Ec;
             if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
             else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
@@ -181,15 +155,77 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
                 ct = hw * r * r * (2.0f - hw);
             }
             accumulate_normal<6>(acc, J, r, hw, ct);
-            if (state == 1 && i < N) A.r[o] = r;
+            if (state == 1 && i < N) A.r[base + i] = r;
+        };
+        if (PPT > 0) {
+            // phase A: project every point of this lane, probe the patch cache, and put ALL the
+            // missing gathers in flight before anything waits on one (memory-level parallelism:
+            // a miss costs a ~2 us HBM round trip, paid once per pass instead of once per point)
+            PointGeom pg[NREG];
+            float tap[NREG][NTAP];
+            bool miss[NREG];
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int i = tid + j * nthr;
+                project_point(ps, kf[j], pg[j]);
+                const bool cached = CACHE && i < EDS_CACHE_CAP;
+                const int key = (pg[j].r0 << 16) ^ (pg[j].c0 & 0xffff);
+                miss[j] = !(cached && s_cell[i] == key);
+                if (miss[j]) {
+                    if (SAMPLING == 0) load_patch16(frame, pg[j].r0, pg[j].c0, reinterpret_cast<float(&)[16]>(tap[j]));
+                    else load_patch4(frame, pg[j].r0, pg[j].c0, reinterpret_cast<float(&)[4]>(tap[j]));
+                    if (cached) s_cell[i] = key;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) tap[j][t] = s_patch[t][i];
+                }
+            }
+            // phase B: refill the cache lines that missed, then consume
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int i = tid + j * nthr;
+                if (CACHE && miss[j] && i < EDS_CACHE_CAP) {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[j][t];
+                }
+                consume(pg[j], tap[j], kw[j], kmh[j], i);
+            }
+        } else {
+            for (int i = tid; i < N; i += nthr) {
+                const size_t o = base + i;
+                PointKf k;
+                k.x = A.x[o]; k.y = A.y[o]; k.rhop = A.rho[o] + 1e-5f; k.f0x = A.f0x[o]; k.f0y = A.f0y[o]; k.cell0 = A.cell0[o];
+                PointGeom pg;
+                project_point(ps, k, pg);
+                float tap[NTAP];
+                const bool cached = CACHE && i < EDS_CACHE_CAP;
+                const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
+                if (cached && s_cell[i] == key) {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) tap[t] = s_patch[t][i];
+                } else {
+                    if (SAMPLING == 0) load_patch16(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[16]>(tap));
+                    else load_patch4(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[4]>(tap));
+                    if (cached) {
+#pragma unroll
+                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[t];
+                        s_cell[i] = key;
+                    }
+                }
+                consume(pg, tap, A.w[o], A.mhat[o], i);
+            }
         }
         EDS_STAMP(1);
         wave_reduce_scatter<EDS_RED_K6>(acc, lane);
         if (lane < 32) s_red[wave][wave_red_index<EDS_RED_K6>(lane, 0)] = acc[0];
         __syncthreads();
         if (tid < EDS_RED_N6) {          // cross-wavefront sum in fp64, unpacked straight into the solver's input
+            float part[EDS_FUSED_MAX_WAVES];
+#pragma unroll
+            for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) part[wv] = s_red[wv][tid];   // 16 independent LDS reads in flight
             double s = 0.0;
-            for (int wv = 0; wv < nwave; ++wv) s += (double)s_red[wv][tid];
+#pragma unroll
+            for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)part[wv];
             if (tid < 21) {
                 int a = 0, rem = tid;           // record index -> (a, b) of the upper triangle
                 while (rem >= 6 - a) { rem -= 6 - a; ++a; }
@@ -202,7 +238,11 @@ __global__ __launch_bounds__(1024) void eds_fused6_kernel(EdsArrays A, const Eds
                 s_sums.cost = s;
             }
         }
-        __syncthreads();
+        // the 28 summing lanes and the solver lane all live in wavefront 0: LDS operations of one
+        // wavefront retire in order, so a wavefront-scope fence replaces a second workgroup barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         EDS_STAMP(2);
         if (tid == 0) {
             sv.on_eval(s_sums);
@@ -284,7 +324,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const EdsArrays A = h->arrays();
     // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
     // the points-per-lane variant is picked from the largest N of the range
-    int threads = 1024;
+    // 8 wavefronts x 4 points per lane measured 12% faster than 16 x 2 at N = 2000 (fewer wavefronts to
+    // reduce across, all four gathers of a lane in flight at once, 256-VGPR budget)
+    int threads = maxN <= 2048 ? 512 : 1024;
     if (const char* ev = getenv("EDS_FUSED_THREADS")) {              // tuning knob (multiple of 64, <= 1024)
         const int v = atoi(ev);
         if (v >= 64 && v <= 1024 && v % 64 == 0) threads = v;
@@ -297,16 +339,20 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const int damped = h->cfg.solver == EDS_SOLVER_LM6;
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
     hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH_FUSED(S, P)                                                                                              \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, true>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+    // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
+    // lane variant needs to keep 4 x 16 taps + constants in registers without spilling
+#define EDS_LAUNCH_FUSED(S, P, T)                                                                                              \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb)
+#define EDS_LAUNCH_FUSED_T(S, P) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024); else EDS_LAUNCH_FUSED(S, P, 512); } while (0)
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
     switch (ppt) {
-        case 1: if (bicubic) EDS_LAUNCH_FUSED(0, 1); else EDS_LAUNCH_FUSED(1, 1); break;
-        case 2: if (bicubic) EDS_LAUNCH_FUSED(0, 2); else EDS_LAUNCH_FUSED(1, 2); break;
-        case 4: if (bicubic) EDS_LAUNCH_FUSED(0, 4); else EDS_LAUNCH_FUSED(1, 4); break;
-        default: if (bicubic) EDS_LAUNCH_FUSED(0, 0); else EDS_LAUNCH_FUSED(1, 0); break;
+        case 1: if (bicubic) EDS_LAUNCH_FUSED_T(0, 1); else EDS_LAUNCH_FUSED_T(1, 1); break;
+        case 2: if (bicubic) EDS_LAUNCH_FUSED_T(0, 2); else EDS_LAUNCH_FUSED_T(1, 2); break;
+        case 4: if (bicubic) EDS_LAUNCH_FUSED_T(0, 4); else EDS_LAUNCH_FUSED_T(1, 4); break;
+        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0); else EDS_LAUNCH_FUSED_T(1, 0); break;
     }
+#undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();

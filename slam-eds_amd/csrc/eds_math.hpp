@@ -29,6 +29,16 @@
 
 namespace edsm {
 
+// 1/sqrt(x).  On the GPU one v_rsq_f64 + refinement replaces a sqrt AND a division (each a
+// 15-20 instruction fp64 sequence on the serial solver lane); the host spells it out.
+EDS_HD double rsqrt_(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rsqrt(x);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 EDS_HD void quat_to_R(const double* q, double* R) {
     const double tx = 2.0 * q[0], ty = 2.0 * q[1], tz = 2.0 * q[2];
     const double twx = tx * q[3], twy = ty * q[3], twz = tz * q[3];
@@ -52,8 +62,7 @@ EDS_HD void quat_mul(const double* a, const double* b, double* out) {
 EDS_HD void se3_left_update(const double* xi, double* t, double* q) {
     const double u0 = xi[0], u1 = xi[1], u2 = xi[2], o0 = xi[3], o1 = xi[4], o2 = xi[5];
     const double th2 = o0 * o0 + o1 * o1 + o2 * o2;
-    const double th = sqrt(th2);
-    const bool tiny = th < 1e-10;
+    const bool tiny = th2 < 1e-20;              // |omega| < 1e-10, Sophus' epsilon
     double imag, real, c1, c2;
     if (tiny) {
         const double th4 = th2 * th2;
@@ -63,9 +72,10 @@ EDS_HD void se3_left_update(const double* xi, double* t, double* q) {
     } else {
         // one half-angle sincos feeds everything: sin(th) = 2 sh ch, 1 - cos(th) = 2 sh^2
         // (same cancellation in th - sin(th) as the Sophus expression; it only scales O(th^2) terms)
+        const double inv_th = rsqrt_(th2), inv_th2 = inv_th * inv_th;
+        const double th = th2 * inv_th;
         double sh, ch;
         sincos(0.5 * th, &sh, &ch);
-        const double inv_th = 1.0 / th, inv_th2 = inv_th * inv_th;
         imag = sh * inv_th;
         real = ch;
         c1 = 2.0 * sh * sh * inv_th2;
@@ -91,7 +101,7 @@ EDS_HD void se3_left_update(const double* xi, double* t, double* q) {
     t[2] = Rd[6] * t0 + Rd[7] * t1 + Rd[8] * t2 + V[6] * u0 + V[7] * u1 + V[8] * u2;
     double nq[4];
     quat_mul(dq, q, nq);
-    const double inv = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+    const double inv = rsqrt_(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
     q[0] = nq[0] * inv; q[1] = nq[1] * inv; q[2] = nq[2] * inv; q[3] = nq[3] * inv;
 }
 
@@ -134,8 +144,8 @@ EDS_HD bool chol_solve_packed(double* L, double* b) {
         EDS_UNROLL
         for (int k = 0; k < j; ++k) d -= L[EDS_TRI(j, k)] * L[EDS_TRI(j, k)];
         ok = ok && (d > 0.0) && (d < 1e300);
-        const double ljj = sqrt(d);
-        const double inv = 1.0 / ljj;
+        const double inv = rsqrt_(d);
+        const double ljj = d * inv;
         id[j] = inv;
         L[EDS_TRI(j, j)] = ljj;
         EDS_UNROLL

@@ -116,6 +116,10 @@ def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, 
     flat = rng.choice(w_in * h_in, size=N, replace=False)
     px = (flat % w_in + 16).astype(np.float64)
     py = (flat // w_in + 16).astype(np.float64)
+    # the reference selects points patch by patch over a grid scanned row-major (KeyFrame.cpp:752-787,
+    # 20x20 cells), so a real keyframe's point vectors are in raster order of their grid cell
+    order = np.argsort((py // 20) * 4096 + (px // 20), kind="stable")
+    px, py = px[order], py[order]
     coord = np.stack([px, py], axis=1)
     norm_coord = np.stack([(px - cx) / fx, (py - cy) / fy], axis=1)
     idp = rng.uniform(0.2, 1.0, size=N)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the default bench command, then two
+# separate PMC passes (FETCH_SIZE / WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+# Everything lands under gpurun_out/ (scratch); tools/summarise_profile.py turns it into profiles/*.
+set -u
+cd "${GRAFT_REPO_ROOT:-$PWD}"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_${1:-r01}
+rm -rf "$OUT"; mkdir -p "$OUT"
+ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu}"
+python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_write.json" 2> "$OUT/write.err"
+find "$OUT" -name "*.csv" | head -40
+du -sh "$OUT"

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 output of tools/profile.sh (gpurun_out/prof_<tag>/) into the tracked summaries
+under profiles/: the kernel-stats CSV as rocprofv3 wrote it, the per-kernel PMC means, a traffic JSON
+that bench.py reads for its `roofline.traffic` field, and a short markdown digest.
+
+    python tools/summarise_profile.py r01
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    for k in ("eds_fused6_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
+        if k in name:
+            return k + name[name.find("<"):name.find(">") + 1] if "<" in name else k
+    return name[:40]
+
+
+stats_csv = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats = {short(r["Name"]): r for r in csv.DictReader(open(stats_csv))}
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for which in ("fetch", "write"):
+    for f in glob.glob(os.path.join(src, f"pmc_{which}", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
+cfg = bench["config"]
+out = {"tag": tag, "bench_config": cfg, "bench_value": bench["value"], "kernels": {}}
+lines = [f"# rocprofv3 digest {tag}", "",
+         f"command: `python3 bench.py {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-cpu')}` "
+         f"({cfg['alignments_per_gpu']} alignments x {cfg['points']} points, {cfg['iterations']} {cfg['solver']} iterations, {cfg['sampling']})",
+         f"bench value (un-profiled run): {bench['value']:.4g} {bench['unit']}", "",
+         "| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | raw HBM bytes/launch | raw GB/s |",
+         "|---|---|---|---|---|---|---|"]
+for k, r in stats.items():
+    if not k.startswith("eds_"):
+        continue
+    avg_us = float(r["AverageNs"]) / 1e3
+    f = pmc.get(k, {}).get("FETCH_SIZE", [])
+    w = pmc.get(k, {}).get("WRITE_SIZE", [])
+    fkb = sum(f) / len(f) if f else None
+    wkb = sum(w) / len(w) if w else None
+    raw = (fkb + wkb) * 1024 if (fkb is not None and wkb is not None) else None
+    out["kernels"][k] = {"calls": int(r["Calls"]), "avg_us": avg_us, "fetch_kb": fkb, "write_kb": wkb, "raw_hbm_bytes": raw}
+    lines.append(f"| {k} | {r['Calls']} | {avg_us:.1f} | {fkb if fkb is None else round(fkb, 1)} | "
+                 f"{wkb if wkb is None else round(wkb, 1)} | {raw if raw is None else int(raw)} | "
+                 f"{'' if raw is None else round(raw / avg_us / 1e3, 1)} |")
+lines += ["",
+          "FETCH_SIZE / WRITE_SIZE were collected in two separate `--pmc` passes (they do not fit one pass on gfx950).",
+          "Raw = (FETCH_SIZE + WRITE_SIZE) x 1024.  Calibration on known byte counts (MI355X_MICROARCH.md asks for it):",
+          "* streaming reads are tallied at exactly 1/2 — `eds_reduce_kernel<6>` reads 28 B/point (57.3 MB/launch) and FETCH_SIZE",
+          "  says 28.3 MB — so the coalesced SoA part of every kernel here must be doubled;",
+          "* scattered 16..64-byte loads are tallied at 64 B per distinct 64-B sector (tools/ubench_gather.hip under",
+          "  `--pmc FETCH_SIZE`: 64 Mi random locations -> 4.32 GB whether 16, 32 or 64 B are read per location), i.e. correctly,",
+          "  except that two sectors of one 128-B line fetched together are tallied once;",
+          "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
+          "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound."]
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
+print("\n".join(lines))
