@@ -1,0 +1,47 @@
+// Drives the C++ shim (slam-eds_amd/csrc/Tracker.hpp) the way the external EDS component drives
+// eds::tracking::Tracker: read one alignment from a flat binary file, call optimize(), print the result.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../slam-eds_amd/csrc/Tracker.hpp"
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: shim_demo <alignment.bin> [num_threads] [loss 0|1|2] [iters]\n"); return 2; }
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f) return 2;
+    int hdr[3]; double K[4];
+    if (std::fread(hdr, sizeof(int), 3, f) != 3 || std::fread(K, sizeof(double), 4, f) != 4) return 2;
+    const int N = hdr[0], H = hdr[1], W = hdr[2];
+    auto kf = std::make_shared<eds::tracking::KeyFrame>();
+    kf->norm_coord.resize(N); kf->grad.resize(N); kf->weights.resize(N); kf->inv_depth.resize(N);
+    std::vector<double> frame((size_t)H * W), v0(6);
+    size_t ok = std::fread(kf->norm_coord.data(), 16, N, f) + std::fread(kf->grad.data(), 16, N, f) + std::fread(kf->inv_depth.data(), 8, N, f) +
+                std::fread(kf->weights.data(), 8, N, f);
+    ok += std::fread(frame.data(), 8, frame.size(), f) + std::fread(v0.data(), 8, 6, f);
+    std::fclose(f);
+    if (ok != (size_t)4 * N + frame.size() + 6) return 2;
+    kf->rows = H; kf->cols = W;
+    kf->K_ref[0] = K[0]; kf->K_ref[4] = K[1]; kf->K_ref[2] = K[2]; kf->K_ref[5] = K[3];
+
+    eds::tracking::Config cfg;
+    cfg.options.num_threads = argc > 2 ? std::atoi(argv[2]) : 1;
+    cfg.loss_type = (eds::tracking::LOSS_FUNCTION)(argc > 3 ? std::atoi(argv[3]) : 0);
+    cfg.loss_params = {0.3};
+    cfg.options.max_num_iterations = {argc > 4 ? std::atoi(argv[4]) : 10};
+    eds::tracking::Tracker tracker(kf, cfg);
+    base::Vector6d velo; for (int i = 0; i < 6; ++i) velo[i] = v0[i];
+    tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
+    base::Transform3d T = base::Transform3d::Identity();
+    const bool good = tracker.optimize(0, &frame, T, eds::tracking::MAD);
+    const base::Transform3d Tef = tracker.getTransform();
+    const base::Vector6d v = tracker.getVelocity();
+    const eds::tracking::TrackerInfo info = tracker.getInfo();
+    double id_err = 0;                       // T_kf_ef * T_ef_kf must be the identity (Tracker.cpp:220)
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += T(r, k) * Tef(k, c); id_err = std::max(id_err, std::fabs(s - (r == c))); }
+    std::printf("{\"ok\": %d, \"t\": [%.17g, %.17g, %.17g], \"R\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], "
+                "\"v\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"num_points\": %u, \"tau\": %.17g, \"residuals\": %zu, \"inverse_err\": %.3g}\n",
+                good ? 1 : 0, Tef(0, 3), Tef(1, 3), Tef(2, 3), Tef(0, 0), Tef(0, 1), Tef(0, 2), Tef(1, 0), Tef(1, 1), Tef(1, 2), Tef(2, 0), Tef(2, 1), Tef(2, 2),
+                v[0], v[1], v[2], v[3], v[4], v[5], info.num_iterations, info.num_points, tracker.config.loss_params[0], kf->residuals.size(), id_err);
+    return good ? 0 : 1;
+}
