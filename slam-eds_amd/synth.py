@@ -99,7 +99,7 @@ def _flow_rows(x, y, rho):
 def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, *,
                    rot_deg: float = 0.2, trans_norm: float = 0.004,
                    blur_ksize: int = 7, blur_sigma: float = 1.5, noise: float = 0.05,
-                   unit_weights: bool = False, start: str = "truth_velocity") -> Alignment:
+                   unit_weights: bool = False, start: str = "truth_velocity", margin: int = 16) -> Alignment:
     """Build one deterministic alignment (numpy PCG64, ``default_rng(seed)``).
 
     ``rot_deg`` / ``trans_norm`` set the ground-truth offset of the event frame
@@ -111,11 +111,11 @@ def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, 
     """
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = intrinsics(H, W)
-    # distinct integer pixels in [16, W-17] x [16, H-17]
-    w_in, h_in = W - 32, H - 32
+    # distinct integer pixels in [margin, W-1-margin] x [margin, H-1-margin]
+    w_in, h_in = W - 2 * margin, H - 2 * margin
     flat = rng.choice(w_in * h_in, size=N, replace=False)
-    px = (flat % w_in + 16).astype(np.float64)
-    py = (flat // w_in + 16).astype(np.float64)
+    px = (flat % w_in + margin).astype(np.float64)
+    py = (flat // w_in + margin).astype(np.float64)
     # the reference selects points patch by patch over a grid scanned row-major (KeyFrame.cpp:752-787,
     # 20x20 cells), so a real keyframe's point vectors are in raster order of their grid cell
     order = np.argsort((py // 20) * 4096 + (px // 20), kind="stable")

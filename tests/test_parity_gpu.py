@@ -373,3 +373,28 @@ def test_tracker_mirror_api(gpu, capi, synth, po):
     ok, T2 = t.optimize(1, np.full_like(al.frame, np.nan), T)
     assert not ok and T2 is T and np.array_equal(t.px, px) and np.array_equal(t.vx, vx) and t.config.loss_params == lp
     t.close()
+
+
+def test_coarse_to_fine_pyramid_levels(gpu, capi, synth, po):
+    """BASELINE.json configs[3]: 4 levels (80x60 ... 640x480) with 2 000 -> 16 000 points (a build-side
+    extension, SURVEY §8d: the reference's own "levels" are same-size morphological frames).  Every level is
+    solved on the device and must match the oracle; the pose of a level seeds the next finer one.  N = 16 000
+    also exercises the streaming (constants-from-HBM) variant of the persistent kernel, N = 4 000 the
+    4-points-per-lane 1024-thread variant."""
+    levels = [(60, 80, 2000), (120, 160, 4000), (240, 320, 8000), (480, 640, 16000)]
+    p, q = None, None
+    for lvl, (H, W, N) in enumerate(levels):
+        al = synth.make_alignment(3234 + lvl, H=H, W=W, N=N, margin=4)
+        if p is None:
+            p, q = al.p0.copy(), al.q0.copy()
+        ref = po.Oracle(al).pose6_lm(p, q, al.v0, iters=6, lambda0=0.01)
+        h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=6)
+        pg, qg, _, info = h.optimize(0, p=p, q=q, v=al.v0)
+        assert info["num_points"] == N and info["num_iterations"] == 6
+        assert np.array_equal(h.trace(0)["accepted"], ref["accepted"])
+        assert po.se3_distance(pg, qg, ref["p"], ref["q"]) <= TOL_POSE
+        r = h.residuals(0)
+        er = po.Oracle(al).pose6_eval(pg, qg, al.v0)["r"]
+        assert np.abs(r - er).max() <= TOL_R * np.abs(er).max()
+        h.close()
+        p, q = pg, qg
