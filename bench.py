@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--sampling", choices=["bicubic", "bilinear"], default="bicubic")
     ap.add_argument("--solver", choices=["lm6", "gn6"], default="lm6")
+    ap.add_argument("--lambda0", type=float, default=0.01, help="initial LM6 damping (DSO template: 0.01)")
     ap.add_argument("--exec", dest="exec_", choices=["device", "host"], default="device")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic alignments (replicated to fill the batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (rank 0, N=1 only)")
@@ -134,7 +135,7 @@ def main():
                               sampling=capi.SAMPLE_BICUBIC if a.sampling == "bicubic" else capi.SAMPLE_BILINEAR,
                               solver=capi.SOLVER_LM6 if a.solver == "lm6" else capi.SOLVER_GN6,
                               exec=capi.EXEC_DEVICE if a.exec_ == "device" else capi.EXEC_HOST,
-                              max_num_iterations=a.iters)
+                              max_num_iterations=a.iters, lambda0=a.lambda0)
     h = capi.Handle(cfg, B, N, H, W)
     frames32 = [np.ascontiguousarray(x.frame, dtype=np.float32) for x in als]
     for b in range(B):                               # every slot owns its copy in HBM

@@ -289,6 +289,9 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     if (hipMalloc(&fb->d_sv, sizeof(edss::Solver6) * (size_t)B) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&fb->h_in, sizeof(EdsFusedIn) * B, hipHostMallocDefault) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&fb->h_out, sizeof(EdsFusedOut) * B, hipHostMallocDefault) != hipSuccess) return -1;
+    if (hipMalloc((void**)&fb->d_out12, sizeof(EdsFused12Out) * B) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&fb->h_out12, sizeof(EdsFused12Out) * B, hipHostMallocDefault) != hipSuccess) return -1;
+    std::memset(fb->h_out12, 0, sizeof(EdsFused12Out) * B);
     std::memset(fb->h_in, 0, sizeof(EdsFusedIn) * B);
     std::memset(fb->h_out, 0, sizeof(EdsFusedOut) * B);
     return 0;
@@ -300,11 +303,21 @@ void eds_fused_free(EdsFusedBuffers* fb) {
     if (fb->d_sv) hipFree(fb->d_sv);
     if (fb->h_in) hipHostFree(fb->h_in);
     if (fb->h_out) hipHostFree(fb->h_out);
+    if (fb->d_out12) hipFree(fb->d_out12);
+    if (fb->h_out12) hipHostFree(fb->h_out12);
     *fb = EdsFusedBuffers();
 }
 
 int eds_fused_solve(eds_trk* h, int level, int first, int count) {
-    if (h->cfg.solver == EDS_SOLVER_REF12) return eds_internal_solve_host(h, level, first, count);
+    if (h->cfg.solver == EDS_SOLVER_REF12) {
+        // The persistent REF12 kernel wins on batches (1.7 M LM iterations/s at B = 1024 vs 0.4 M host-driven) but its
+        // serial 12x12 solver lane still spills (round-1 gap): for a handful of alignments the
+        // host-driven loop has the lower latency (0.41 ms vs 0.74 ms for one 2 000-point solve).
+        const char* force = getenv("EDS_REF12_EXEC");                // tuning knob: "device" | "host"
+        const bool want_device = force ? (std::strcmp(force, "device") == 0) : (count >= 32);
+        if (want_device && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
+        return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks or > 2048 points
+    }
     EdsFusedBuffers& fb = h->fused;
     if (fb.pending_count > 0) return eds_internal_fail(EDS_ERR_STATE, "previous batch not collected: call eds_trk_sync first");
     int lv = level < 0 ? 0 : (level >= EDS_MAX_LEVELS ? EDS_MAX_LEVELS - 1 : level);
@@ -361,6 +374,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;
     fb.pending_count = count;
+    fb.pending_kind = 6;
     fb.launch_wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return EDS_OK;
 }
@@ -368,6 +382,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 int eds_fused_collect(eds_trk* h) {
     EdsFusedBuffers& fb = h->fused;
     if (fb.pending_count <= 0) return EDS_OK;
+    if (fb.pending_kind == 12) return eds_fused12_collect(h);
     const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     float dev_ms = 0.f;
     hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);

@@ -1,6 +1,8 @@
 // Persistent on-device solve (EDS_EXEC_DEVICE): one workgroup per alignment runs the whole
-// Gauss-Newton / damped loop — residual+Jacobian pass, wavefront reduction, 6x6 solve, SE(3)
-// update, accept test — without returning to the host between iterations.
+// iteration loop — residual+Jacobian pass, wavefront reduction, small dense solve, pose update,
+// accept test — without returning to the host between iterations.
+//   eds_fused.hip    pose-only solvers (GN6 / LM6)
+//   eds_fused12.hip  the reference problem (REF12: 12 local parameters, Ceres-LM semantics)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,23 +12,30 @@ struct eds_trk;
 struct EdsFusedIn {            // start state of a slot
     double p[3], q[4], v[6], pad[3];
 };
-struct EdsFusedOut {           // compact result of a slot (trace stays in HBM until asked for)
+struct EdsFusedOut {           // compact result of a pose-only solve (trace stays in HBM until asked for)
     double p[3], q[4];
     double initial_cost, final_cost;
     int32_t iterations, ntrace, failed, naccepted;
     double pad[3];
 };
+struct EdsFused12Out {         // compact result of a REF12 solve
+    double p[3], q[4], v[6];
+    double initial_cost, final_cost;
+    int32_t termination, num_successful, num_unsuccessful, failed;
+    double pad;
+};
 
 struct EdsFusedBuffers {
     EdsFusedIn* d_in = nullptr;
     EdsFusedOut* d_out = nullptr;
+    EdsFused12Out* d_out12 = nullptr;
     void* d_sv = nullptr;          // edss::Solver6 per slot (full state incl. trace)
     EdsFusedIn* h_in = nullptr;    // pinned
     EdsFusedOut* h_out = nullptr;  // pinned
+    EdsFused12Out* h_out12 = nullptr;
     int B = 0;
-    int pending_first = 0, pending_count = 0;   // range launched but not yet collected
+    int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
     double launch_wall_us = 0.0;
-    void* t0 = nullptr;
 };
 
 int  eds_fused_alloc(EdsFusedBuffers* fb, int B);
@@ -34,6 +43,10 @@ void eds_fused_free(EdsFusedBuffers* fb);
 int  eds_fused_solve(eds_trk* h, int level, int first, int count);   // asynchronous on h->st
 int  eds_fused_collect(eds_trk* h);                                  // after the stream is idle
 int  eds_fused_fetch_trace(eds_trk* h, int slot);                    // D2H of one slot's trace
+
+bool eds_fused12_supported(const eds_trk* h, int first, int count);
+int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
+int  eds_fused12_collect(eds_trk* h);
 
 // defined in eds_capi.hip
 int eds_internal_fail(int code, const char* msg);

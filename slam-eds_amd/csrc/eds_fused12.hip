@@ -1,0 +1,280 @@
+// Persistent on-device solve of THE REFERENCE PROBLEM (EDS_SOLVER_REF12 with EDS_EXEC_DEVICE):
+// 12 local parameters (translation, quaternion-local, unit velocity), per-block model normalisation and
+// robust loss, Ceres trust-region LM semantics (reference Tracker.cpp:104-241, PhotometricError.hpp:124-182).
+//
+// Same organisation as eds_fused.hip — one workgroup per alignment, points resident in registers, frame
+// patches in the LDS cache, lane 0 runs the shared state machine (edss::Solver12) — with two differences:
+//   * every point contributes a 1x12 row (closed forms of SURVEY §8a), so the running sums are the 78 + 12 + 1
+//     entries of the upper triangle of J^T J, J^T r and r^2: a 128-wide reduce-scatter butterfly;
+//   * the reference normalises the model and applies its loss per residual block (options.num_threads blocks,
+//     Tracker.cpp:178-195), so the sums are formed block by block (up to EDS_DEV_MAX_BLOCKS = 8 on the device;
+//     more blocks fall back to the host-driven loop).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+
+#include "eds_device.hpp"
+#include "eds_fused.hpp"
+#include "eds_handle.hpp"
+#include "eds_math.hpp"
+#include "eds_solver.hpp"
+
+using namespace edsd;
+
+#define EDS12_THREADS 512
+#define EDS12_WAVES (EDS12_THREADS / 64)
+#define EDS12_CACHE_CAP 2048
+
+template <int SAMPLING, int PPT>
+__global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
+                                                                  EdsFused12Out* __restrict__ out, int first, int iters,
+                                                                  int loss_type, double loss_a, double ftol, double gtol,
+                                                                  double ptol, int nb) {
+    const int slot = first + blockIdx.x;
+    const int tid = threadIdx.x, nthr = EDS12_THREADS;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
+    __shared__ edss::Solver12 sv;
+    __shared__ edss::Sums12Dev sums;
+    __shared__ double s_pose[EDS_POSE_STRIDE];
+    __shared__ float s_red[EDS12_WAVES][EDS_RED_K12];
+    __shared__ int s_state;
+    __shared__ float s_patch[NTAP][EDS12_CACHE_CAP];
+    __shared__ int s_cell[EDS12_CACHE_CAP];
+
+    const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const double* __restrict__ G = A.G + (size_t)slot * EDS_MAX_BLOCKS * 36;
+    const int N = (int)gpb[EDS_PB_N];
+    const int ne = N / nb;
+    const size_t base = (size_t)slot * A.Np;
+    FrameView frame;
+    frame.base = A.frame + (size_t)slot * A.Hp * A.Wp;
+    frame.H = A.H; frame.W = A.W; frame.Hp = A.Hp; frame.Wp = A.Wp; frame.TW = A.Wp >> 2; frame.tiled = A.tiled;
+
+    if (tid == 0) {
+        const EdsFusedIn& I = in[slot];
+        for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
+        sv.init(iters, loss_type, loss_a, ftol, gtol, ptol, I.p, I.q, I.v);
+        edsm::fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose);
+        sums.nb = nb;
+        s_state = 0;
+    }
+    // per-point constants in registers for the whole solve
+    PointKf kf[PPT];
+    float kw[PPT], ka[PPT][6];
+    int kblk[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid + j * nthr;
+        const bool in_range = i < N;
+        const size_t o = base + (in_range ? i : 0);
+        const float x = A.x[o], y = A.y[o], rho = A.rho[o];
+        kf[j].x = x; kf[j].y = y; kf[j].rhop = rho + 1e-5f;
+        kf[j].f0x = A.f0x[o]; kf[j].f0y = A.f0y[o]; kf[j].cell0 = A.cell0[o];
+        kw[j] = in_range ? A.w[o] : 0.0f;
+        model_row(x, y, rho, A.gx[o], A.gy[o], ka[j]);
+        kblk[j] = in_range ? block_of(i, ne, nb) : -1;
+        if (i < EDS12_CACHE_CAP) s_cell[i] = 0x7fffffff;
+    }
+    __syncthreads();
+
+    for (;;) {
+        const int state = s_state;
+        PoseF ps;
+        load_pose(s_pose, ps);
+        float vf[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
+        float Pv[36];                   // local Jacobian of the unit-norm velocity plus (wave-uniform -> SGPRs)
+#pragma unroll
+        for (int k = 0; k < 36; ++k) Pv[k] = uniformf((float)s_pose[EDS_PB_PV + k]);
+        for (int blk = 0; blk < nb; ++blk) {
+            const float inv_n = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk]);
+            float gvec[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gvec[k] = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk + 1 + k]);
+            float acc[EDS_RED_K12];
+#pragma unroll
+            for (int j = 0; j < EDS_RED_K12; ++j) acc[j] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                if (kblk[j] != blk) continue;
+                const int i = tid + j * nthr;
+                PointGeom pg;
+                project_point(ps, kf[j], pg);
+                float tap[NTAP];
+                const bool cached = i < EDS12_CACHE_CAP;
+                const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
+                if (cached && s_cell[i] == key) {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) tap[t] = s_patch[t][i];
+                } else {
+                    if (SAMPLING == 0) load_patch16(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[16]>(tap));
+                    else load_patch4(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[4]>(tap));
+                    if (cached) {
+#pragma unroll
+                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[t];
+                        s_cell[i] = key;
+                    }
+                }
+                float E, Er, Ec;
+                if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
+                else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
+                PointProj pp;
+                finish_point(ps, pg, E, Er, Ec, pp);
+                const float w = kw[j];
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) m += ka[j][k] * vf[k];
+                const float r = w * (m * inv_n - pp.E);
+                float J[12];
+                J[0] = -w * pp.g0; J[1] = -w * pp.g1; J[2] = -w * pp.g2;
+                // quaternion local: -2 w (R X) x gradE_P with R X = P - t   
+                const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
+                const float w2 = -2.0f * w;
+                J[3] = w2 * (ry * pp.g2 - rz * pp.g1);
+                J[4] = w2 * (rz * pp.g0 - rx * pp.g2);
+                J[5] = w2 * (rx * pp.g1 - ry * pp.g0);
+                // velocity local: w (a/n - m (G v)/n^3) (I - v v^T/|v|^2)/|v|
+                float row[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) row[k] = w * (ka[j][k] * inv_n - m * gvec[k]);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) s += row[k] * Pv[6 * k + c];
+                    J[6 + c] = s;
+                }
+                accumulate_normal<12>(acc, J, r, 1.0f, r * r);
+                if (state == 1) A.r[base + i] = r;
+            }
+            wave_reduce_scatter<EDS_RED_K12>(acc, lane);
+            s_red[wave][wave_red_index<EDS_RED_K12>(lane, 0)] = acc[0];
+            s_red[wave][wave_red_index<EDS_RED_K12>(lane, 1)] = acc[1];
+            __syncthreads();
+            if (tid < EDS_RED_N12) {            // cross-wavefront sum in fp64, unpacked into the solver's input
+                double s = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < EDS12_WAVES; ++wv) s += (double)s_red[wv][tid];
+                if (tid < 78) {
+                    int a = 0, rem = tid;
+                    while (rem >= 12 - a) { rem -= 12 - a; ++a; }
+                    const int b = a + rem;
+                    sums.H[blk][12 * a + b] = s;
+                    sums.H[blk][12 * b + a] = s;
+                } else if (tid < 90) {
+                    sums.g[blk][tid - 78] = s;
+                } else {
+                    sums.s[blk] = s;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            sv.on_eval(sums);
+            if (sv.done) {
+                s_state = 2;
+            } else {
+                edsm::fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose);
+                s_state = sv.final_pass ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (s_state == 2) break;
+    }
+
+    if (tid == 0) {
+        EdsFused12Out& O = out[slot];
+        const bool ok = sv.termination != edss::TERM_FAILURE;
+        for (int i = 0; i < 3; ++i) O.p[i] = ok ? sv.best_p[i] : sv.p[i];
+        for (int i = 0; i < 4; ++i) O.q[i] = ok ? sv.best_q[i] : sv.q[i];
+        for (int i = 0; i < 6; ++i) O.v[i] = ok ? sv.best_v[i] : sv.v[i];
+        O.initial_cost = sv.initial_cost; O.final_cost = sv.minimum_cost;
+        O.termination = sv.termination; O.num_successful = sv.num_successful; O.num_unsuccessful = sv.num_unsuccessful;
+        O.failed = ok ? 0 : 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+bool eds_fused12_supported(const eds_trk* h, int first, int count) {
+    int nb = h->cfg.num_blocks < 1 ? 1 : h->cfg.num_blocks;
+    if (nb > EDS_DEV_MAX_BLOCKS) return false;
+    for (int s = first; s < first + count; ++s)
+        if (h->slots[s].N > 4 * EDS12_THREADS) return false;
+    return true;
+}
+
+int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
+    EdsFusedBuffers& fb = h->fused;
+    if (fb.pending_count > 0) return eds_internal_fail(EDS_ERR_STATE, "previous batch not collected: call eds_trk_sync first");
+    int lv = level < 0 ? 0 : (level >= EDS_MAX_LEVELS ? EDS_MAX_LEVELS - 1 : level);
+    const int iters = h->cfg.max_num_iterations[lv];
+    const int nb = h->cfg.num_blocks < 1 ? 1 : h->cfg.num_blocks;
+    int maxN = 0;
+    for (int s = first; s < first + count; ++s) {
+        const Slot& sl = h->slots[s];
+        if (!sl.has_kf || !sl.has_frame) return eds_internal_fail(EDS_ERR_STATE, "keyframe or event frame not set");
+        if (sl.N > maxN) maxN = sl.N;
+        EdsFusedIn& I = fb.h_in[s];
+        std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
+    }
+    hipError_t e = hipMemcpyAsync(fb.d_in + first, fb.h_in + first, sizeof(EdsFusedIn) * count, hipMemcpyHostToDevice, h->st);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    const EdsArrays A = h->arrays();
+    const int ppt = (maxN + EDS12_THREADS - 1) / EDS12_THREADS;
+    const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
+    hipEventRecord(h->ev0, h->st);
+#define EDS_LAUNCH12(S, P)                                                                                                  \
+    hipLaunchKernelGGL((eds_fused12_kernel<S, P>), dim3(count), dim3(EDS12_THREADS), 0, h->st, A, fb.d_in, fb.d_out12, first, \
+                       iters, h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,    \
+                       h->cfg.parameter_tolerance, nb)
+    if (ppt <= 1) { if (bicubic) EDS_LAUNCH12(0, 1); else EDS_LAUNCH12(1, 1); }
+    else if (ppt <= 2) { if (bicubic) EDS_LAUNCH12(0, 2); else EDS_LAUNCH12(1, 2); }
+    else { if (bicubic) EDS_LAUNCH12(0, 4); else EDS_LAUNCH12(1, 4); }
+#undef EDS_LAUNCH12
+    hipEventRecord(h->ev1, h->st);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    e = hipMemcpyAsync(fb.h_out12 + first, fb.d_out12 + first, sizeof(EdsFused12Out) * count, hipMemcpyDeviceToHost, h->st);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    fb.pending_first = first;
+    fb.pending_count = count;
+    fb.pending_kind = 12;
+    fb.launch_wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return EDS_OK;
+}
+
+int eds_fused12_collect(eds_trk* h) {
+    EdsFusedBuffers& fb = h->fused;
+    const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    float dev_ms = 0.f;
+    hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
+    for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) {
+        Slot& sl = h->slots[s];
+        const EdsFused12Out& O = fb.h_out12[s];
+        const bool ok = O.failed == 0;
+        if (ok) { std::memcpy(sl.p, O.p, sizeof(sl.p)); std::memcpy(sl.q, O.q, sizeof(sl.q)); std::memcpy(sl.v, O.v, sizeof(sl.v)); }
+        sl.res_on_device = ok;
+        sl.trace_on_device = false;
+        sl.residuals.clear();
+        sl.ntrace = 0;
+        eds_trk_info& in = sl.info;
+        std::memset(&in, 0, sizeof(in));
+        in.meas_time_us = now - fb.launch_wall_us;
+        in.time_seconds = in.meas_time_us * 1e-6;
+        in.device_time_us = dev_ms * 1e3;
+        in.num_points = sl.N;
+        in.num_successful_steps = O.num_successful;
+        in.num_unsuccessful_steps = O.num_unsuccessful;
+        in.num_iterations = O.num_successful + O.num_unsuccessful;       // Tracker.cpp:211
+        in.success = ok;
+        in.termination = O.termination;
+        in.initial_cost = O.initial_cost;
+        in.final_cost = O.final_cost;
+    }
+    fb.pending_count = 0;
+    fb.pending_kind = 0;
+    return EDS_OK;
+}

@@ -135,13 +135,18 @@ struct Solver6 {
 };
 
 // ---------------------------------------------------------------------------------------
-struct Sums12 {
+template <int MAXB>
+struct Sums12T {
     int nb;
-    double s[EDS_MAX_BLOCKS];           // ||r_block||^2
-    double H[EDS_MAX_BLOCKS][144];      // J_b^T J_b  (Ceres-local columns, uncorrected)
-    double g[EDS_MAX_BLOCKS][12];       // J_b^T r_b
+    double s[MAXB];                     // ||r_block||^2
+    double H[MAXB][144];                // J_b^T J_b  (Ceres-local columns, uncorrected)
+    double g[MAXB][12];                 // J_b^T r_b
 };
-EDS_HD void unpack12_add(const double* rec, Sums12* S, int k, bool first) {
+typedef Sums12T<EDS_MAX_BLOCKS> Sums12;          // host-driven loop: up to 16 residual blocks
+#define EDS_DEV_MAX_BLOCKS 8                     // persistent kernel: the sums live in LDS next to the patch cache
+typedef Sums12T<EDS_DEV_MAX_BLOCKS> Sums12Dev;
+template <class S12>
+EDS_HD void unpack12_add(const double* rec, S12* S, int k, bool first) {
     int c = 0;
     for (int a = 0; a < 12; ++a)
         for (int b = a; b < 12; ++b) {
@@ -205,7 +210,8 @@ struct Solver12 {
     }
     // cost = 1/2 sum rho(s_b); optionally the corrected normal equations (rho'' <= 0 for both
     // losses, so the Ceres corrector reduces to scaling rows by sqrt(rho')).
-    EDS_HD bool reduce(const Sums12& S, double* cost, double* A_, double* g_) const {
+    template <class S12>
+    EDS_HD bool reduce(const S12& S, double* cost, double* A_, double* g_) const {
         double c = 0.0;
         if (A_) { for (int i = 0; i < 144; ++i) A_[i] = 0.0; for (int i = 0; i < 12; ++i) g_[i] = 0.0; }
         for (int k = 0; k < S.nb; ++k) {
@@ -223,7 +229,8 @@ struct Solver12 {
         return (t == t) && (fabs(t) < 1e300);
     }
     // EvaluateGradientAndJacobian at the accepted point
-    EDS_HD bool linearise(const Sums12& S) {
+    template <class S12>
+    EDS_HD bool linearise(const S12& S) {
         if (!reduce(S, &x_cost, A, g)) return false;
         if (!have_scale) {
             for (int k = 0; k < 12; ++k) scale[k] = 1.0 / (1.0 + sqrt(A[13 * k]));
@@ -273,28 +280,33 @@ struct Solver12 {
             ++iteration;
             step_successful = 0;
             // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
-            double As[144], gs[12];
+            // (packed lower triangle, scaled on the fly: on the GPU the whole solve stays in registers)
+            double L[78], y[12];
+            EDS_UNROLL
             for (int a = 0; a < 12; ++a) {
-                for (int b = 0; b < 12; ++b) As[12 * a + b] = A[12 * a + b] * scale[a] * scale[b];
-                gs[a] = g[a] * scale[a];
+                EDS_UNROLL
+                for (int b = 0; b <= a; ++b) L[EDS_TRI(a, b)] = A[12 * a + b] * scale[a] * scale[b];
+                y[a] = g[a] * scale[a];
             }
-            if (!reuse_diagonal)
-                for (int k = 0; k < 12; ++k) diagonal[k] = fmin(fmax(As[13 * k], 1e-6), 1e32);
-            double Al[144], y[12];
-            for (int i = 0; i < 144; ++i) Al[i] = As[i];
-            for (int k = 0; k < 12; ++k) Al[13 * k] += diagonal[k] / radius;
+            if (!reuse_diagonal) {
+                EDS_UNROLL
+                for (int k = 0; k < 12; ++k) diagonal[k] = fmin(fmax(L[EDS_TRI(k, k)], 1e-6), 1e32);
+            }
+            EDS_UNROLL
+            for (int k = 0; k < 12; ++k) L[EDS_TRI(k, k)] += diagonal[k] / radius;
             reuse_diagonal = 1;
-            bool valid = edsm::cholesky_solve(12, Al, gs, y);
+            bool valid = edsm::chol_solve_packed<12>(L, y);
             if (valid) {
                 double sg = 0.0, sAs = 0.0;
+                EDS_UNROLL
+                for (int a = 0; a < 12; ++a) step[a] = -y[a];
+                EDS_UNROLL
                 for (int a = 0; a < 12; ++a) {
-                    step[a] = -y[a];
-                }
-                for (int a = 0; a < 12; ++a) {
-                    sg += step[a] * gs[a];
+                    sg += step[a] * g[a] * scale[a];
                     double t = 0.0;
-                    for (int b = 0; b < 12; ++b) t += As[12 * a + b] * step[b];
-                    sAs += step[a] * t;
+                    EDS_UNROLL
+                    for (int b = 0; b < 12; ++b) t += A[12 * a + b] * scale[b] * step[b];
+                    sAs += step[a] * scale[a] * t;
                 }
                 model_cost_change = -sg - 0.5 * sAs;
                 valid = model_cost_change > 0.0;
@@ -312,7 +324,8 @@ struct Solver12 {
         }
     }
     // Consumes the sums evaluated at (cp, cq, cv).
-    EDS_HD void on_eval(const Sums12& S) {
+    template <class S12>
+    EDS_HD void on_eval(const S12& S) {
         if (final_pass) { double c; reduce(S, &c, nullptr, nullptr); final_cost = c; done = 1; return; }
         if (!started) {                 // IterationZero
             started = 1;
