@@ -139,6 +139,22 @@ int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp);
 /* Replaces `const std::vector<double>* event_frame` (Tracker.hpp:80): H*W row-major. */
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
+/* ---- event-frame construction on the device ---------------------------------------- */
+/* Forward undistortion LUT of the event camera, H x W floats each (EventFrame::fwd_mapx / fwd_mapy,
+ * reference src/tracking/EventFrame.cpp:72-79,316-317); NULL, NULL = identity.  Once per handle. */
+int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy);
+/* Replaces EventFrame::create for out_scale == 1 (EventFrame.cpp:302-389) and
+ * drawValuesPoints(undist_coord, pol, H, W, "bilinear", 0.5, true) (src/utils/Utils.cpp:50-122): builds the
+ * normalised brightness-increment frame of pyramid `level` (0 = plain; i >= 1 = dilate + erode with a (2i+1)^2 box,
+ * EventFrame.cpp:350-357) from `n_events` events given as sensor coordinates x[i], y[i] and polarity[i] (0/1), in
+ * time order, straight into slot `slot`'s frame storage.  blur_sigma <= 0 skips the 3x3 Gaussian (reference: 0.5);
+ * use_exp_weights selects eds::utils::expWeight (reference: true).  norm_out (optional) receives the Frobenius norm
+ * the frame was divided by (EventFrame::norm[level]). */
+int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y,
+                              const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norm_out);
+/* Reads slot `slot`'s frame back as H*W row-major doubles (whatever set_event_frame* / build_event_frame stored). */
+int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame);
+
 /* Tracker::reset / set / optimize overloads seed px,qx,vx (Tracker.cpp:49-102). */
 int eds_trk_set_state(eds_trk* h, int slot, const double p[3], const double q_xyzw[4], const double v[6]);
 int eds_trk_get_state(eds_trk* h, int slot, double p[3], double q_xyzw[4], double v[6]);

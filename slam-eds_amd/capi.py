@@ -31,6 +31,7 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
+    "eds_trk_set_undistort_map", "eds_trk_build_event_frame", "eds_trk_get_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
@@ -105,6 +106,10 @@ def lib():
         L.eds_trk_set_event_frame_f32.argtypes = [C.c_void_p, C.c_int, _fp]
         L.eds_trk_set_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
+        L.eds_trk_set_undistort_map.argtypes = [C.c_void_p, _fp, _fp]
+        L.eds_trk_build_event_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                                C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
+        L.eds_trk_get_event_frame.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_trk_set_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_results.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -212,6 +217,32 @@ class Handle:
         else:
             fr = _f64(fr)
             _check(lib().eds_trk_set_event_frame(self._h, slot, _p(fr)))
+
+    def set_undistort_map(self, mapx=None, mapy=None):
+        if mapx is None:
+            _check(lib().eds_trk_set_undistort_map(self._h, None, None))
+            return
+        mx, my = np.ascontiguousarray(mapx, dtype=np.float32), np.ascontiguousarray(mapy, dtype=np.float32)
+        if mx.size != self.H * self.W or my.size != self.H * self.W:
+            raise EdsError(ERR_INVALID, "undistortion map size != H*W")
+        _check(lib().eds_trk_set_undistort_map(self._h, mx.ctypes.data_as(_fp), my.ctypes.data_as(_fp)))
+
+    def build_event_frame(self, slot, x, y, polarity, level=0, blur_sigma=0.5, use_exp_weights=True):
+        """EventFrame::create on the device; returns the Frobenius norm the frame was divided by."""
+        ex = np.ascontiguousarray(x, dtype=np.uint16)
+        ey = np.ascontiguousarray(y, dtype=np.uint16)
+        pol = np.ascontiguousarray(polarity, dtype=np.uint8)
+        norm = C.c_double(0.0)
+        _check(lib().eds_trk_build_event_frame(self._h, slot, int(ex.shape[0]), ex.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               ey.ctypes.data_as(C.POINTER(C.c_uint16)), pol.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               int(level), float(blur_sigma), int(bool(use_exp_weights)),
+                                               C.cast(C.byref(norm), _dp)))
+        return norm.value
+
+    def get_event_frame(self, slot):
+        fr = np.zeros((self.H, self.W))
+        _check(lib().eds_trk_get_event_frame(self._h, slot, _p(fr)))
+        return fr
 
     def set_state(self, slot, p=None, q=None, v=None):
         p = None if p is None else _f64(p)

@@ -286,6 +286,7 @@ void free_all(eds_trk* h) {
                      h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
+    eds_frame_free(&h->frame_build);
     void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -550,6 +551,39 @@ int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
     EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
     EDS_HIP_TRY(hipStreamSynchronize(h->st));
     h->slots[slot].has_frame = true;
+    return EDS_OK;
+}
+
+int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if ((mapx == nullptr) != (mapy == nullptr)) return fail(EDS_ERR_INVALID, "mapx and mapy must both be given or both be NULL");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_frame_set_map(h, mapx, mapy);
+}
+
+int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y, const uint8_t* polarity,
+                              int level, double blur_sigma, int use_exp_weights, double* norm_out) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (n_events < 0 || level < 0 || level > 16) return fail(EDS_ERR_INVALID, "bad event count or level");
+    if (n_events > 0 && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_frame_build(h, slot, n_events, x, y, polarity, level, blur_sigma, use_exp_weights, norm_out);
+}
+
+int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!frame) return fail(EDS_ERR_INVALID, "null output");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    const size_t n = (size_t)h->Hp * h->Wp;
+    EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dframe + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
+    const int TW = h->Wp >> 2;
+    for (int r = 0; r < h->H; ++r)
+        for (int c = 0; c < h->W; ++c) {
+            const size_t o = h->tiled ? ((size_t)((r >> 2) * TW + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * h->Wp + c);
+            frame[(size_t)r * h->W + c] = h->h_f32[o];
+        }
     return EDS_OK;
 }
 

@@ -48,6 +48,19 @@ bool eds_fused12_supported(const eds_trk* h, int first, int count);
 int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);
 
+// ---- event-frame construction on device (eds_frame.hip) ---------------------------------------------------
+struct EdsFrameBuffers {
+    float *d_mapx = nullptr, *d_mapy = nullptr;     // forward undistortion LUT (H x W), optional
+    double *d_img = nullptr, *d_tmp = nullptr, *d_norm = nullptr;
+    uint16_t *d_ex = nullptr, *d_ey = nullptr;
+    uint8_t* d_pol = nullptr;
+    int cap_events = 0;
+};
+void eds_frame_free(EdsFrameBuffers* fb);
+int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy);
+int  eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol, int level,
+                     double blur_sigma, int use_exp_weights, double* norm_out);
+
 // defined in eds_capi.hip
 int eds_internal_fail(int code, const char* msg);
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count);

@@ -1,0 +1,110 @@
+"""Event-frame construction: numpy oracle known answers on CPU, HIP kernels vs the oracle on GPU."""
+import numpy as np
+import pytest
+
+
+def make_events(seed, n, H, W, distort=True):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, W, n).astype(np.uint16)
+    y = rng.integers(0, H, n).astype(np.uint16)
+    pol = rng.integers(0, 2, n).astype(np.uint8)
+    if distort:      # a smooth forward LUT with sub-pixel offsets that pushes some events outside the image
+        cc, rr = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+        mapx = (cc + 1.7 * np.sin(rr / 23.0) + 0.004 * (cc - W / 2)).astype(np.float32)
+        mapy = (rr + 1.3 * np.cos(cc / 31.0) - 0.003 * (rr - H / 2)).astype(np.float32)
+    else:
+        mapx = mapy = None
+    return x, y, pol, mapx, mapy
+
+
+# ---- oracle known answers (CPU) ---------------------------------------------------------------------------------
+def test_oracle_single_event_splat_and_weights():
+    import np_frame_oracle as fo
+    # one event exactly on a pixel, no blur: all its weight lands there; exp weight of the only event = exp(-4.5)
+    img = fo.draw_values_points(np.array([5.0]), np.array([3.0]), np.array([1.0]), 8, 12, s=0, use_exp_weights=True)
+    assert img[3, 5] == pytest.approx(np.exp(-4.5)) and np.count_nonzero(img) == 1
+    # sub-pixel position: the four bilinear weights sum to one
+    img = fo.draw_values_points(np.array([5.25]), np.array([3.5]), np.array([-1.0]), 8, 12, s=0, use_exp_weights=False)
+    assert img.sum() == pytest.approx(-1.0) and img[3, 5] == pytest.approx(-0.75 * 0.5) and img[4, 6] == pytest.approx(-0.25 * 0.5)
+    # outside the image: zero weight (Utils.cpp:92-95), nothing written
+    img = fo.draw_values_points(np.array([-3.2, 20.0]), np.array([2.0, 2.0]), np.array([1.0, 1.0]), 8, 12, s=0, use_exp_weights=False)
+    assert np.count_nonzero(img) == 0
+    # on the last column only the in-image taps vote (x1 = W is out: wc = wd = 0)
+    img = fo.draw_values_points(np.array([11.5]), np.array([2.0]), np.array([1.0]), 8, 12, s=0, use_exp_weights=False)
+    assert img[2, 11] == pytest.approx(0.5) and img.sum() == pytest.approx(0.5)
+    assert fo.exp_weight(0.5) == 1.0 and fo.exp_weight(0.0) == pytest.approx(np.exp(-4.5))
+
+
+def test_oracle_blur_and_levels():
+    import np_frame_oracle as fo
+    img = np.zeros((7, 9)); img[3, 4] = 1.0
+    b = fo.gaussian_blur_3x3(img, 0.5)
+    t = np.exp(-2.0); k = np.array([t, 1, t]) / (1 + 2 * t)
+    assert np.allclose(b[2:5, 3:6], np.outer(k, k)) and b.sum() == pytest.approx(1.0)
+    corner = np.zeros((5, 5)); corner[0, 0] = 1.0                       # reflect-101: the border pixel is not duplicated
+    bc = fo.gaussian_blur_3x3(corner, 0.5)
+    assert bc[0, 0] == pytest.approx(k[1] * k[1]) and bc[0, 1] == pytest.approx(k[1] * k[0])
+    lv = fo.morph_level(img, 1)                                         # dilate + erode of a single spike
+    assert lv[2:5, 3:6].min() == 1.0 and lv[0, 0] == 0.0 and lv[3, 4] == 1.0
+    x, y, pol, _, _ = make_events(1, 500, 40, 60, distort=False)
+    f, n = fo.event_frame(x, y, pol, 40, 60)
+    assert np.linalg.norm(f) == pytest.approx(1.0) and n > 0
+
+
+# ---- HIP vs oracle (GPU) ----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n", [((48, 64), 300), ((480, 640), 60000), ((181, 243), 5000)], ids=["small", "vga", "odd"])
+@pytest.mark.parametrize("level", [0, 2])
+@pytest.mark.parametrize("distort", [False, True], ids=["identity", "lut"])
+def test_build_event_frame_vs_oracle(gpu, capi, shape, n, level, distort):
+    import np_frame_oracle as fo
+    H, W = shape
+    x, y, pol, mapx, mapy = make_events(42 + n, n, H, W, distort)
+    ref, ref_norm = fo.event_frame(x, y, pol, H, W, mapx, mapy, level=level)
+    h = capi.Handle(capi.default_config(), 2, 64, H, W)
+    h.set_undistort_map(mapx, mapy)
+    norm = h.build_event_frame(1, x, y, pol, level=level)
+    got = h.get_event_frame(1)
+    assert norm == pytest.approx(ref_norm, rel=1e-12)                   # fp64 atomics: only the addition order differs
+    assert np.abs(got - ref).max() <= 1e-7 * np.abs(ref).max()          # stored as fp32
+    assert np.linalg.norm(got) == pytest.approx(1.0, rel=1e-6)
+    # no blur / no exponential weights variants
+    ref2, n2 = fo.event_frame(x, y, pol, H, W, mapx, mapy, level=0, sigma=0.0, use_exp_weights=False)
+    assert h.build_event_frame(0, x, y, pol, level=0, blur_sigma=0.0, use_exp_weights=False) == pytest.approx(n2, rel=1e-12)
+    assert np.abs(h.get_event_frame(0) - ref2).max() <= 1e-7 * np.abs(ref2).max()
+    h.close()
+
+
+@pytest.mark.gpu
+def test_tracker_on_device_built_frame(gpu, capi, synth, po):
+    """End to end: events -> frame on the GPU -> alignment, against the oracle fed with the oracle's frame."""
+    import np_frame_oracle as fo
+    al = synth.make_alignment(77, H=240, W=320, N=800)
+    # events that reproduce the sign structure of the synthetic frame: one event per strong pixel
+    strong = np.argwhere(np.abs(al.frame) > 0.4 * np.abs(al.frame).max())
+    rng = np.random.default_rng(3)
+    strong = strong[rng.permutation(len(strong))]
+    x, y = strong[:, 1].astype(np.uint16), strong[:, 0].astype(np.uint16)
+    pol = (al.frame[strong[:, 0], strong[:, 1]] > 0).astype(np.uint8)
+    ref_frame, _ = fo.event_frame(x, y, pol, al.H, al.W)
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=8), 1, al.N, al.H, al.W)
+    h.set_keyframe(0, al.norm_coord, al.grad, al.idp, al.weights, al.fx, al.fy, al.cx, al.cy)
+    h.build_event_frame(0, x, y, pol)
+    p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+    al2 = type(al)(**{**al.__dict__, "frame": ref_frame})
+    ref = po.Oracle(al2).pose6_lm(al.p0, al.q0, al.v0, iters=8, lambda0=0.01)
+    assert np.array_equal(h.trace(0)["accepted"], ref["accepted"])
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= 1e-4
+    h.close()
+
+
+@pytest.mark.gpu
+def test_build_event_frame_edge_cases(gpu, capi):
+    h = capi.Handle(capi.default_config(), 1, 64, 48, 64)
+    with pytest.raises(capi.EdsError):
+        h.build_event_frame(3, [1], [1], [1])                          # slot out of range
+    n = h.build_event_frame(0, np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros(0, np.uint8))
+    assert n == 0.0 and np.isnan(h.get_event_frame(0)).all()            # 0/0 like the reference (EventFrame.cpp:359-383)
+    with pytest.raises(capi.EdsError):
+        h.set_undistort_map(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32))
+    h.close()
