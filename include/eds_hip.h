@@ -194,6 +194,23 @@ int eds_trk_get_residuals(eds_trk* h, int slot, double* r);
  * (CONSTANT leaves it).  Like the reference, MAD partially reorders the stored residuals. */
 int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau);
 
+/* Batched form: tau[count] for slots [first, first+count).  When the residuals of the last solve are still resident
+ * in HBM (device-mode solves) the median / MAD selection runs on the GPU — one workgroup per alignment, bitonic
+ * sort in LDS — and only 8 bytes per alignment come back. */
+int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, double* tau);
+
+/* ---- post-solve point maintenance ---------------------------------------------------- */
+/* Replaces Tracker::getCoord(delete_out_point) (reference Tracker.cpp:319-376) for slot `slot` at its current pose:
+ * re-projects every point with the RAW inverse depth (:343-351), optionally erases the points that left the frame
+ * (xp < 0 || xp > cols || yp < 0 || yp > rows, :354) from every index-aligned per-point plane on the device —
+ * order-preserving, like repeated KeyFrame::erasePoint (KeyFrame.cpp:1060-1106) — and returns for the n_kept
+ * survivors their new pixel coordinates coord_xy (n x 2), tracks_xy = new - old keyframe pixel (:364-366), the
+ * original indices kept_index (so the caller can erase the same entries from the KeyFrame members this library
+ * does not hold: patches, bundle_patches, ...), and the mean squared flow (:372) that Tracker::needNewKeyframe
+ * (:650-654) tests.  Any output pointer may be NULL; the arrays must hold N entries. */
+int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* coord_xy, double* tracks_xy,
+                          int32_t* kept_index, int* n_kept, double* mean_sq_flow);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
 int eds_trk_timer_start(eds_trk* h);

@@ -35,6 +35,7 @@ EXPORTS = (
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
+    "eds_trk_loss_param_batch", "eds_trk_update_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
 )
 
@@ -121,6 +122,8 @@ def lib():
         L.eds_trk_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip]
         L.eds_trk_get_residuals.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_trk_loss_param.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        L.eds_trk_loss_param_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
+        L.eds_trk_update_points.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp]
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
@@ -325,6 +328,23 @@ class Handle:
         tau = C.c_double(current)
         _check(lib().eds_trk_loss_param(self._h, slot, int(method), C.cast(C.byref(tau), _dp)))
         return tau.value
+
+    def loss_param_batch(self, method, first=0, count=None):
+        count = self.batch - first if count is None else count
+        tau = np.zeros(count)
+        _check(lib().eds_trk_loss_param_batch(self._h, first, count, int(method), _p(tau)))
+        return tau
+
+    def update_points(self, slot, delete_out_points=True):
+        """Tracker::getCoord(delete_out_point): returns dict(coord, tracks, kept, mean_sq_flow)."""
+        N = self._N[slot]
+        coord, tracks = np.zeros((N, 2)), np.zeros((N, 2))
+        kept = np.zeros(N, dtype=np.int32)
+        n, flow = C.c_int32(0), C.c_double(0.0)
+        _check(lib().eds_trk_update_points(self._h, slot, int(bool(delete_out_points)), _p(coord), _p(tracks),
+                                           kept.ctypes.data_as(_ip), C.cast(C.byref(n), _ip), C.cast(C.byref(flow), _dp)))
+        self._N[slot] = n.value
+        return dict(coord=coord[:n.value], tracks=tracks[:n.value], kept=kept[:n.value], mean_sq_flow=flow.value)
 
     # -- measurement ---------------------------------------------------------------------
     def timer_start(self):

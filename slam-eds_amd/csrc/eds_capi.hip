@@ -287,6 +287,7 @@ void free_all(eds_trk* h) {
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
     eds_frame_free(&h->frame_build);
+    eds_points_free(&h->point_ops);
     void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -774,6 +775,10 @@ int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau) {
     if (!tau) return fail(EDS_ERR_INVALID, "null output");
     Slot& s = h->slots[slot];
     if (method == EDS_LP_CONSTANT) return EDS_OK;
+    if (s.res_on_device && (method == EDS_LP_MAD || method == EDS_LP_STD) && eds_points_supported(h, slot, 1)) {
+        EDS_HIP_TRY(hipSetDevice(h->dev));          // residuals still in HBM: select there, 8 bytes come back
+        return eds_points_loss_param(h, slot, 1, method, tau);
+    }
     if ((rc = materialise_residuals(h, slot))) return rc;
     if ((int)s.residuals.size() != s.N || s.N < 1) return fail(EDS_ERR_STATE, "no residuals stored");
     std::vector<double>& r = s.residuals;
@@ -848,6 +853,42 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     EDS_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     EDS_HIP_TRY(hipGetLastError());
     *mean_ms = ms / (float)reps;
+    return EDS_OK;
+}
+
+int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, double* tau) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    if (!tau) return fail(EDS_ERR_INVALID, "null output");
+    if (method == EDS_LP_CONSTANT) return EDS_OK;
+    if (method != EDS_LP_MAD && method != EDS_LP_STD) return fail(EDS_ERR_INVALID, "unknown loss-param method");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    bool on_device = eds_points_supported(h, first, count);
+    for (int s = first; s < first + count && on_device; ++s) on_device = h->slots[s].res_on_device;
+    if (on_device) return eds_points_loss_param(h, first, count, method, tau);
+    for (int s = first; s < first + count; ++s)          // residuals already on the host (or too many points): host selection
+        if ((rc = eds_trk_loss_param(h, s, method, &tau[s - first]))) return rc;
+    return EDS_OK;
+}
+
+int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* coord_xy, double* tracks_xy, int32_t* kept_index,
+                          int* n_kept, double* mean_sq_flow) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    Slot& s = h->slots[slot];
+    if (!s.has_kf) return fail(EDS_ERR_STATE, "keyframe not set");
+    if (!eds_points_supported(h, slot, 1)) return fail(EDS_ERR_INVALID, "more than 4096 points: not supported by the device point maintenance");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    int n = 0;
+    if ((rc = eds_points_update(h, slot, delete_out_points != 0, coord_xy, tracks_xy, kept_index, &n, mean_sq_flow))) return rc;
+    if (n_kept) *n_kept = n;
+    if (n != s.N) {                      // points were erased: every index-aligned plane was compacted on the device
+        s.N = n;
+        s.residuals.clear();
+        s.res_on_device = false;
+        if (n > 0 && (rc = refresh_gram(h, slot))) return rc;
+        if (n == 0) s.has_kf = false;
+    }
     return EDS_OK;
 }
 

@@ -61,6 +61,17 @@ int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy);
 int  eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol, int level,
                      double blur_sigma, int use_exp_weights, double* norm_out);
 
+// ---- loss scale and point maintenance on device (eds_points.hip) --------------------------------------------
+struct EdsPointBuffers {
+    double *d_coord = nullptr, *d_track = nullptr, *d_summary = nullptr, *d_pose = nullptr, *d_tau = nullptr;
+    int* d_kept = nullptr;
+};
+void eds_points_free(EdsPointBuffers* pb);
+bool eds_points_supported(const eds_trk* h, int first, int count);
+int  eds_points_loss_param(eds_trk* h, int first, int count, int method, double* tau_out);
+int  eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, double* tracks_xy, int32_t* kept_index, int* n_kept,
+                       double* mean_sq_flow);
+
 // defined in eds_capi.hip
 int eds_internal_fail(int code, const char* msg);
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count);

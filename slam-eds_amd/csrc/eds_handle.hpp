@@ -39,6 +39,7 @@ struct eds_trk {
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
+    EdsPointBuffers point_ops;
     // pinned host staging
     double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr;
     float *h_f32 = nullptr, *h_r = nullptr;

@@ -217,6 +217,32 @@ class Tracker:
         self.kf.residuals = self._h.residuals(0)
         return [tau]
 
+    def getCoord(self, delete_out_point: bool = False):
+        """Tracker::getCoord (Tracker.cpp:319-376): warped active points in the event frame.  With
+        ``delete_out_point`` the points that left the frame are erased from every index-aligned KeyFrame vector
+        (KeyFrame::erasePoint, KeyFrame.cpp:1060-1106) — on the device and, through the returned index list, here."""
+        self._ensure_handle()
+        kf, h = self.kf, self._h
+        K = np.asarray(kf.K_ref, dtype=np.float64)
+        h.set_keyframe(0, kf.norm_coord, kf.grad, kf.inv_depth, kf.weights, K[0, 0], K[1, 1], K[0, 2], K[1, 2])
+        h.set_state(0, self.px, self.qx, self.vx)
+        out = h.update_points(0, delete_out_point)
+        keep = out["kept"]
+        if len(keep) != len(kf.inv_depth):
+            for name in ("norm_coord", "grad", "weights", "inv_depth"):
+                setattr(kf, name, np.ascontiguousarray(np.asarray(getattr(kf, name))[keep]))
+            if len(kf.residuals) == 0 or len(kf.residuals) != len(keep):
+                kf.residuals = np.zeros(0)
+        self.tracks = out["tracks"]                                  # kf->tracks (Tracker.cpp:365)
+        self.squared_norm_flow = out["mean_sq_flow"]                 # :372
+        return out["coord"]
+
+    def needNewKeyframe(self, weight_factor: float = 0.03) -> bool:
+        """Tracker::needNewKeyframe (Tracker.cpp:650-654)."""
+        rows, cols = self.kf.rows, self.kf.cols
+        image_weight = (cols + rows) * weight_factor
+        return bool(image_weight * float(np.sqrt(np.float32(getattr(self, "squared_norm_flow", 0.0)))) / (cols + rows) > 1)
+
     def close(self):
         if self._h is not None:
             self._h.close()

@@ -1,0 +1,97 @@
+"""Loss scale on the device and post-solve point maintenance against the CPU oracles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_loss_param_on_device_matches_host_and_oracle(gpu, capi, synth, po):
+    als = [synth.make_alignment(900 + b, H=120, W=160, N=n) for b, n in enumerate((1, 2, 63, 64, 500, 777, 1024, 1500))]
+    cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=4)
+    h = capi.Handle(cfg, len(als), 1500, 120, 160)
+    for b, a in enumerate(als):
+        h.set_alignment(b, a)
+    h.optimize_batch(0, 0, len(als))
+    for method, lp in ((capi.LP_MAD, po.LP_MAD), (capi.LP_STD, po.LP_STD)):
+        tau_dev = h.loss_param_batch(method)                          # residuals still in HBM: selected on the GPU
+        for b, a in enumerate(als):
+            p, q, v = h.get_state(b)
+            er = po.Oracle(a).pose6_eval(p, q, v)["r"]
+            tau_ref, _ = po.loss_param(er, lp)
+            r_dev = h.residuals(b)                                    # now also copied to the host
+            tau_exact, _ = po.loss_param(r_dev, lp)                   # oracle rule on the very same fp32 residuals
+            assert tau_dev[b] == pytest.approx(tau_exact, rel=1e-12, abs=1e-300)
+            assert tau_dev[b] == pytest.approx(tau_ref, rel=2e-4, abs=1e-12)
+            assert h.loss_param(b, method) == pytest.approx(tau_exact, rel=1e-12, abs=1e-300)     # host path agrees
+    h.close()
+
+
+@pytest.mark.parametrize("delete", [True, False])
+def test_update_points_vs_oracle(gpu, capi, synth, po, delete):
+    import np_points_oracle as pto
+    al = synth.make_alignment(61, H=120, W=160, N=900, margin=2)
+    K = (al.fx, al.fy, al.cx, al.cy)
+    # a pose that pushes a good fraction of the points out of the frame
+    p = np.array([0.06, -0.03, 0.01])
+    q = synth.quat_from_axis_angle([0.1, 1.0, 0.2], 0.05)
+    ref = pto.get_coord(al.norm_coord, al.idp, al.coord, K, al.H, al.W, p, q, delete)
+    if delete:
+        assert 50 < al.N - len(ref["kept"]) < al.N - 50
+    else:
+        assert len(ref["kept"]) == al.N
+    h = capi.Handle(capi.default_config(exec=capi.EXEC_HOST), 1, al.N, al.H, al.W)
+    h.set_alignment(0, al)
+    h.set_state(0, p, q, al.v0)
+    out = h.update_points(0, delete)
+    assert np.array_equal(out["kept"], ref["kept"])
+    assert np.abs(out["coord"] - ref["coord"]).max() < 5e-5                      # pixels (fp32 displacement form)
+    assert np.abs(out["tracks"] - ref["tracks"]).max() < 5e-5
+    assert out["mean_sq_flow"] == pytest.approx(ref["mean_sq_flow"], rel=1e-5)
+    assert pto.need_new_keyframe(out["mean_sq_flow"], al.H, al.W) == pto.need_new_keyframe(ref["mean_sq_flow"], al.H, al.W)
+    # the compacted device planes now behave exactly like a keyframe uploaded with the kept points only
+    keep = ref["kept"]
+    al2 = type(al)(**{**al.__dict__, "norm_coord": al.norm_coord[keep], "grad": al.grad[keep], "idp": al.idp[keep],
+                      "weights": al.weights[keep], "coord": al.coord[keep]})
+    pe, qe = np.array([0.001, 0.002, -0.001]), synth.quat_from_axis_angle([0.3, -0.2, 0.9], 0.004)
+    g = h.eval(0, pe, qe, al.v0, ncols=6)
+    e = po.Oracle(al2).pose6_eval(pe, qe, al.v0)
+    assert g["r"].shape == (len(keep),)
+    assert np.abs(g["r"] - e["r"]).max() <= 1e-5 * np.abs(e["r"]).max()
+    assert np.linalg.norm(g["JtJ"] - e["H"]) <= 1e-4 * np.linalg.norm(e["H"])
+    # ... including a solve of the reference problem with per-block statistics rebuilt for the new point count
+    h.set_config(capi.default_config(exec=capi.EXEC_HOST, solver=capi.SOLVER_REF12, num_blocks=3, max_num_iterations=6))
+    pr, qr, vr, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+    ref12 = po.Oracle(al2, num_blocks=3, max_num_iterations=6).solve_lm(al.p0, al.q0, al.v0)
+    assert info["num_points"] == len(keep) and info["num_iterations"] == ref12["num_iterations"]
+    assert po.se3_distance(pr, qr, ref12["p"], ref12["q"]) <= 1e-4
+    h.close()
+
+
+def test_update_points_all_in_frame_is_a_no_op(gpu, capi, synth):
+    al = synth.make_alignment(62, H=120, W=160, N=300)
+    h = capi.Handle(capi.default_config(), 1, al.N, al.H, al.W)
+    h.set_alignment(0, al)
+    out = h.update_points(0, True)                                    # identity pose: tracks are zero
+    assert len(out["kept"]) == al.N and np.array_equal(out["kept"], np.arange(al.N))
+    assert np.abs(out["tracks"]).max() < 1e-9 and out["mean_sq_flow"] < 1e-18
+    assert np.abs(out["coord"] - al.coord).max() < 1e-9
+    h.close()
+
+
+def test_tracker_mirror_get_coord(gpu, capi, synth):
+    import importlib
+    import np_points_oracle as pto
+    trk = importlib.import_module("slam-eds_amd.tracker")
+    al = synth.make_alignment(63, H=120, W=160, N=400, margin=2)
+    K = np.array([[al.fx, 0, al.cx], [0, al.fy, al.cy], [0, 0, 1.0]])
+    kf = trk.KeyFrame(al.norm_coord.copy(), al.grad.copy(), al.weights.copy(), al.idp.copy(), K, al.H, al.W)
+    t = trk.Tracker(kf, trk.Config())
+    p, q = np.array([0.05, 0.02, 0.0]), synth.quat_from_axis_angle([0.0, 1.0, 0.1], 0.04)
+    t.reset(kf, p, q, True)
+    ref = pto.get_coord(al.norm_coord, al.idp, al.coord, (al.fx, al.fy, al.cx, al.cy), al.H, al.W, p, q, True)
+    coord = t.getCoord(True)
+    assert coord.shape == ref["coord"].shape and np.abs(coord - ref["coord"]).max() < 5e-5
+    assert len(kf.inv_depth) == len(ref["kept"]) and np.array_equal(kf.inv_depth, al.idp[ref["kept"]])
+    assert t.squared_norm_flow == pytest.approx(ref["mean_sq_flow"], rel=1e-5)
+    assert t.needNewKeyframe(0.03) == pto.need_new_keyframe(ref["mean_sq_flow"], al.H, al.W, 0.03)
+    t.close()
