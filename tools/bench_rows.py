@@ -1,0 +1,32 @@
+"""Timing of the §8f rows on the GPU: event-frame construction, device loss scale, point maintenance."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+capi = importlib.import_module("slam-eds_amd.capi"); synth = importlib.import_module("slam-eds_amd.synth")
+import np_frame_oracle as fo
+H, W = 480, 640
+h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE), 256, 2000, H, W)
+rng = np.random.default_rng(0)
+for n in (10_000, 100_000, 1_000_000):
+    x = rng.integers(0, W, n).astype(np.uint16); y = rng.integers(0, H, n).astype(np.uint16); pol = rng.integers(0, 2, n).astype(np.uint8)
+    h.build_event_frame(0, x, y, pol)
+    t = time.perf_counter()
+    for _ in range(20): h.build_event_frame(0, x, y, pol)
+    dt = (time.perf_counter() - t) / 20
+    t = time.perf_counter(); fo.event_frame(x, y, pol, H, W); dcpu = time.perf_counter() - t
+    print(f"event frame 640x480 from {n:8d} events: GPU {dt*1e6:8.1f} us per frame incl. event upload ({n/dt/1e6:7.1f} M events/s) | numpy oracle {dcpu*1e3:7.1f} ms")
+als = [synth.make_alignment(5000 + i) for i in range(8)]
+for b in range(256):
+    h.set_alignment(b, als[b % 8])
+h.optimize_batch(0, 0, 256)
+t = time.perf_counter()
+for _ in range(10): tau = h.loss_param_batch(capi.LP_MAD)
+print(f"MAD scale of 256 x 2000 residuals on device: {(time.perf_counter()-t)/10*1e6:.1f} us per batch ({(time.perf_counter()-t)/10/256*1e6:.2f} us per alignment)")
+h.optimize_batch(0, 0, 256)
+t = time.perf_counter(); taus = [h.loss_param(b, capi.LP_MAD) for b in range(256)]; d1 = time.perf_counter() - t
+r = [h.residuals(b) for b in range(256)]
+t = time.perf_counter(); taus = [h.loss_param(b, capi.LP_MAD) for b in range(256)]; d2 = time.perf_counter() - t
+print(f"  single-slot calls: device-resident {d1/256*1e6:.1f} us each; host nth_element path {d2/256*1e6:.1f} us each")
+t = time.perf_counter()
+for b in range(256): out = h.update_points(b, True)
+print(f"point maintenance (getCoord + culling), 2000 points: {(time.perf_counter()-t)/256*1e6:.1f} us per alignment incl. readback of coords/tracks")
