@@ -177,7 +177,11 @@ def main():
 
     out = None
     if rank == 0:
-        passes = a.iters + (2 if a.solver == "lm6" else 1)          # initial linearisation (LM6) + iterations + final residual pass
+        # residual/Jacobian passes per solve: LM6 = initial linearisation + one per iteration (the persistent kernel keeps
+        # the accepted pose's residuals in registers; the host-driven loop and N > 2048 add a final residual pass);
+        # GN6 = one per iteration + the final residual pass
+        in_regs = a.exec_ == "device" and N <= 2048
+        passes = a.iters + (1 if (a.solver == "lm6" and in_regs) else (2 if a.solver == "lm6" else 1))
         per_pt = BYTES_RESJAC[a.sampling] + BYTES_REDUCE
         roof = None
         if a.exec_ == "device":

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
+    __shared__ int s_accept;           // the pass just consumed became the accepted pose
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     constexpr int NREG = PPT > 0 ? PPT : 1;
     constexpr bool CACHE = true;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         const EdsFusedIn& I = in[slot];
         for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
         edsm::fill_pose_block(I.p, I.q, I.v, A.G + (size_t)slot * EDS_MAX_BLOCKS * 36, nb, s_pose);
-        sv.init(damped, iters, lambda0, I.p, I.q);
+        sv.init(damped, iters, lambda0, I.p, I.q, PPT > 0 ? 1 : 0);   // PPT > 0: residuals of the accepted pose stay in registers
         s_state = sv.final_pass ? 1 : 0;
     }
     for (int k = tid; k < EDS_FUSED_MAX_WAVES * EDS_RED_K6; k += nthr) (&s_red[0][0])[k] = 0.0f;   // rows of absent wavefronts stay 0
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #else
 #define EDS_STAMP(k) do { } while (0)
 #endif
+    float rcand[NREG], racc[NREG];      // residuals of the pass in flight / of the accepted pose (PPT > 0)
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
     for (;;) {
         EDS_STAMP(0);
         const int state = s_state;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
         // Consumes one point: sample from its (register-resident) taps, residual, 1x6 row, running sums.
-        auto consume = [&](const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, int i) {
+        auto consume = [&](const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, int i) -> float {
             float E, Er, Ec;
             if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
             else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
@@ -155,7 +159,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 ct = hw * r * r * (2.0f - hw);
             }
             accumulate_normal<6>(acc, J, r, hw, ct);
-            if (state == 1 && i < N) A.r[base + i] = r;
+            if (PPT == 0 && state == 1 && i < N) A.r[base + i] = r;      // streaming variant: residuals stored by a final pass
+            return r;
         };
         if (PPT > 0) {
             // phase A: project every point of this lane, probe the patch cache, and put ALL the
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
                     for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[j][t];
                 }
-                consume(pg[j], tap[j], kw[j], kmh[j], i);
+                rcand[j] = consume(pg[j], tap[j], kw[j], kmh[j], i);
             }
         } else {
             for (int i = tid; i < N; i += nthr) {
@@ -246,6 +251,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP(2);
         if (tid == 0) {
             sv.on_eval(s_sums);
+            s_accept = sv.last_accepted;
             if (sv.done) {
                 s_state = 2;
             } else {
@@ -255,7 +261,18 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         }
         EDS_STAMP(3);
         __syncthreads();
+        if (PPT > 0 && s_accept) {      // the pass just consumed became the accepted pose: its residuals are the ones to keep
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) racc[j] = rcand[j];
+        }
         if (s_state == 2) break;
+    }
+    if (PPT > 0) {                      // residuals at the accepted pose (what Tracker.cpp:223-230 stores), kept in registers
+#pragma unroll                          // all along: the damped solver needs no extra pass to produce them
+        for (int j = 0; j < NREG; ++j) {
+            const int i = tid + j * nthr;
+            if (i < N) A.r[base + i] = racc[j];
+        }
     }
 #ifdef EDS_FUSED_STAMPS
     // diagnostic build only: cycles of lane 0 in [point loop | reduction | solver] into the pad words

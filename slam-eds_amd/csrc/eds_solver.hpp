@@ -40,6 +40,8 @@ struct Solver6 {
     double cp[3], cq[4];        // pose to evaluate next
     Sums6 cur;
     int have_cur, iter, done, failed, final_pass;
+    int skip_final;             // the caller keeps the residuals of the accepted pose itself (persistent kernel): no extra pass
+    int last_accepted;          // whether the pass just consumed became the accepted pose
     double initial_cost, final_cost;
     double xi[6];               // increment that produced the current candidate
     // trace of the solve (parity / diagnostics)
@@ -47,8 +49,9 @@ struct Solver6 {
     double tr_xi[EDS_MAX_TRACE][6], tr_cost[EDS_MAX_TRACE];
     int tr_acc[EDS_MAX_TRACE];
 
-    EDS_HD void init(int damped_, int max_iters_, double lambda0, const double* p0, const double* q0) {
+    EDS_HD void init(int damped_, int max_iters_, double lambda0, const double* p0, const double* q0, int skip_final_ = 0) {
         damped = damped_; max_iters = max_iters_; lambda = damped_ ? lambda0 : 0.0;
+        skip_final = skip_final_; last_accepted = 0;
         for (int i = 0; i < 3; ++i) p[i] = cp[i] = p0[i];
         for (int i = 0; i < 4; ++i) q[i] = cq[i] = q0[i];
         have_cur = 0; iter = 0; done = 0; failed = 0; final_pass = 0; ntrace = 0;
@@ -93,12 +96,14 @@ struct Solver6 {
         }
     }
     EDS_HD void finish() {          // one more pass at the accepted pose for the residuals (Tracker.cpp:223-230)
+        if (skip_final && damped && have_cur) { final_cost = cur.cost; done = 1; return; }   // ... unless the caller kept them
         for (int i = 0; i < 3; ++i) cp[i] = p[i];
         for (int i = 0; i < 4; ++i) cq[i] = q[i];
         final_pass = 1;
     }
     // Consumes the sums evaluated at (cp, cq).
     EDS_HD void on_eval(const Sums6& s) {
+        last_accepted = 1;          // a final pass, a Gauss-Newton pass and the first damped pass are all at the accepted pose
         if (final_pass) { final_cost = s.cost; done = 1; return; }
         if (!finite6(s)) {
             if (!have_cur) { failed = 1; done = 1; return; }
@@ -118,6 +123,7 @@ struct Solver6 {
             cur = s; have_cur = 1; initial_cost = s.cost;
         } else {
             const int ok = finite6(s) && (s.cost < cur.cost);
+            last_accepted = ok;
             record(s.cost, ok);
             ++iter;
             if (ok) {
