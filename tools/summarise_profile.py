@@ -27,13 +27,18 @@ def short(name):
     return name[:40]
 
 
-stats_csv = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    # gpurun merges results back without deleting what an earlier call left: take the latest file only
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats_csv = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 stats = {short(r["Name"]): r for r in csv.DictReader(open(stats_csv))}
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for which in ("fetch", "write"):
-    for f in glob.glob(os.path.join(src, f"pmc_{which}", "*", "*_counter_collection.csv")):
+    for f in [newest(os.path.join(src, f"pmc_{which}", "*", "*_counter_collection.csv"))]:
         for r in csv.DictReader(open(f)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
