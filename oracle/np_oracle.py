@@ -96,7 +96,8 @@ def project(al, p, q):
     return RX, P, u, v
 
 
-def residual(al, p, q, v, num_blocks=1, sampling="bicubic"):
+def residual(al, p, q, v, num_blocks=1, sampling="bicubic", nc=False):
+    """nc=True: PhotometricErrorNC.hpp:151-186 - the sampled brightness is L2-normalised per block as well."""
     A = flow_matrix(al)
     m = A @ np.asarray(v)
     nrm = np.empty(al.N)
@@ -104,11 +105,17 @@ def residual(al, p, q, v, num_blocks=1, sampling="bicubic"):
         nrm[s:s + n] = np.sqrt(S0 + np.sum(m[s:s + n] ** 2))
     _, _, u, vv = project(al, p, q)
     E = (bicubic if sampling == "bicubic" else bilinear)(al.frame, vv, u)[0]
+    if nc:
+        E = E.copy()
+        for s, n in block_ranges(al.N, num_blocks):
+            E[s:s + n] /= np.sqrt(S0 + np.sum(E[s:s + n] ** 2))
     return al.weights * (m / nrm - E)
 
 
-def jacobians(al, p, q, v, num_blocks=1, sampling="bicubic"):
-    """Closed-form r, J_local (N x 12, Ceres local coordinates) and J_se3 (N x 6)."""
+def jacobians(al, p, q, v, num_blocks=1, sampling="bicubic", nc=False):
+    """Closed-form r, J_local (N x 12, Ceres local coordinates) and J_se3 (N x 6).
+    nc=True (PhotometricErrorNC): E_i -> E_i/||E||_block, so the pose columns become
+    w_i (J'_i/||E|| - E_i sum_j E_j J'_j / ||E||^3) with J'_j = -dE_j/d(pose) (un-weighted)."""
     v = np.asarray(v, dtype=np.float64)
     A = flow_matrix(al)
     m = A @ v
@@ -132,8 +139,16 @@ def jacobians(al, p, q, v, num_blocks=1, sampling="bicubic"):
         nn = np.sqrt(S)
         Jv = Ab / nn - np.outer(mb, G @ v) / nn ** 3
         J[s:s + n, 6:12] = w[s:s + n, None] * (Jv @ proj)
-        r[s:s + n] = w[s:s + n] * (mb / nn - E[s:s + n])
-    J_se3 = np.concatenate([-w[:, None] * gP, -w[:, None] * np.cross(P, gP)], axis=1)
+        if nc:
+            Eb = E[s:s + n]
+            Jp = np.concatenate([-gP[s:s + n], -2.0 * np.cross(RX[s:s + n], gP[s:s + n])], axis=1)   # un-weighted
+            SE = S0 + np.sum(Eb ** 2)
+            nE = np.sqrt(SE)
+            J[s:s + n, 0:6] = w[s:s + n, None] * (Jp / nE - np.outer(Eb, Eb @ Jp) / nE ** 3)
+            r[s:s + n] = w[s:s + n] * (mb / nn - Eb / nE)
+        else:
+            r[s:s + n] = w[s:s + n] * (mb / nn - E[s:s + n])
+    J_se3 = np.concatenate([-w[:, None] * gP, -w[:, None] * np.cross(P, gP)], axis=1)   # plain residual only
     return r, J, J_se3
 
 
@@ -174,14 +189,14 @@ def se3_exp_matrix(xi):
     return out
 
 
-def fd_jacobian_local(al, p, q, v, num_blocks=1, h=1e-6, sampling="bicubic"):
+def fd_jacobian_local(al, p, q, v, num_blocks=1, h=1e-6, sampling="bicubic", nc=False):
     """Central finite differences of the residual in Ceres local coordinates (N x 12)."""
     J = np.zeros((al.N, 12))
     for k in range(12):
         d = np.zeros(12)
         d[k] = h
-        rp = residual(al, *state_plus(p, q, v, d), num_blocks, sampling)
-        rm = residual(al, *state_plus(p, q, v, -d), num_blocks, sampling)
+        rp = residual(al, *state_plus(p, q, v, d), num_blocks, sampling, nc)
+        rm = residual(al, *state_plus(p, q, v, -d), num_blocks, sampling, nc)
         J[:, k] = (rp - rm) / (2 * h)
     return J
 

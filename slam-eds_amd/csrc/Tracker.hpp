@@ -101,6 +101,7 @@ struct HipOptions {
     int sampling = EDS_SAMPLE_BICUBIC;
     int exec = EDS_EXEC_DEVICE;
     double huber_tau = 0.0, lambda0 = 0.01;
+    bool nc = false;                        // PhotometricErrorNC instead of PhotometricError (Tracker.cpp:25-27 toggle)
 };
 
 class Tracker {
@@ -121,7 +122,7 @@ class Tracker {
     eds_trk_cfg make_cfg() const {
         eds_trk_cfg c; eds_trk_cfg_default(&c);
         c.device = hip.device; c.solver = hip.solver; c.sampling = hip.sampling; c.exec = hip.exec;
-        c.huber_tau = hip.huber_tau; c.lambda0 = hip.lambda0;
+        c.huber_tau = hip.huber_tau; c.lambda0 = hip.lambda0; c.nc = hip.nc ? 1 : 0;
         c.num_blocks = std::max(1, config.options.num_threads);
         c.loss_type = (int)config.loss_type;
         c.loss_param = config.loss_params.empty() ? 1.0 : config.loss_params[0];

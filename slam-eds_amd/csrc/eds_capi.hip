@@ -67,6 +67,7 @@ void fill_static(const eds_trk* h, int slot) {
     pb[EDS_PB_NB] = nb;
     pb[EDS_PB_NE] = s.N / nb;
     pb[EDS_PB_N] = s.N;
+    pb[EDS_PB_NCMODE] = h->cfg.nc ? 1.0 : 0.0;
 }
 
 void fill_pose(const eds_trk* h, int slot, const double* p, const double* q, const double* v) {
@@ -106,6 +107,7 @@ int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bo
     if (rc) return rc;
     if (refresh_model && ncols == 6) eds_launch_model(A, first, count, nchunk, h->st);
     eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
+    if (ncols == 12 && h->cfg.nc) eds_launch_nc_normalise(A, first, count, effective_blocks(h), nchunk, h->st);
     if (with_reduction) {
         const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
         int cpb, nseg;
@@ -282,7 +284,7 @@ int materialise_residuals(eds_trk* h, int slot) {
 void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
-    void* dptrs[] = {h->df0x, h->df0y, h->dcell0, h->dpose, h->dG, h->dpart, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
+    void* dptrs[] = {h->df0x, h->df0y, h->dcell0, h->dpose, h->dG, h->dpart, h->dncstat, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
                      h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
@@ -401,6 +403,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_ALLOC(h->dG, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
     EDS_ALLOC(h->dpart, (size_t)batch * h->max_seg * EDS_RED_K * 8);
+    EDS_ALLOC(h->dncstat, (size_t)batch * EDS_MAX_BLOCKS * 8 * 8);
     EDS_HALLOC(h->h_pose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_HALLOC(h->h_part, (size_t)batch * h->max_seg * EDS_RED_K * 8);
     EDS_HALLOC(h->h_G, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
@@ -417,6 +420,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     hipMemsetAsync(h->dpose, 0, (size_t)batch * EDS_POSE_STRIDE * 8, h->st);
     hipMemsetAsync(h->dG, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8, h->st);
     hipMemsetAsync(h->dpart, 0, (size_t)batch * h->max_seg * EDS_RED_K * 8, h->st);
+    hipMemsetAsync(h->dncstat, 0, (size_t)batch * EDS_MAX_BLOCKS * 8 * 8, h->st);
     int rc = eds_fused_alloc(&h->fused, batch);
     if (rc != 0) { free_all(h); return fail(EDS_ERR_HIP, "fused buffers: hipMalloc failed"); }
     e = hipStreamSynchronize(h->st);
@@ -656,6 +660,7 @@ int eds_trk_eval(eds_trk* h, int slot, const double p[3], const double q[4], con
     int rc = check_slot(h, slot);
     if (rc) return rc;
     if (ncols != 6 && ncols != 12) return fail(EDS_ERR_INVALID, "ncols must be 6 or 12");
+    if (ncols == 6 && h->cfg.nc) return fail(EDS_ERR_INVALID, "the NC residual (cfg.nc) has 12-column rows only");
     if (!p || !q || !v) return fail(EDS_ERR_INVALID, "null state");
     Slot& s = h->slots[slot];
     if (!s.has_kf || !s.has_frame) return fail(EDS_ERR_STATE, "keyframe or event frame not set");
@@ -695,6 +700,8 @@ int eds_trk_eval(eds_trk* h, int slot, const double p[3], const double q[4], con
 static int solve_range(eds_trk* h, int level, int first, int count) {
     if (!h) return fail(EDS_ERR_INVALID, "null handle");
     if (first < 0 || count < 1 || first + count > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds");
+    if (h->cfg.nc && h->cfg.solver != EDS_SOLVER_REF12)
+        return fail(EDS_ERR_INVALID, "the NC residual (cfg.nc) is defined for EDS_SOLVER_REF12 only");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     if (h->cfg.exec == EDS_EXEC_DEVICE) return eds_fused_solve(h, level, first, count);
     return solve_host(h, level, first, count);
@@ -827,6 +834,7 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     if (!h || !mean_ms) return fail(EDS_ERR_INVALID, "null argument");
     if (first < 0 || count < 1 || first + count > h->B || reps < 1) return fail(EDS_ERR_INVALID, "bad range");
     if (ncols != 6 && ncols != 12) return fail(EDS_ERR_INVALID, "ncols must be 6 or 12");
+    if (ncols == 6 && h->cfg.nc) return fail(EDS_ERR_INVALID, "the NC residual (cfg.nc) has 12-column rows only");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     for (int s = first; s < first + count; ++s) {
         const Slot& sl = h->slots[s];

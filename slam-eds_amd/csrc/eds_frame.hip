@@ -99,10 +99,10 @@ __global__ void k_sumsq(const double* __restrict__ src, size_t n, double* __rest
 }
 // frame / ||frame||_F -> fp32 in the handle's layout (padded with replicated borders, optionally 4x4-tiled)
 __global__ void k_store(const double* __restrict__ src, const double* __restrict__ sumsq, float* __restrict__ dst, int H, int W,
-                        int Hp, int Wp, int tiled) {
+                        int Hp, int Wp, int tiled, int normalise) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= Wp) return;
-    const double inv = 1.0 / sqrt(*sumsq);
+    const double inv = normalise ? 1.0 / sqrt(*sumsq) : 1.0;     // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
     const double v = src[(size_t)min(r, H - 1) * W + min(c, W - 1)] * inv;
     const size_t o = tiled ? ((size_t)((r >> 2) * (Wp >> 2) + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * Wp + c);
     dst[o] = (float)v;
@@ -178,7 +178,8 @@ int eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, cons
     }
     hipLaunchKernelGGL(k_sumsq, dim3(256), dim3(256), 0, st, cur, n, fb.d_norm);
     const dim3 g3((h->Wp + 255) / 256, h->Hp);
-    hipLaunchKernelGGL(k_store, g3, b2, 0, st, cur, fb.d_norm, h->dframe + (size_t)slot * h->Hp * h->Wp, H, W, h->Hp, h->Wp, h->tiled);
+    hipLaunchKernelGGL(k_store, g3, b2, 0, st, cur, fb.d_norm, h->dframe + (size_t)slot * h->Hp * h->Wp, H, W, h->Hp, h->Wp, h->tiled,
+                       h->cfg.nc ? 0 : 1);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     double ss = 0.0;

@@ -332,8 +332,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         // host-driven loop has the lower latency (0.41 ms vs 0.74 ms for one 2 000-point solve).
         const char* force = getenv("EDS_REF12_EXEC");                // tuning knob: "device" | "host"
         const bool want_device = force ? (std::strcmp(force, "device") == 0) : (count >= 32);
-        if (want_device && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
-        return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks or > 2048 points
+        if (want_device && !h->cfg.nc && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
+        return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks, > 2048 points, NC residual
     }
     EdsFusedBuffers& fb = h->fused;
     if (fb.pending_count > 0) return eds_internal_fail(EDS_ERR_STATE, "previous batch not collected: call eds_trk_sync first");

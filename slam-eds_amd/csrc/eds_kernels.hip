@@ -134,13 +134,19 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
 #pragma unroll
         for (int k = 0; k < 6; ++k) m += a[k] * (float)pb[EDS_PB_V + k];
         const float inv_n = (float)bk[0];
-        A.r[o] = w * (m * inv_n - pp.E);
-        Jo[0 * plane] = -w * pp.g0;
-        Jo[1 * plane] = -w * pp.g1;
-        Jo[2 * plane] = -w * pp.g2;
+        // PhotometricErrorNC: the sampled brightness is divided by its block norm too, which is only known after
+        // this pass.  Emit the un-normalised pieces (model part in r, E in the mhat plane - unused by the 12-column
+        // path -, pose columns of -E without the weight); eds_nc_fix_kernel finishes them.
+        const bool ncm = pb[EDS_PB_NCMODE] != 0.0;
+        const float wp = ncm ? 1.0f : w;
+        if (ncm) { A.r[o] = m * inv_n; A.mhat[o] = pp.E; }
+        else A.r[o] = w * (m * inv_n - pp.E);
+        Jo[0 * plane] = -wp * pp.g0;
+        Jo[1 * plane] = -wp * pp.g1;
+        Jo[2 * plane] = -wp * pp.g2;
         // quaternion local: -2 w (R X) x gradE_P, with R X = P - t
         const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
-        const float w2 = -2.0f * w;
+        const float w2 = -2.0f * wp;
         Jo[3 * plane] = w2 * (ry * pp.g2 - rz * pp.g1);
         Jo[4 * plane] = w2 * (rz * pp.g0 - rx * pp.g2);
         Jo[5 * plane] = w2 * (rx * pp.g1 - ry * pp.g0);
@@ -156,6 +162,64 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
             Jo[(6 + c) * plane] = s;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// PhotometricErrorNC (reference PhotometricErrorNC.hpp:151-186): r_i = w_i (m_i/||m|| - E_i/||E||) with
+// ||E||^2 = 1e-3 + sum_j E_j^2 over the residual block.  With J'_j = -dE_j/d(local pose) from the pass above,
+//   d(-E_i/||E||) = J'_i/||E|| - E_i (sum_j E_j J'_j)/||E||^3.
+// Step 1: one workgroup per (slot, block) forms 1/||E|| and c = sum_j E_j J'_j / ||E||^3 in fp64.
+__global__ __launch_bounds__(EDS_TPB) void eds_nc_stat_kernel(EdsArrays A, int first, int count, int nb_grid) {
+    int slot, k;
+    if (!decode_wg(first, count, nb_grid, slot, k)) return;
+    const double* pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N], nb = (int)pb[EDS_PB_NB], ne = (int)pb[EDS_PB_NE];
+    if (k >= nb) return;
+    const int start = k * ne;
+    const int n = ne + ((k + 1 == nb) ? (N - (k + 1) * ne) : 0);
+    const size_t plane = (size_t)A.B * A.Np;
+    double acc[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = 0.0;
+    for (int i = threadIdx.x; i < n; i += EDS_TPB) {
+        const size_t o = (size_t)slot * A.Np + start + i;
+        const double E = (double)A.mhat[o];
+        acc[0] += E * E;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc[1 + c] += E * (double)A.J[o + c * plane];
+    }
+    __shared__ double sh[EDS_TPB][7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sh[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    for (int s = EDS_TPB / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int i = 0; i < 7; ++i) sh[threadIdx.x][i] += sh[threadIdx.x + s][i];
+        __syncthreads();
+    }
+    if (threadIdx.x < 7) {
+        double* out = A.ncstat + ((size_t)slot * EDS_MAX_BLOCKS + k) * 8;
+        const double S = 1e-3 + sh[0][0];                        // meas_norm_sq starts at 1e-3 (PhotometricErrorNC.hpp:151)
+        const double inv = 1.0 / sqrt(S);
+        out[threadIdx.x] = threadIdx.x == 0 ? inv : sh[0][threadIdx.x] * inv / S;
+    }
+}
+
+// Step 2: per point, r = w (m/||m|| - E/||E||) and pose columns w (J'/||E|| - E c).
+__global__ __launch_bounds__(EDS_TPB) void eds_nc_fix_kernel(EdsArrays A, int first, int count, int nchunk) {
+    int slot, chunk;
+    if (!decode_wg(first, count, nchunk, slot, chunk)) return;
+    const double* __restrict__ pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
+    const int N = (int)pb[EDS_PB_N], nb = (int)pb[EDS_PB_NB], ne = (int)pb[EDS_PB_NE];
+    const int i = chunk * EDS_TPB + threadIdx.x;
+    if (i >= N) return;
+    const size_t o = (size_t)slot * A.Np + i;
+    const size_t plane = (size_t)A.B * A.Np;
+    const double* __restrict__ st = A.ncstat + ((size_t)slot * EDS_MAX_BLOCKS + block_of(i, ne, nb)) * 8;
+    const float inv = (float)st[0], w = A.w[o], E = A.mhat[o];
+    A.r[o] = w * (A.r[o] - E * inv);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) A.J[o + c * plane] = w * (A.J[o + c * plane] * inv - E * (float)st[1 + c]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -230,6 +294,10 @@ void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, i
     else if (sampling == 0) hipLaunchKernelGGL((eds_resjac_kernel<0, 12>), g, b, 0, st, A, first, count, nchunk);
     else if (ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<1, 6>), g, b, 0, st, A, first, count, nchunk);
     else hipLaunchKernelGGL((eds_resjac_kernel<1, 12>), g, b, 0, st, A, first, count, nchunk);
+}
+void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, int nchunk, hipStream_t st) {
+    hipLaunchKernelGGL(eds_nc_stat_kernel, dim3(grid_for(count, nb)), dim3(EDS_TPB), 0, st, A, first, count, nb);
+    hipLaunchKernelGGL(eds_nc_fix_kernel, dim3(grid_for(count, nchunk)), dim3(EDS_TPB), 0, st, A, first, count, nchunk);
 }
 void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st) {
     const dim3 g(grid_for(count, nseg)), b(EDS_TPB);

@@ -19,6 +19,7 @@ struct EdsArrays {
     float* r;            // [B][Np]
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
+    double* ncstat;      // [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC block statistics (eds_layout.hpp)
     int B, Np, H, W, max_seg;
     int Hp, Wp, tiled;   // frame allocation: padded to multiples of 4; 4x4-tiled or row-major (eds_device.hpp FrameView)
 };
@@ -26,4 +27,7 @@ struct EdsArrays {
 void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st);
 void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st);
 void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, int count, int nchunk, hipStream_t st);
+// PhotometricErrorNC (reference PhotometricErrorNC.hpp:124-192): block statistics of the sampled brightness, then the
+// per-point correction of r and of the pose columns; between the residual/Jacobian pass and the reduction
+void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, int nchunk, hipStream_t st);
 void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st);

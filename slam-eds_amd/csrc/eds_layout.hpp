@@ -19,6 +19,7 @@
 //   G       f64 [B][EDS_MAX_BLOCKS][36]  A^T A of each residual block (constant per keyframe;
 //                         gives ||m||^2 = v^T G v + 1e-3 and A^T m = G v in O(1))
 //   part    f64 [B][nseg][EDS_RED_K]  per-workgroup partial sums of the reduction kernel
+//   ncstat  f64 [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC only: per block 1/||E||, then sum_j E_j J'_j (6) / ||E||^3
 #pragma once
 #include <stdint.h>
 
@@ -37,6 +38,7 @@
 #define EDS_PB_NB 27               // 1   number of residual blocks
 #define EDS_PB_NE 28               // 1   points per block (N / nb, Tracker.cpp:178)
 #define EDS_PB_N 29                // 1   number of points
+#define EDS_PB_NCMODE 30           // 1   1 = PhotometricErrorNC residual: sampled brightness L2-normalised per block too
 #define EDS_PB_PV 32               // 36  d(unit-norm plus)/d delta = (I - v v^T/|v|^2)/|v|  (PhotometricError.hpp:32-54)
 #define EDS_PB_BLK 68              // 8 per block: inv_n, gvec[6] = G v / n^3, S
 #define EDS_PB_BLK_STRIDE 8

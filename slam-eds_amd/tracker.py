@@ -42,6 +42,7 @@ class Config:
     sampling: int = capi.SAMPLE_BICUBIC
     exec: int = capi.EXEC_DEVICE
     huber_tau: float = 0.0
+    nc: bool = False                         # PhotometricErrorNC instead of PhotometricError (Tracker.cpp:25-27 toggle)
     lambda0: float = 0.01
     device: int = 0
 
@@ -157,7 +158,7 @@ class Tracker:
         return capi.default_config(device=c.device, sampling=c.sampling, solver=c.solver, exec=c.exec,
                                    num_blocks=max(1, int(o.num_threads)), loss_type=int(c.loss_type),
                                    loss_param=float(c.loss_params[0]) if c.loss_params else 1.0,
-                                   huber_tau=float(c.huber_tau), lambda0=float(c.lambda0),
+                                   huber_tau=float(c.huber_tau), lambda0=float(c.lambda0), nc=int(bool(c.nc)),
                                    num_levels=len(o.max_num_iterations), max_num_iterations=list(o.max_num_iterations),
                                    function_tolerance=float(o.function_tolerance))
 

@@ -108,3 +108,18 @@ def test_build_event_frame_edge_cases(gpu, capi):
     with pytest.raises(capi.EdsError):
         h.set_undistort_map(np.zeros((3, 3), np.float32), np.zeros((3, 3), np.float32))
     h.close()
+
+
+@pytest.mark.gpu
+def test_build_event_frame_unnormalised_for_nc(gpu, capi):
+    """With the NC residual selected the frame is stored as accumulated (EventFrame.cpp:278-281); the norm is still reported."""
+    import np_frame_oracle as fo
+    H, W = 60, 80
+    x, y, pol, _, _ = make_events(9, 2000, H, W, distort=False)
+    ref, ref_norm = fo.event_frame(x, y, pol, H, W)
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_REF12, nc=1), 1, 64, H, W)
+    norm = h.build_event_frame(0, x, y, pol)
+    got = h.get_event_frame(0)
+    assert norm == pytest.approx(ref_norm, rel=1e-12)
+    assert np.abs(got - ref * ref_norm).max() <= 1e-7 * np.abs(ref * ref_norm).max()
+    h.close()

@@ -112,6 +112,30 @@ def test_jacobians_vs_finite_differences(npo, al):
     assert (np.median(np.abs(Jfd - J), axis=0) <= 1e-7 * np.maximum(scale, 1)).all()
 
 
+@pytest.mark.parametrize("nb", [1, 3])
+def test_nc_residual_autodiff_vs_closed_form_vs_finite_differences(po, npo, synth, al, nb):
+    """PhotometricErrorNC (PhotometricErrorNC.hpp:124-192): the frame is NOT normalised and the sampled
+    brightness is divided by its own per-block norm (1e-3 offset like the model's)."""
+    raw = type(al)(**{**al.__dict__, "frame": al.frame * 37.5})
+    p, q = _pose(ang=0.01, t=0.004)
+    v = al.v_true + 0.1 * np.random.default_rng(2).standard_normal(6)
+    v /= np.linalg.norm(v)
+    e = po.Oracle(raw, num_blocks=nb, nc=True).eval12(p, q, v)
+    r, J, _ = npo.jacobians(raw, p, q, v, nb, nc=True)
+    assert np.abs(e["r_raw"] - r).max() < 1e-13
+    assert np.abs(e["J_local_raw"] - J).max() < 1e-9
+    assert np.abs(npo.residual(raw, p, q, v, nb, nc=True) - r).max() < 1e-14
+    Jfd = npo.fd_jacobian_local(raw, p, q, v, nb, h=1e-6, nc=True)
+    scale = np.maximum(np.abs(J).max(axis=0), 1)
+    assert (np.quantile(np.abs(Jfd - J), 0.95, axis=0) <= 1e-6 * scale).all()
+    # for the plain residual the scale of the frame matters, for NC it does not (up to the 1e-3 offsets)
+    e2 = po.Oracle(type(al)(**{**al.__dict__, "frame": al.frame * 375.0}), num_blocks=nb, nc=True).eval12(p, q, v)
+    assert np.abs(e2["r_raw"] - r).max() < 1e-4 * np.abs(r).max()
+    # and the solve runs to a usable solution
+    s = po.Oracle(raw, num_blocks=nb, nc=True, max_num_iterations=10).solve_lm(al.p0, al.q0, al.v_true)
+    assert s["usable"] and s["final_cost"] < s["initial_cost"]
+
+
 def test_block_partition_matches_reference_rule(po, npo, synth):
     # Tracker.cpp:178-195: N / T per block, remainder to the LAST block; N < T leaves leading blocks empty
     assert npo.block_ranges(10, 3) == [(0, 3), (3, 3), (6, 4)]

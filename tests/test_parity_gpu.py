@@ -431,3 +431,54 @@ def test_reference_problem_batched_on_device(gpu, capi, synth, po):
         er = po.Oracle(a, num_blocks=2).eval12(table[b, 0:3], table[b, 3:7], table[b, 7:13], jac=False)["r_raw"]
         assert np.abs(r - er).max() <= TOL_R * np.abs(er).max()
     hb.close()
+
+
+# ---------------------------------------------------------------------------------------
+def _raw_frame(al, scale=37.5):
+    """PhotometricErrorNC takes the event frame un-normalised (EventFrame.cpp:278-281)."""
+    return type(al)(**{**al.__dict__, "frame": al.frame * scale})
+
+
+@pytest.mark.parametrize("sampling", [0, 1], ids=["bicubic", "bilinear"])
+@pytest.mark.parametrize("nb", [1, 5])
+def test_nc_residual_vs_oracle(gpu, capi, synth, po, sampling, nb):
+    """Second residual mode of the reference (PhotometricErrorNC.hpp:124-192): brightness normalised per block too."""
+    al = _raw_frame(synth.make_alignment(812, H=240, W=320, N=1203))
+    p, q = eval_pose(synth)
+    v = al.v_true
+    e = po.Oracle(al, sampling=sampling, num_blocks=nb, nc=True).eval12(p, q, v)
+    h = make_handle(capi, al, sampling=sampling, num_blocks=nb, nc=1, solver=capi.SOLVER_REF12, exec=capi.EXEC_HOST)
+    g = h.eval(0, p, q, v, ncols=12)
+    J = e["J_local_raw"]
+    assert np.abs(g["r"] - e["r_raw"]).max() <= TOL_R * np.abs(e["r_raw"]).max()
+    assert rel(g["J"], J) <= TOL_J
+    assert rel(g["JtJ"], J.T @ J) <= TOL_H and rel(g["Jtr"], J.T @ e["r_raw"]) <= TOL_H
+    # it really is a different residual from the plain one on the same (raw) frame
+    plain = po.Oracle(al, sampling=sampling, num_blocks=nb).eval12(p, q, v)
+    assert np.abs(plain["r_raw"] - e["r_raw"]).max() > 100 * TOL_R * np.abs(e["r_raw"]).max()
+    with pytest.raises(capi.EdsError):
+        h.eval(0, p, q, v, ncols=6)                      # the NC functor has 12-column rows only
+    h.close()
+
+
+@pytest.mark.parametrize("ex", [0, 1], ids=["host", "device"])
+@pytest.mark.parametrize("nb,loss", [(1, 0), (4, 1)])
+def test_nc_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
+    al = _raw_frame(synth.make_alignment(4322, H=240, W=320, N=1500))
+    ref = po.Oracle(al, num_blocks=nb, nc=True, loss_type=loss, loss_param=0.2, max_num_iterations=6).solve_lm(al.p0, al.q0, al.v_true)   # 6: ends on the cap, not on a tolerance
+    # (a tolerance exit one iteration apart between fp32 and fp64 sums is legitimate and would make the counts differ)
+    h = make_handle(capi, al, exec=ex, solver=capi.SOLVER_REF12, num_blocks=nb, nc=1, loss_type=loss, loss_param=0.2,
+                    max_num_iterations=6)
+    p, q, v, info = h.optimize(0, v=al.v_true)           # exec=device routes NC solves to the host-driven loop (documented)
+    assert info["success"] and ref["usable"]
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
+    assert np.abs(v - ref["v"]).max() <= 1e-4
+    assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
+    assert info["initial_cost"] == pytest.approx(ref["initial_cost"], rel=1e-5)
+    assert info["final_cost"] == pytest.approx(ref["final_cost"], rel=1e-4)
+    er = po.Oracle(al, num_blocks=nb, nc=True).eval12(p, q, v)["r_raw"]
+    assert np.abs(h.residuals(0) - er).max() <= 10 * TOL_R * np.abs(er).max()      # kf->residuals at the solution
+    h.set_config(capi.default_config(solver=capi.SOLVER_LM6, nc=1))
+    with pytest.raises(capi.EdsError):
+        h.optimize(0)                                    # pose-only solvers have no NC form
+    h.close()
