@@ -213,6 +213,33 @@ int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, doubl
 int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* coord_xy, double* tracks_xy,
                           int32_t* kept_index, int* n_kept, double* mean_sq_flow);
 
+/* ---- keyframe point set-up on the device -------------------------------------------- */
+enum eds_kf_method { EDS_KF_MAX = 0, EDS_KF_MEDIAN = 1 };   /* eds::tracking::CANDIDATE_POINT_METHOD */
+enum eds_img_type { EDS_IMG_U8 = 0, EDS_IMG_F32 = 1, EDS_IMG_F64 = 2 };
+typedef struct eds_kf_select {
+    int32_t method;                 /* EDS_KF_MAX: num_points / n_cells strongest gradients per cell; EDS_KF_MEDIAN: every
+                                     * pixel above its cell's median (KeyFrame::candidatePoints, KeyFrame.cpp:740-823) */
+    int32_t cell;                   /* cell edge in pixels; the reference uses cv::Size(20, 20) (KeyFrame.cpp:408); <= 32 */
+    int32_t num_points;             /* MAX only: the reference passes rows*cols*percent_points/100 (KeyFrame.cpp:406-409) */
+    int32_t reserved;
+    double  min_depth, max_depth;   /* without a depth map every point starts at idp = 1/((max-min)/2) (KeyFrame.cpp:1186-1192) */
+    double  weight_threshold;       /* KeyFrame::cleanPoints(0.7) (KeyFrame.cpp:451,1566-1587) */
+} eds_kf_select;
+void eds_kf_select_default(eds_kf_select* sel);
+/* Replaces the tracker-facing part of KeyFrame::create (reference src/tracking/KeyFrame.cpp:333-463): grayscale image
+ * (H x W of the handle, row-major, already undistorted) -> [0,1] -> log(img + 0.2) -> Sobel 3x3 -> gradient magnitude ->
+ * per-cell point selection -> norm_coord, grad -> nearest depth-map point (n_depth points depth_xy (n x 2, pixels) with
+ * inverse depth depth_idp; n_depth = 0: constant initial depth) -> weights -> cleanPoints.  The surviving points go
+ * straight into slot `slot` as by eds_trk_set_keyframe (same order as the reference pushes them); *n_points receives
+ * their number (also when it exceeds the handle's max_points, which is an error). */
+int eds_trk_build_keyframe(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
+                           const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy,
+                           int* n_points);
+/* The index-aligned vectors KeyFrame keeps (coord, norm_coord, grad, inv_depth, weights; KeyFrame.hpp:80-96) of the
+ * keyframe eds_trk_build_keyframe built last; any pointer may be NULL. */
+int eds_trk_get_keyframe_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp,
+                                double* weights);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
 int eds_trk_timer_start(eds_trk* h);

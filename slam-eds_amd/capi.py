@@ -23,6 +23,8 @@ SOLVER_GN6, SOLVER_LM6, SOLVER_REF12 = 0, 1, 2
 EXEC_HOST, EXEC_DEVICE = 0, 1
 LOSS_NONE, LOSS_HUBER, LOSS_CAUCHY = 0, 1, 2
 LP_CONSTANT, LP_MAD, LP_STD = 0, 1, 2
+KF_MAX, KF_MEDIAN = 0, 1
+IMG_U8, IMG_F32, IMG_F64 = 0, 1, 2
 MAX_LEVELS = 8
 
 # every symbol include/eds_hip.h declares (tests check the .so exports all of them)
@@ -36,12 +38,19 @@ EXPORTS = (
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
     "eds_trk_loss_param_batch", "eds_trk_update_points",
+    "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
 )
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
+
+
+class KfSelect(C.Structure):
+    """``eds_kf_select`` — the arguments of KeyFrame::create that steer the point set-up (KeyFrame.cpp:333-341)."""
+    _fields_ = [("method", C.c_int32), ("cell", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32),
+                ("min_depth", C.c_double), ("max_depth", C.c_double), ("weight_threshold", C.c_double)]
 
 
 class Cfg(C.Structure):
@@ -124,6 +133,11 @@ def lib():
         L.eds_trk_loss_param.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         L.eds_trk_loss_param_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         L.eds_trk_update_points.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp]
+        L.eds_kf_select_default.argtypes = [C.POINTER(KfSelect)]
+        L.eds_kf_select_default.restype = None
+        L.eds_trk_build_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(KfSelect), C.c_int, _dp, _dp,
+                                             C.c_double, C.c_double, C.c_double, C.c_double, _ip]
+        L.eds_trk_get_keyframe_points.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
@@ -345,6 +359,38 @@ class Handle:
                                            kept.ctypes.data_as(_ip), C.cast(C.byref(n), _ip), C.cast(C.byref(flow), _dp)))
         self._N[slot] = n.value
         return dict(coord=coord[:n.value], tracks=tracks[:n.value], kept=kept[:n.value], mean_sq_flow=flow.value)
+
+    # -- keyframe set-up on the device ------------------------------------------------------
+    def build_keyframe(self, slot, img, K, method=KF_MEDIAN, num_points=0, cell=20, depth_xy=None, depth_idp=None,
+                       min_depth=1.0, max_depth=3.0, weight_threshold=0.7):
+        """KeyFrame::create's tracker-facing part on the device; returns dict(coord, norm_coord, grad, idp, weights)."""
+        img = np.ascontiguousarray(img)
+        if img.shape != (self.H, self.W):
+            raise EdsError(ERR_INVALID, f"image must be {self.H} x {self.W}")
+        if img.dtype == np.uint8:
+            ty = IMG_U8
+        elif img.dtype == np.float32:
+            ty = IMG_F32
+        else:
+            ty, img = IMG_F64, np.ascontiguousarray(img, dtype=np.float64)
+        sel = KfSelect()
+        lib().eds_kf_select_default(C.byref(sel))
+        sel.method, sel.cell, sel.num_points = int(method), int(cell), int(num_points)
+        sel.min_depth, sel.max_depth, sel.weight_threshold = float(min_depth), float(max_depth), float(weight_threshold)
+        nd = 0 if depth_xy is None else len(depth_xy)
+        dxy = _f64(depth_xy) if nd else None
+        didp = _f64(depth_idp) if nd else None
+        n = C.c_int32(0)
+        fx, fy, cx, cy = [float(k) for k in K]
+        _check(lib().eds_trk_build_keyframe(self._h, slot, ty, img.ctypes.data_as(C.c_void_p), C.byref(sel), nd,
+                                            _p(dxy) if nd else None, _p(didp) if nd else None, fx, fy, cx, cy,
+                                            C.cast(C.byref(n), _ip)))
+        N = n.value
+        self._N[slot] = N
+        out = dict(coord=np.zeros((N, 2)), norm_coord=np.zeros((N, 2)), grad=np.zeros((N, 2)), idp=np.zeros(N), weights=np.zeros(N))
+        _check(lib().eds_trk_get_keyframe_points(self._h, slot, _p(out["coord"]), _p(out["norm_coord"]), _p(out["grad"]),
+                                                 _p(out["idp"]), _p(out["weights"])))
+        return out
 
     # -- measurement ---------------------------------------------------------------------
     def timer_start(self):

@@ -290,6 +290,7 @@ void free_all(eds_trk* h) {
     eds_fused_free(&h->fused);
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
+    eds_keyframe_free(&h->kf_build);
     void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -900,4 +901,34 @@ int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* c
     return EDS_OK;
 }
 
+/* ---- keyframe point set-up on the device ------------------------------------------ */
+void eds_kf_select_default(eds_kf_select* sel) {
+    if (!sel) return;
+    std::memset(sel, 0, sizeof(*sel));
+    sel->method = EDS_KF_MEDIAN;            // KeyFrame::create falls back to MEDIAN without a point target (KeyFrame.cpp:410-411)
+    sel->cell = 20;                          // cv::Size(20, 20)  (KeyFrame.cpp:408)
+    sel->num_points = 0;
+    sel->min_depth = 1.0; sel->max_depth = 3.0;
+    sel->weight_threshold = 0.7;             // cleanPoints(0.7)  (KeyFrame.cpp:451)
+}
+
+int eds_trk_build_keyframe(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
+                           const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!img || !sel) return fail(EDS_ERR_INVALID, "null image or selection parameters");
+    if (n_depth < 0) return fail(EDS_ERR_INVALID, "negative depth-map size");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_keyframe_build(h, slot, img_type, img, sel, n_depth, depth_xy, depth_idp, fx, fy, cx, cy, n_points);
+}
+
+int eds_trk_get_keyframe_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp, double* weights) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_keyframe_get_points(h, slot, coord_xy, norm_xy, grad_xy, idp, weights);
+}
+
 }  // extern "C"
+
+int eds_internal_refresh_gram(eds_trk* h, int slot) { return refresh_gram(h, slot); }

@@ -72,6 +72,23 @@ int  eds_points_loss_param(eds_trk* h, int first, int count, int method, double*
 int  eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, double* tracks_xy, int32_t* kept_index, int* n_kept,
                        double* mean_sq_flow);
 
+// ---- keyframe point set-up on device (eds_keyframe.hip) ------------------------------------------------------
+struct eds_kf_select;
+struct EdsKeyframeBuffers {
+    void* d_raw = nullptr;                                                   // the image as handed over (u8 / f32 / f64)
+    double *d_log = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_mag = nullptr, *d_partial = nullptr;
+    int *d_cand = nullptr, *d_cnt = nullptr, *d_off = nullptr, *d_summary = nullptr;
+    double *d_coord = nullptr, *d_grad = nullptr, *d_idp = nullptr, *d_w = nullptr;   // candidates, then the cleaned points (in place)
+    double *d_dxy = nullptr, *d_didp = nullptr;                              // depth map
+    int cap_depth = 0, last_slot = -1, last_N = 0, last_candidates = 0;
+    double K[4] = {0, 0, 0, 0};
+};
+void eds_keyframe_free(EdsKeyframeBuffers* kb);
+int  eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
+                        const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points);
+int  eds_keyframe_get_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp, double* weights);
+
 // defined in eds_capi.hip
+int eds_internal_refresh_gram(eds_trk* h, int slot);
 int eds_internal_fail(int code, const char* msg);
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count);

@@ -40,6 +40,7 @@ struct eds_trk {
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
     EdsPointBuffers point_ops;
+    EdsKeyframeBuffers kf_build;
     // pinned host staging
     double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr;
     float *h_f32 = nullptr, *h_r = nullptr;

@@ -1,0 +1,414 @@
+// Keyframe point set-up on the device for gfx950.
+//
+// What the reference does once per keyframe on the CPU with OpenCV (KeyFrame::create, KeyFrame.cpp:333-463):
+//   image -> [0,1] -> log(img + 0.2)                          :363-374
+//   Sobel 3x3 in x and y, gradient magnitude                  :384-401
+//   candidatePoints: 20x20 cells; MAX = k strongest per cell, MEDIAN = everything above the cell median   :740-823
+//   norm_coord = (coord - c)/f, grad = Sobel at the pixel     :413-430
+//   setDepthMap: nearest depth-map point -> idp, distance -> weight in [0,1]     :1137-1198
+//   cleanPoints(0.7): drop weight < 0.7, order preserved      :1566-1587
+// Here: all of it in fp64 on the GPU, ending directly in the slot's SoA planes (no N x 6 upload), with the
+// index-aligned fp64 arrays kept for the caller's KeyFrame container (eds_trk_get_keyframe_points).
+//
+// Bandwidth-shaped, integer/selection work — no MFMA.  Selection per cell is rank-by-counting in LDS (a 400-element
+// cell needs 160 k comparisons; 768 cells per VGA image), which reproduces cv::minMaxLoc's first-in-row-major tie
+// rule and std::nth_element's order statistic without sorting.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "eds_handle.hpp"
+
+#pragma clang fp contract(off)      // sums are formed exactly as written (the oracle states the same association)
+
+namespace {
+
+constexpr int KF_T = 256;
+constexpr int KF_MAX_CELL = 32;                     // cell^2 <= 1024 magnitudes in LDS
+constexpr double KF_LOG_EPS = (double)0.2f;         // `static constexpr float log_eps = 0.2` (KeyFrame.hpp:54)
+
+__device__ __forceinline__ double load_px(const void* img, int type, size_t i) {
+    if (type == 0) return (double)static_cast<const uint8_t*>(img)[i];
+    if (type == 1) return (double)static_cast<const float*>(img)[i];
+    return static_cast<const double*>(img)[i];
+}
+
+// block-level min / max; result valid on thread 0
+__device__ __forceinline__ void block_minmax(double& mn, double& mx) {
+    __shared__ double s_mn[KF_T], s_mx[KF_T];
+    s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = KF_T / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_mn[threadIdx.x] = fmin(s_mn[threadIdx.x], s_mn[threadIdx.x + s]);
+            s_mx[threadIdx.x] = fmax(s_mx[threadIdx.x], s_mx[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    mn = s_mn[0]; mx = s_mx[0];
+    __syncthreads();
+}
+
+// partial[2 b], partial[2 b + 1] = min, max over block b's grid-stride share  (cv::minMaxLoc, KeyFrame.cpp:365)
+__global__ __launch_bounds__(KF_T) void k_minmax(const void* img, int type, size_t n, double* partial) {
+    double mn = INFINITY, mx = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * KF_T + threadIdx.x; i < n; i += (size_t)gridDim.x * KF_T) {
+        const double v = load_px(img, type, i);
+        mn = fmin(mn, v); mx = fmax(mx, v);
+    }
+    block_minmax(mn, mx);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = mn; partial[2 * blockIdx.x + 1] = mx; }
+}
+
+__device__ __forceinline__ void final_minmax(const double* partial, int nblocks, double& mn, double& mx) {
+    mn = INFINITY; mx = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += KF_T) { mn = fmin(mn, partial[2 * b]); mx = fmax(mx, partial[2 * b + 1]); }
+    block_minmax(mn, mx);
+}
+
+// L = log((img - min)/(max - min) + log_eps)   (KeyFrame.cpp:366,373-374)
+__global__ __launch_bounds__(KF_T) void k_log(const void* img, int type, size_t n, const double* partial, int nblocks, double* L) {
+    double mn, mx;
+    final_minmax(partial, nblocks, mn, mx);
+    const double range = mx - mn;
+    for (size_t i = (size_t)blockIdx.x * KF_T + threadIdx.x; i < n; i += (size_t)gridDim.x * KF_T)
+        L[i] = log((load_px(img, type, i) - mn) / range + KF_LOG_EPS);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// cv::Sobel(L, CV_64F, 1, 0, 3) / (0, 1, 3), BORDER_REFLECT_101, and cv::cartToPolar's magnitude  (KeyFrame.cpp:384-401)
+__global__ __launch_bounds__(KF_T) void k_sobel(const double* __restrict__ L, int H, int W, double* __restrict__ gx,
+                                                double* __restrict__ gy, double* __restrict__ mag) {
+    const int c = blockIdx.x * KF_T + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    const int r0 = reflect101(r - 1, H), r2 = reflect101(r + 1, H), c0 = reflect101(c - 1, W), c2 = reflect101(c + 1, W);
+    const double* t = L + (size_t)r0 * W; const double* m = L + (size_t)r * W; const double* b = L + (size_t)r2 * W;
+    const double x = ((t[c2] - t[c0]) + 2.0 * (m[c2] - m[c0])) + (b[c2] - b[c0]);
+    const double y = ((b[c0] - t[c0]) + 2.0 * (b[c] - t[c])) + (b[c2] - t[c2]);
+    const size_t o = (size_t)r * W + c;
+    gx[o] = x; gy[o] = y; mag[o] = sqrt(x * x + y * y);
+}
+
+// One workgroup per cell.  cand[cellid][pos] = local index (row-major inside the cell) in the reference's push order.
+__global__ __launch_bounds__(KF_T) void k_select(const double* __restrict__ mag, int W, int cell, int ncx, int method, int k_per_cell,
+                                                 int* __restrict__ cand, int* __restrict__ cnt) {
+    __shared__ double v[KF_MAX_CELL * KF_MAX_CELL];
+    __shared__ double s_med;
+    __shared__ int s_const, s_count;
+    const int n2 = cell * cell;
+    const int cy = blockIdx.x / ncx, cx = blockIdx.x - cy * ncx;
+    const int x0 = cx * cell, y0 = cy * cell;
+    for (int i = threadIdx.x; i < n2; i += KF_T) v[i] = mag[(size_t)(y0 + i / cell) * W + x0 + i % cell];
+    if (threadIdx.x == 0) { s_count = 0; s_const = 0; s_med = 0.0; }
+    __syncthreads();
+    int* out = cand + (size_t)blockIdx.x * n2;
+    constexpr int PER = KF_MAX_CELL * KF_MAX_CELL / KF_T;
+    int desc[PER], asc[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int i = threadIdx.x + e * KF_T;
+        desc[e] = asc[e] = 0;
+        if (i >= n2) continue;
+        const double vi = v[i];
+        int gt = 0, lt = 0, eqb = 0;
+        for (int j = 0; j < n2; ++j) {
+            const double vj = v[j];
+            gt += vj > vi; lt += vj < vi; eqb += (vj == vi) & (j < i);
+        }
+        desc[e] = gt + eqb; asc[e] = lt + eqb;
+        if (method == 1 && asc[e] == n2 / 2) s_med = vi;                       // nth_element(size / 2)  (Utils.cpp:497-498)
+        if (method == 0 && desc[e] == 0 && lt == 0) s_const = 1;               // max == min: nothing to pick (:784)
+    }
+    __syncthreads();
+    if (method == 1) {                       // MEDIAN: every magnitude above the cell median, row-major order (:797-817)
+        const double med = s_med;
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * KF_T;
+            if (i >= n2 || !(v[i] > med)) continue;
+            int pos = 0;
+            for (int j = 0; j < i; ++j) pos += v[j] > med;
+            out[pos] = i;
+            atomicAdd(&s_count, 1);
+        }
+    } else {                                 // MAX: k times arg-max-and-zero; stops once the rest is flat (:768-793)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int i = threadIdx.x + e * KF_T;
+            if (i >= n2) continue;
+            if (!s_const && desc[e] < k_per_cell && v[i] > 0.0) { out[desc[e]] = i; atomicAdd(&s_count, 1); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_count;
+}
+
+// exclusive scan of the per-cell counts (single workgroup); off[ncell] = total
+__global__ __launch_bounds__(KF_T) void k_scan_cells(const int* __restrict__ cnt, int ncell, int* __restrict__ off) {
+    __shared__ int s[KF_T];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += KF_T) {
+        const int i = base + threadIdx.x;
+        const int c = i < ncell ? cnt[i] : 0;
+        s[threadIdx.x] = c;
+        __syncthreads();
+        for (int d = 1; d < KF_T; d <<= 1) {
+            const int t = (int)threadIdx.x >= d ? s[threadIdx.x - d] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < ncell) off[i] = s_run + s[threadIdx.x] - c;
+        __syncthreads();
+        if (threadIdx.x == KF_T - 1) s_run += s[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[ncell] = s_run;
+}
+
+// candidate pixel coordinates and their Sobel gradient, in push order  (KeyFrame.cpp:413-430)
+__global__ __launch_bounds__(KF_T) void k_emit(const int* __restrict__ cand, const int* __restrict__ cnt, const int* __restrict__ off,
+                                               int cell, int ncx, int W, const double* __restrict__ gx, const double* __restrict__ gy,
+                                               double* __restrict__ coord, double* __restrict__ grad) {
+    const int cid = blockIdx.x;
+    const int n2 = cell * cell, c = cnt[cid], o = off[cid];
+    const int cy = cid / ncx, cx = cid - cy * ncx;
+    for (int p = threadIdx.x; p < c; p += KF_T) {
+        const int li = cand[(size_t)cid * n2 + p];
+        const int x = cx * cell + li % cell, y = cy * cell + li / cell;
+        coord[2 * (size_t)(o + p)] = (double)x; coord[2 * (size_t)(o + p) + 1] = (double)y;
+        grad[2 * (size_t)(o + p)] = gx[(size_t)y * W + x]; grad[2 * (size_t)(o + p) + 1] = gy[(size_t)y * W + x];
+    }
+}
+
+// nearest depth-map point of every candidate (brute force through LDS tiles; lowest index wins exact ties)
+__global__ __launch_bounds__(KF_T) void k_nearest(const double* __restrict__ coord, int n, const double* __restrict__ dxy,
+                                                  const double* __restrict__ didp, int m, double* __restrict__ idp, double* __restrict__ dist) {
+    constexpr int TILE = 1024;
+    __shared__ double sx[TILE], sy[TILE];
+    const int i = blockIdx.x * KF_T + threadIdx.x;
+    const double qx = i < n ? coord[2 * (size_t)i] : 0.0, qy = i < n ? coord[2 * (size_t)i + 1] : 0.0;
+    double best = INFINITY;
+    int bi = 0;
+    for (int base = 0; base < m; base += TILE) {
+        const int len = min(TILE, m - base);
+        __syncthreads();
+        for (int j = threadIdx.x; j < len; j += KF_T) { sx[j] = dxy[2 * (size_t)(base + j)]; sy[j] = dxy[2 * (size_t)(base + j) + 1]; }
+        __syncthreads();
+        for (int j = 0; j < len; ++j) {
+            const double dx = qx - sx[j], dy = qy - sy[j];
+            const double d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; bi = base + j; }
+        }
+    }
+    if (i < n) {
+        const double dx = dxy[2 * (size_t)bi] - qx, dy = dxy[2 * (size_t)bi + 1] - qy;     // cv::norm(dist)  (:1161-1162)
+        idp[i] = didp[bi];
+        dist[i] = sqrt(dx * dx + dy * dy);
+    }
+}
+
+// weights from the distances (:1168-1181), cleanPoints(thr) (:1566-1587): in-place, order-preserving compaction.
+// Single workgroup; a chunk is read completely before it is written, and destinations never pass the read front.
+__global__ __launch_bounds__(1024) void k_weights_clean(double* __restrict__ coord, double* __restrict__ grad, double* __restrict__ idp,
+                                                        double* __restrict__ wd, int n, int has_depth, double const_idp,
+                                                        const double* __restrict__ partial, int nblocks, double thr, int* __restrict__ summary) {
+    __shared__ double s_mn[1024], s_mx[1024];
+    __shared__ int s_wave[16];
+    __shared__ int s_run;
+    double mn = INFINITY, mx = -INFINITY;
+    if (has_depth) {
+        for (int b = threadIdx.x; b < nblocks; b += 1024) { mn = fmin(mn, partial[2 * b]); mx = fmax(mx, partial[2 * b + 1]); }
+        s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                s_mn[threadIdx.x] = fmin(s_mn[threadIdx.x], s_mn[threadIdx.x + s]);
+                s_mx[threadIdx.x] = fmax(s_mx[threadIdx.x], s_mx[threadIdx.x + s]);
+            }
+            __syncthreads();
+        }
+        mn = s_mn[0]; mx = s_mx[0];
+    }
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        double w = 1.0, c0 = 0, c1 = 0, g0 = 0, g1 = 0, d = const_idp;
+        bool keep = false;
+        if (i < n) {
+            if (has_depth) {
+                if (mn != mx) w = 1.0 - ((wd[i] - mn) / (mx - mn));
+                d = idp[i];
+            }
+            keep = !(w < thr);
+            c0 = coord[2 * (size_t)i]; c1 = coord[2 * (size_t)i + 1]; g0 = grad[2 * (size_t)i]; g1 = grad[2 * (size_t)i + 1];
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < 16; ++k) { const int c = s_wave[k]; before += k < wave ? c : 0; total += c; }
+        const int run = s_run;
+        if (keep) {
+            const size_t o = (size_t)(run + before + within);
+            coord[2 * o] = c0; coord[2 * o + 1] = c1; grad[2 * o] = g0; grad[2 * o + 1] = g1; idp[o] = d; wd[o] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_run = run + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { summary[0] = n; summary[1] = s_run; }
+}
+
+// the slot's fp32 planes from the cleaned fp64 arrays — the same conversion set_keyframe does on the host
+__global__ __launch_bounds__(KF_T) void k_fill_slot(EdsArrays A, int slot, int N, double fx, double fy, double cx, double cy,
+                                                    const double* __restrict__ coord, const double* __restrict__ grad,
+                                                    const double* __restrict__ idp, const double* __restrict__ w) {
+    const int i = blockIdx.x * KF_T + threadIdx.x;
+    if (i >= A.Np) return;
+    const size_t o = (size_t)slot * A.Np + i;
+    const bool in = i < N;
+    const double nx = in ? (coord[2 * (size_t)i] - cx) / fx : 0.0, ny = in ? (coord[2 * (size_t)i + 1] - cy) / fy : 0.0;   // :417-423
+    const_cast<float*>(A.x)[o] = (float)nx;
+    const_cast<float*>(A.y)[o] = (float)ny;
+    const_cast<float*>(A.rho)[o] = in ? (float)idp[i] : 1.f;
+    const_cast<float*>(A.gx)[o] = in ? (float)grad[2 * (size_t)i] : 0.f;
+    const_cast<float*>(A.gy)[o] = in ? (float)grad[2 * (size_t)i + 1] : 0.f;
+    const_cast<float*>(A.w)[o] = in ? (float)w[i] : 0.f;
+    const double u0 = in ? fx * nx + cx : 0.0, v0 = in ? fy * ny + cy : 0.0;
+    double cu = floor(u0), cv = floor(v0);
+    if (!(cu > -32000.0)) cu = -32000.0; if (cu > 32000.0) cu = 32000.0;
+    if (!(cv > -32000.0)) cv = -32000.0; if (cv > 32000.0) cv = 32000.0;
+    const_cast<float*>(A.f0x)[o] = (float)(u0 - cu);
+    const_cast<float*>(A.f0y)[o] = (float)(v0 - cv);
+    const_cast<int*>(A.cell0)[o] = (int)(((unsigned)(int)cv << 16) | ((unsigned)(int)cu & 0xffffu));
+}
+
+}  // namespace
+
+void eds_keyframe_free(EdsKeyframeBuffers* kb) {
+    void* d[] = {kb->d_raw, kb->d_log, kb->d_gx, kb->d_gy, kb->d_mag, kb->d_partial, kb->d_cand, kb->d_cnt, kb->d_off,
+                 kb->d_coord, kb->d_grad, kb->d_idp, kb->d_w, kb->d_dxy, kb->d_didp, kb->d_summary};
+    for (void* p : d) if (p) hipFree(p);
+    *kb = EdsKeyframeBuffers();
+}
+
+static int ensure(eds_trk* h) {
+    EdsKeyframeBuffers& kb = h->kf_build;
+    if (kb.d_raw) return EDS_OK;
+    const size_t n = (size_t)h->H * h->W;
+    hipError_t e = hipMalloc(&kb.d_raw, n * 8);
+    double** planes[] = {&kb.d_log, &kb.d_gx, &kb.d_gy, &kb.d_mag, &kb.d_idp, &kb.d_w};
+    for (double** p : planes) if (e == hipSuccess) e = hipMalloc((void**)p, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_coord, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_grad, n * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_partial, 2 * 256 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_cand, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_cnt, (n / 4 + 2) * 4);       // cells are at least 2 x 2
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_off, (n / 4 + 2) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&kb.d_summary, 16);
+    if (e != hipSuccess) { eds_keyframe_free(&kb); return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(keyframe set-up buffers)"); }
+    return EDS_OK;
+}
+
+int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
+                       const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points) {
+    const int H = h->H, W = h->W;
+    const size_t n = (size_t)H * W;
+    const int cell = sel->cell;
+    if (cell < 2 || cell > KF_MAX_CELL || cell > H || cell > W) return eds_internal_fail(EDS_ERR_INVALID, "cell size must be in [2, 32] and fit the image");
+    if (sel->method != EDS_KF_MAX && sel->method != EDS_KF_MEDIAN) return eds_internal_fail(EDS_ERR_INVALID, "unknown point selection method");
+    if (img_type < 0 || img_type > 2) return eds_internal_fail(EDS_ERR_INVALID, "img_type must be EDS_IMG_U8, EDS_IMG_F32 or EDS_IMG_F64");
+    if (n_depth > 0 && (!depth_xy || !depth_idp)) return eds_internal_fail(EDS_ERR_INVALID, "null depth map");
+    int rc = ensure(h);
+    if (rc) return rc;
+    EdsKeyframeBuffers& kb = h->kf_build;
+    kb.last_slot = -1;
+    if (n_depth > kb.cap_depth) {
+        if (kb.d_dxy) { hipFree(kb.d_dxy); hipFree(kb.d_didp); kb.d_dxy = kb.d_didp = nullptr; }
+        kb.cap_depth = n_depth + n_depth / 4 + 256;
+        if (hipMalloc((void**)&kb.d_dxy, (size_t)kb.cap_depth * 16) != hipSuccess || hipMalloc((void**)&kb.d_didp, (size_t)kb.cap_depth * 8) != hipSuccess) {
+            kb.cap_depth = 0;
+            return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(depth map)");
+        }
+    }
+    hipStream_t st = h->st;
+    const size_t px = img_type == 0 ? 1 : (img_type == 1 ? 4 : 8);
+    hipError_t e = hipMemcpyAsync(kb.d_raw, img, n * px, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_depth > 0) e = hipMemcpyAsync(kb.d_dxy, depth_xy, (size_t)n_depth * 16, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && n_depth > 0) e = hipMemcpyAsync(kb.d_didp, depth_idp, (size_t)n_depth * 8, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    const int NB = 256;
+    hipLaunchKernelGGL(k_minmax, dim3(NB), dim3(KF_T), 0, st, kb.d_raw, img_type, n, kb.d_partial);
+    hipLaunchKernelGGL(k_log, dim3(NB), dim3(KF_T), 0, st, kb.d_raw, img_type, n, kb.d_partial, NB, kb.d_log);
+    hipLaunchKernelGGL(k_sobel, dim3((W + KF_T - 1) / KF_T, H), dim3(KF_T), 0, st, kb.d_log, H, W, kb.d_gx, kb.d_gy, kb.d_mag);
+    const int ncx = W / cell, ncy = H / cell, ncell = ncx * ncy;       // only whole cells (KeyFrame.cpp:752-754)
+    const int k_per_cell = sel->method == EDS_KF_MAX ? (sel->num_points > 0 ? sel->num_points / ncell : 0) : 0;
+    hipLaunchKernelGGL(k_select, dim3(ncell), dim3(KF_T), 0, st, kb.d_mag, W, cell, ncx, (int)sel->method, k_per_cell, kb.d_cand, kb.d_cnt);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(KF_T), 0, st, kb.d_cnt, ncell, kb.d_off);
+    hipLaunchKernelGGL(k_emit, dim3(ncell), dim3(KF_T), 0, st, kb.d_cand, kb.d_cnt, kb.d_off, cell, ncx, W, kb.d_gx, kb.d_gy, kb.d_coord, kb.d_grad);
+    int ncand = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&ncand, kb.d_off + ncell, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    if (ncand < 1) return eds_internal_fail(EDS_ERR_INVALID, "the selection produced no candidate point");
+    const double const_idp = 1.0 / ((sel->max_depth - sel->min_depth) / 2.0);       // KeyFrame.cpp:1189
+    if (n_depth > 0) {
+        hipLaunchKernelGGL(k_nearest, dim3((ncand + KF_T - 1) / KF_T), dim3(KF_T), 0, st, kb.d_coord, ncand, kb.d_dxy, kb.d_didp, n_depth, kb.d_idp, kb.d_w);
+        hipLaunchKernelGGL(k_minmax, dim3(NB), dim3(KF_T), 0, st, (const void*)kb.d_w, 2, (size_t)ncand, kb.d_partial);
+    }
+    hipLaunchKernelGGL(k_weights_clean, dim3(1), dim3(1024), 0, st, kb.d_coord, kb.d_grad, kb.d_idp, kb.d_w, ncand, n_depth > 0 ? 1 : 0,
+                       const_idp, kb.d_partial, NB, sel->weight_threshold, kb.d_summary);
+    int summary[2] = {0, 0};
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(summary, kb.d_summary, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    const int N = summary[1];
+    if (n_points) *n_points = N;
+    kb.last_N = N; kb.last_candidates = ncand;
+    kb.K[0] = fx; kb.K[1] = fy; kb.K[2] = cx; kb.K[3] = cy;
+    if (N < 1) return eds_internal_fail(EDS_ERR_INVALID, "no point survived the weight threshold");
+    if (N > h->Nmax) return eds_internal_fail(EDS_ERR_INVALID, "the keyframe has more points than the handle's max_points");
+    hipLaunchKernelGGL(k_fill_slot, dim3(h->Np / KF_T), dim3(KF_T), 0, st, h->arrays(), slot, N, fx, fy, cx, cy, kb.d_coord, kb.d_grad, kb.d_idp, kb.d_w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    Slot& s = h->slots[slot];
+    s.N = N; s.K[0] = fx; s.K[1] = fy; s.K[2] = cx; s.K[3] = cy;
+    if ((rc = eds_internal_refresh_gram(h, slot))) return rc;
+    s.has_kf = true;
+    s.residuals.clear();
+    kb.last_slot = slot;
+    return EDS_OK;
+}
+
+int eds_keyframe_get_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp, double* weights) {
+    EdsKeyframeBuffers& kb = h->kf_build;
+    if (kb.last_slot != slot || kb.last_N < 1) return eds_internal_fail(EDS_ERR_STATE, "this slot is not the one eds_trk_build_keyframe filled last");
+    const size_t N = (size_t)kb.last_N;
+    hipError_t e = hipStreamSynchronize(h->st);
+    if (e == hipSuccess && (coord_xy || norm_xy)) {
+        double* dst = coord_xy ? coord_xy : norm_xy;
+        e = hipMemcpy(dst, kb.d_coord, N * 16, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && norm_xy) {
+            for (size_t i = 0; i < N; ++i) {                      // KeyFrame.cpp:417-423
+                const double x = dst[2 * i], y = dst[2 * i + 1];
+                norm_xy[2 * i] = (x - kb.K[2]) / kb.K[0];
+                norm_xy[2 * i + 1] = (y - kb.K[3]) / kb.K[1];
+            }
+        }
+    }
+    if (e == hipSuccess && grad_xy) e = hipMemcpy(grad_xy, kb.d_grad, N * 16, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && idp) e = hipMemcpy(idp, kb.d_idp, N * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && weights) e = hipMemcpy(weights, kb.d_w, N * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    return EDS_OK;
+}

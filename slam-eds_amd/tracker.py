@@ -17,6 +17,8 @@ from . import capi
 CONSTANT, MAD, STD = capi.LP_CONSTANT, capi.LP_MAD, capi.LP_STD
 # eds::tracking::LOSS_FUNCTION (tracking/Config.hpp:36)
 NONE, HUBER, CAUCHY = capi.LOSS_NONE, capi.LOSS_HUBER, capi.LOSS_CAUCHY
+# eds::tracking::CANDIDATE_POINT_METHOD
+SELECT_MAX, SELECT_MEDIAN = capi.KF_MAX, capi.KF_MEDIAN
 
 
 @dataclass
@@ -58,6 +60,26 @@ class KeyFrame:
     rows: int                       # kf->img.rows
     cols: int                       # kf->img.cols
     residuals: np.ndarray = field(default_factory=lambda: np.zeros(0))
+    coord: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))   # pixel coordinates (KeyFrame.hpp:80)
+
+    @classmethod
+    def create(cls, img, K_ref, depth_xy=None, depth_idp=None, points_selection_method: int = SELECT_MEDIAN,
+               min_depth: float = 1.0, max_depth: float = 3.0, percent_points: float = 0.0, device: int = 0) -> "KeyFrame":
+        """The tracker-facing part of KeyFrame::create (KeyFrame.cpp:333-463) on the GPU: log image, Sobel, per-cell
+        point selection, depth association against the depth map (``depth_xy`` pixels, ``depth_idp``), cleanPoints(0.7).
+        Like the reference, a point target outside (0, rows*cols) falls back to MEDIAN (:406-411)."""
+        img = np.asarray(img)
+        rows, cols = img.shape
+        K = np.asarray(K_ref, dtype=np.float64)
+        target = rows * cols * (percent_points / 100.0)
+        method, num = (points_selection_method, int(target)) if 0 < target < rows * cols else (SELECT_MEDIAN, 0)
+        h = capi.Handle(capi.default_config(device=device), 1, rows * cols, rows, cols)
+        try:
+            out = h.build_keyframe(0, img, (K[0, 0], K[1, 1], K[0, 2], K[1, 2]), method=method, num_points=num,
+                                   depth_xy=depth_xy, depth_idp=depth_idp, min_depth=min_depth, max_depth=max_depth)
+        finally:
+            h.close()
+        return cls(out["norm_coord"], out["grad"], out["weights"], out["idp"], K, rows, cols, coord=out["coord"])
 
 
 @dataclass

@@ -30,3 +30,21 @@ print(f"  single-slot calls: device-resident {d1/256*1e6:.1f} us each; host nth_
 t = time.perf_counter()
 for b in range(256): out = h.update_points(b, True)
 print(f"point maintenance (getCoord + culling), 2000 points: {(time.perf_counter()-t)/256*1e6:.1f} us per alignment incl. readback of coords/tracks")
+# keyframe set-up
+import np_keyframe_oracle as ko
+h.close()
+img = rng.standard_normal((H, W))
+for _ in range(3): img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 0) + np.roll(img, -1, 1)) / 5.0
+img = np.round(255 * (img - img.min()) / (img.max() - img.min())).astype(np.uint8)
+K = (0.78 * W, 0.78 * W, (W - 1) / 2, (H - 1) / 2)
+for md in (3000, 30000):
+    dxy = np.stack([rng.uniform(0, W - 1, md), rng.uniform(0, H - 1, md)], axis=1); didp = rng.uniform(0.2, 1.0, md)
+    hk = capi.Handle(capi.default_config(), 1, H * W, H, W)
+    for method, npts, name in ((capi.KF_MAX, 2000, "MAX 2000"), (capi.KF_MAX, 30000, "MAX 30000"), (capi.KF_MEDIAN, 0, "MEDIAN")):
+        out = hk.build_keyframe(0, img, K, method=method, num_points=npts, depth_xy=dxy, depth_idp=didp)
+        t = time.perf_counter()
+        for _ in range(5): out = hk.build_keyframe(0, img, K, method=method, num_points=npts, depth_xy=dxy, depth_idp=didp)
+        dt = (time.perf_counter() - t) / 5
+        t = time.perf_counter(); ref = ko.keyframe(img, K, method, npts, depth_xy=dxy, depth_idp=didp); dcpu = time.perf_counter() - t
+        print(f"keyframe set-up 640x480 {name:10s} depth map {md:6d}: GPU {dt*1e3:7.2f} ms incl. image upload + readback of {len(out['idp']):6d} points | numpy oracle {dcpu*1e3:8.1f} ms")
+    hk.close()
