@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 
 #include "eds_device.hpp"
@@ -19,12 +20,14 @@
 #include "eds_handle.hpp"
 #include "eds_math.hpp"
 #include "eds_solver.hpp"
+#include "eds_solver12_coop.hpp"
 
 using namespace edsd;
 
 #define EDS12_THREADS 512
 #define EDS12_WAVES (EDS12_THREADS / 64)
 #define EDS12_CACHE_CAP 2048
+#define EDS12_NACC 96
 
 template <int SAMPLING, int PPT>
 __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
@@ -35,11 +38,14 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
     const int tid = threadIdx.x, nthr = EDS12_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
+    constexpr int HALF = PPT > 1 ? PPT / 2 : 1;          // gathers in flight per lane (register budget: 2 x 16 taps)
     __shared__ edss::Solver12 sv;
     __shared__ edss::Sums12Dev sums;
+    __shared__ edsc::Work12 work;
     __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_red[EDS12_WAVES][EDS_RED_K12];
-    __shared__ int s_state;
+    __shared__ int s_state;            // 0: iterate, 2: done
+    __shared__ int s_accept;           // the evaluation just consumed became the accepted point
     __shared__ float s_patch[NTAP][EDS12_CACHE_CAP];
     __shared__ int s_cell[EDS12_CACHE_CAP];
 
@@ -52,107 +58,146 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
     frame.base = A.frame + (size_t)slot * A.Hp * A.Wp;
     frame.H = A.H; frame.W = A.W; frame.Hp = A.Hp; frame.Wp = A.Wp; frame.TW = A.Wp >> 2; frame.tiled = A.tiled;
 
-    if (tid == 0) {
-        const EdsFusedIn& I = in[slot];
-        for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
-        sv.init(iters, loss_type, loss_a, ftol, gtol, ptol, I.p, I.q, I.v);
-        edsm::fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose);
-        sums.nb = nb;
-        s_state = 0;
+    if (wave == 0) {
+        if (lane == 0) {
+            const EdsFusedIn& I = in[slot];
+            for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
+            sv.init(iters, loss_type, loss_a, ftol, gtol, ptol, I.p, I.q, I.v);
+            sv.skip_final = 1;              // the residuals of the accepted point stay in registers (racc below)
+            sums.nb = nb;
+            s_state = 0; s_accept = 0;
+#ifdef EDS_FUSED_STAMPS
+            for (int k = 0; k < 8; ++k) work.st[k] = 0;
+#endif
+        }
+        EDS_WSYNC();
+        edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose, lane);
     }
     // per-point constants in registers for the whole solve
     PointKf kf[PPT];
-    float kw[PPT], ka[PPT][6];
-    int kblk[PPT];
+    float kw[PPT], kgx[PPT], kgy[PPT];  // the 6-entry model row a_i is rebuilt from (x, y, rho, gx, gy) when needed: 2 registers, not 6
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int i = tid + j * nthr;
         const bool in_range = i < N;
         const size_t o = base + (in_range ? i : 0);
-        const float x = A.x[o], y = A.y[o], rho = A.rho[o];
-        kf[j].x = x; kf[j].y = y; kf[j].rhop = rho + 1e-5f;
+        kf[j].x = A.x[o]; kf[j].y = A.y[o]; kf[j].rhop = A.rho[o] + 1e-5f;
         kf[j].f0x = A.f0x[o]; kf[j].f0y = A.f0y[o]; kf[j].cell0 = A.cell0[o];
         kw[j] = in_range ? A.w[o] : 0.0f;
-        model_row(x, y, rho, A.gx[o], A.gy[o], ka[j]);
-        kblk[j] = in_range ? block_of(i, ne, nb) : -1;
+        kgx[j] = A.gx[o]; kgy[j] = A.gy[o];
         if (i < EDS12_CACHE_CAP) s_cell[i] = 0x7fffffff;
     }
+    auto in_block = [&](int j, int blk) -> bool {
+        const int i = tid + j * nthr;
+        return i < N && block_of(i, ne, nb) == blk;
+    };
+    float rcand[PPT], racc[PPT];        // residuals of the evaluation in flight / of the accepted point
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
     __syncthreads();
 
+#ifdef EDS_FUSED_STAMPS
+    unsigned long long st_acc[3] = {0, 0, 0}, st_t = __builtin_readcyclecounter();
+    int st_n = 0;
+#define EDS12_STAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#else
+#define EDS12_STAMP(k) do { } while (0)
+#endif
     for (;;) {
-        const int state = s_state;
         PoseF ps;
         load_pose(s_pose, ps);
         float vf[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
-        float Pv[36];                   // local Jacobian of the unit-norm velocity plus (wave-uniform -> SGPRs)
-#pragma unroll
-        for (int k = 0; k < 36; ++k) Pv[k] = uniformf((float)s_pose[EDS_PB_PV + k]);
         for (int blk = 0; blk < nb; ++blk) {
             const float inv_n = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk]);
             float gvec[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) gvec[k] = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk + 1 + k]);
-            float acc[EDS_RED_K12];
+            float acc[EDS12_NACC];          // 91 live sums: a 64-wide and a 32-wide butterfly instead of one 128-wide
 #pragma unroll
-            for (int j = 0; j < EDS_RED_K12; ++j) acc[j] = 0.0f;
+            for (int j = 0; j < EDS12_NACC; ++j) acc[j] = 0.0f;
 #pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                if (kblk[j] != blk) continue;
-                const int i = tid + j * nthr;
-                PointGeom pg;
-                project_point(ps, kf[j], pg);
-                float tap[NTAP];
-                const bool cached = i < EDS12_CACHE_CAP;
-                const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
-                if (cached && s_cell[i] == key) {
+            for (int h0 = 0; h0 < PPT; h0 += HALF) {
+                // phase A: project this half's points, probe the patch cache, put every missing gather in flight
+                PointGeom pg[HALF];
+                float tap[HALF][NTAP];
+                bool miss[HALF];
 #pragma unroll
-                    for (int t = 0; t < NTAP; ++t) tap[t] = s_patch[t][i];
-                } else {
-                    if (SAMPLING == 0) load_patch16(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[16]>(tap));
-                    else load_patch4(frame, pg.r0, pg.c0, reinterpret_cast<float(&)[4]>(tap));
-                    if (cached) {
+                for (int jj = 0; jj < HALF; ++jj) {
+                    const int j = h0 + jj;
+                    const int i = tid + j * nthr;
+                    miss[jj] = false;
+                    if (!in_block(j, blk)) continue;
+                    project_point(ps, kf[j], pg[jj]);
+                    const bool cached = i < EDS12_CACHE_CAP;
+                    const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
+                    miss[jj] = !(cached && s_cell[i] == key);
+                    if (miss[jj]) {
+                        if (SAMPLING == 0) load_patch16(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[16]>(tap[jj]));
+                        else load_patch4(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[4]>(tap[jj]));
+                        if (cached) s_cell[i] = key;
+                    } else {
 #pragma unroll
-                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[t];
-                        s_cell[i] = key;
+                        for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][i];
                     }
                 }
-                float E, Er, Ec;
-                if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
-                else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
-                PointProj pp;
-                finish_point(ps, pg, E, Er, Ec, pp);
-                const float w = kw[j];
-                float m = 0.0f;
+                __builtin_amdgcn_sched_barrier(0);
+                // phase B: refill the cache, residual, 1x12 row (closed forms of SURVEY §8a), running sums
 #pragma unroll
-                for (int k = 0; k < 6; ++k) m += ka[j][k] * vf[k];
-                const float r = w * (m * inv_n - pp.E);
-                float J[12];
-                J[0] = -w * pp.g0; J[1] = -w * pp.g1; J[2] = -w * pp.g2;
-                // quaternion local: -2 w (R X) x gradE_P with R X = P - t   
-                const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
-                const float w2 = -2.0f * w;
-                J[3] = w2 * (ry * pp.g2 - rz * pp.g1);
-                J[4] = w2 * (rz * pp.g0 - rx * pp.g2);
-                J[5] = w2 * (rx * pp.g1 - ry * pp.g0);
-                // velocity local: w (a/n - m (G v)/n^3) (I - v v^T/|v|^2)/|v|
-                float row[6];
+                for (int jj = 0; jj < HALF; ++jj) {
+                    const int j = h0 + jj;
+                    const int i = tid + j * nthr;
+                    if (!in_block(j, blk)) continue;
+                    if (miss[jj] && i < EDS12_CACHE_CAP) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) row[k] = w * (ka[j][k] * inv_n - m * gvec[k]);
+                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
+                    }
+                    // pin this point's arithmetic behind the previous point's: without it the compiler interleaves the
+                    // unrolled bodies and the live temporaries of PPT points overflow the register file
+                    asm volatile("" : "+v"(pg[jj].ax), "+v"(pg[jj].ay), "+v"(acc[0]));
+                    float E, Er, Ec;
+                    if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                    else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                    PointProj pp;
+                    finish_point(ps, pg[jj], E, Er, Ec, pp);
+                    const float w = kw[j];
+                    float ka[6];
+                    model_row(kf[j].x, kf[j].y, kf[j].rhop - 1e-5f, kgx[j], kgy[j], ka);
+                    float m = 0.0f;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    float s = 0.0f;
+                    for (int k = 0; k < 6; ++k) m += ka[k] * vf[k];
+                    const float r = w * (m * inv_n - pp.E);
+                    float J[12];
+                    J[0] = -w * pp.g0; J[1] = -w * pp.g1; J[2] = -w * pp.g2;
+                    // quaternion local: -2 w (R X) x gradE_P with R X = P - t
+                    const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
+                    const float w2 = -2.0f * w;
+                    J[3] = w2 * (ry * pp.g2 - rz * pp.g1);
+                    J[4] = w2 * (rz * pp.g0 - rx * pp.g2);
+                    J[5] = w2 * (rx * pp.g1 - ry * pp.g0);
+                    // velocity local: w (a/n - m (G v)/n^3) (I - v v^T/|v|^2)/|v|; the projector is read from LDS
+                    // (wave-uniform broadcast) rather than held in 36 registers
+                    float row[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) s += row[k] * Pv[6 * k + c];
-                    J[6 + c] = s;
+                    for (int k = 0; k < 6; ++k) row[k] = w * (ka[k] * inv_n - m * gvec[k]);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) s += row[k] * (float)s_pose[EDS_PB_PV + 6 * k + c];
+                        J[6 + c] = s;
+                    }
+                    accumulate_normal<12>(acc, J, r, 1.0f, r * r);
+                    rcand[j] = r;
+                    __builtin_amdgcn_sched_barrier(0);      // keep one point's temporaries from overlapping the next one's
                 }
-                accumulate_normal<12>(acc, J, r, 1.0f, r * r);
-                if (state == 1) A.r[base + i] = r;
             }
-            wave_reduce_scatter<EDS_RED_K12>(acc, lane);
-            s_red[wave][wave_red_index<EDS_RED_K12>(lane, 0)] = acc[0];
-            s_red[wave][wave_red_index<EDS_RED_K12>(lane, 1)] = acc[1];
+            EDS12_STAMP(0);
+            wave_reduce_scatter<64>(acc, lane);
+            wave_reduce_scatter<32>(acc + 64, lane);
+            s_red[wave][wave_red_index<64>(lane, 0)] = acc[0];
+            if (lane < 32) s_red[wave][64 + wave_red_index<32>(lane, 0)] = acc[64];
             __syncthreads();
             if (tid < EDS_RED_N12) {            // cross-wavefront sum in fp64, unpacked into the solver's input
                 double s = 0.0;
@@ -171,20 +216,43 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
                 }
             }
             __syncthreads();
+            EDS12_STAMP(1);
         }
-        if (tid == 0) {
-            sv.on_eval(sums);
-            if (sv.done) {
-                s_state = 2;
-            } else {
-                edsm::fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose);
-                s_state = sv.final_pass ? 1 : 0;
-            }
+        if (wave == 0) {                        // the LM state machine, spread over this wavefront (eds_solver12_coop.hpp)
+            edsc::coop12_on_eval(sv, sums, work, lane);
+            const int done = edsc::uniform_int(sv.done);
+            if (!done) edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose, lane);
+#ifdef EDS_FUSED_STAMPS
+            if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); work.st[6] += n_ - work.st_t; work.st_t = n_; }
+#endif
+            if (lane == 0) { s_state = done ? 2 : 0; s_accept = work.accepted; }
         }
         __syncthreads();
+        EDS12_STAMP(2);
+#ifdef EDS_FUSED_STAMPS
+        ++st_n;
+#endif
+        if (s_accept) {
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) racc[j] = rcand[j];
+        }
         if (s_state == 2) break;
     }
+    // residuals at the solution (what Tracker.cpp:223-230 writes to kf->residuals): those of the last accepted point
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid + j * nthr;
+        if (i < N) A.r[base + i] = racc[j];
+    }
 
+#ifdef EDS_FUSED_STAMPS
+    if (tid == 0 && blockIdx.x == 0)
+        printf("[stamps12] lane-0 cycles per evaluation: points %llu  reduce %llu  solver %llu  (%d evaluations)\n",
+               st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_n);
+    if (tid == 0 && blockIdx.x == 0)
+        printf("[stamps12]   solver split: decide %llu linearise %llu bookkeeping %llu cholesky %llu step %llu tail %llu pose %llu\n",
+               work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
+#endif
     if (tid == 0) {
         EdsFused12Out& O = out[slot];
         const bool ok = sv.termination != edss::TERM_FAILURE;

@@ -194,6 +194,7 @@ struct Solver12 {
     int reuse_diagonal, consecutive_invalid, have_scale;
     int iteration, step_successful, started;
     int done, termination, num_successful, num_unsuccessful, final_pass;
+    int skip_final;                     // the caller keeps the residuals of the accepted point itself: no residual pass at the end
     double initial_cost, final_cost;
 
     EDS_HD void init(int max_iters_, int loss_type_, double loss_a_, double ftol_, double gtol_, double ptol_,
@@ -204,7 +205,7 @@ struct Solver12 {
         for (int i = 0; i < 6; ++i) v[i] = cv[i] = best_v[i] = v0[i];
         radius = 1e4; decrease_factor = 2.0; reuse_diagonal = 0; consecutive_invalid = 0; have_scale = 0;
         iteration = 0; step_successful = 0; started = 0; done = 0; termination = TERM_FAILURE;
-        num_successful = num_unsuccessful = 0; final_pass = 0;
+        num_successful = num_unsuccessful = 0; final_pass = 0; skip_final = 0;
         x_cost = x_norm = grad_max_norm = minimum_cost = initial_cost = final_cost = model_cost_change = 0.0;
     }
     EDS_HD static double norm13(const double* p_, const double* q_, const double* v_) {
@@ -256,7 +257,7 @@ struct Solver12 {
         termination = term;
         const bool usable = (term == TERM_CONVERGENCE || term == TERM_NO_CONVERGENCE);
         // residuals at the solution (Tracker.cpp:223-230); skipped when the solution is not usable
-        if (usable) {
+        if (usable && !skip_final) {
             for (int i = 0; i < 3; ++i) cp[i] = best_p[i];
             for (int i = 0; i < 4; ++i) cq[i] = best_q[i];
             for (int i = 0; i < 6; ++i) cv[i] = best_v[i];
