@@ -301,22 +301,16 @@ void free_all(eds_trk* h) {
 
 }  // namespace
 
-// Row-major H x W host frame (double or float) -> the handle's HBM layout in pinned staging:
-// fp32, padded to multiples of 4 with replicated border pixels (= Grid2D's clamp), optionally in
-// 4x4 tiles of one 64-byte sector each (eds_device.hpp FrameView).
+// Row-major H x W host frame (double or float) -> the handle's HBM layout in pinned staging: fp32, padded to multiples
+// of 4 plus a margin, everything outside the image filled with the nearest border pixel (= Grid2D's clamp), in 4x4
+// tiles of one 64-byte sector each or row-major (eds_layout.hpp eds_frame_index).
 template <class T>
 static void stage_frame(eds_trk* h, const T* frame) {
-    const int H = h->H, W = h->W, Hp = h->Hp, Wp = h->Wp, TW = Wp >> 2;
+    const int H = h->H, W = h->W, Hp = h->Hp, Wp = h->Wp, M = EDS_FRAME_MARGIN;
     float* dst = h->h_f32;
-    for (int r = 0; r < Hp; ++r) {
-        const T* src = frame + (size_t)std::min(r, H - 1) * W;
-        if (h->tiled) {
-            float* trow = dst + ((size_t)(r >> 2) * TW) * 16 + ((r & 3) << 2);
-            for (int c = 0; c < Wp; ++c) trow[(size_t)(c >> 2) * 16 + (c & 3)] = (float)src[std::min(c, W - 1)];
-        } else {
-            float* drow = dst + (size_t)r * Wp;
-            for (int c = 0; c < Wp; ++c) drow[c] = (float)src[std::min(c, W - 1)];
-        }
+    for (int r = -M; r < Hp - M; ++r) {
+        const T* src = frame + (size_t)std::min(std::max(r, 0), H - 1) * W;
+        for (int c = -M; c < Wp - M; ++c) dst[eds_frame_index(r, c, Wp, h->tiled)] = (float)src[std::min(std::max(c, 0), W - 1)];
     }
 }
 
@@ -369,7 +363,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (!h) return fail(EDS_ERR_INVALID, "out of memory");
     h->cfg = *cfg;
     h->B = batch; h->Nmax = max_points_; h->H = H; h->W = W; h->dev = cfg->device;
-    h->Hp = (H + 3) & ~3; h->Wp = (W + 3) & ~3;
+    h->Hp = eds_frame_extent(H); h->Wp = eds_frame_extent(W);
     h->tiled = 1;
     if (const char* e = getenv("EDS_FRAME_LAYOUT")) h->tiled = (std::strcmp(e, "rowmajor") != 0);   // tuning knob
     h->Np = ((max_points_ + EDS_POINT_ALIGN - 1) / EDS_POINT_ALIGN) * EDS_POINT_ALIGN;
@@ -584,12 +578,8 @@ int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {
     EDS_HIP_TRY(hipSetDevice(h->dev));
     const size_t n = (size_t)h->Hp * h->Wp;
     EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dframe + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
-    const int TW = h->Wp >> 2;
     for (int r = 0; r < h->H; ++r)
-        for (int c = 0; c < h->W; ++c) {
-            const size_t o = h->tiled ? ((size_t)((r >> 2) * TW + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * h->Wp + c);
-            frame[(size_t)r * h->W + c] = h->h_f32[o];
-        }
+        for (int c = 0; c < h->W; ++c) frame[(size_t)r * h->W + c] = h->h_f32[eds_frame_index(r, c, h->Wp, h->tiled)];
     return EDS_OK;
 }
 

@@ -36,29 +36,39 @@ __device__ __forceinline__ void hermite(float p0, float p1, float p2, float p3, 
 // The allocation is padded to multiples of 4 with border-replicated pixels, which is exactly what
 // Grid2D's index clamp returns there.
 struct FrameView {
-    const float* __restrict__ base;
+    const float* __restrict__ base;   // LOGICAL pixel (0, 0): the allocation starts EDS_FRAME_MARGIN rows and columns earlier
     int H, W;          // logical size (clamp range)
-    int Hp, Wp;        // padded size (multiples of 4)
+    int Hp, Wp;        // allocated size (multiples of 4, margins included)
     int TW;            // tiles per tile-row = Wp / 4
     int tiled;
 };
-__device__ __forceinline__ size_t frame_index(const FrameView& f, int r, int c) {
-    return f.tiled ? ((size_t)((r >> 2) * f.TW + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * f.Wp + c);
+// view of slot `slot`'s frame inside the [B][Hp*Wp] allocation
+__device__ __forceinline__ FrameView make_frame_view(const float* frames, int slot, int H, int W, int Hp, int Wp, int tiled) {
+    FrameView f;
+    f.H = H; f.W = W; f.Hp = Hp; f.Wp = Wp; f.TW = Wp >> 2; f.tiled = tiled;
+    f.base = frames + (size_t)slot * Hp * Wp + eds_frame_index(0, 0, Wp, tiled);
+    return f;
+}
+// element offset of logical pixel (r, c) from f.base; valid for -MARGIN <= r < Hp - MARGIN (arithmetic shifts)
+__device__ __forceinline__ ptrdiff_t frame_index(const FrameView& f, int r, int c) {
+    return f.tiled ? ((ptrdiff_t)((r >> 2) * f.TW + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((ptrdiff_t)r * f.Wp + c);
 }
 
-// Loads the 4x4 neighbourhood rows r0-1..r0+2, cols c0-1..c0+2 (clamped).
+// Loads the 4x4 neighbourhood rows r0-1..r0+2, cols c0-1..c0+2, indices clamped to the frame like Grid2D::GetValue.
+// The replicated margin makes the clamp a clamp of the ORIGIN: for r0 <= -2 all four rows read row 0, for r0 >= H all
+// read row H-1, and anything in between lies inside the allocation — so there is one code path, no border branch.
 __device__ __forceinline__ void load_patch16(const FrameView& f, int r0, int c0, float (&p)[16]) {
-    const bool interior = c0 >= 1 && c0 + 2 < f.Wp && r0 >= 1 && r0 + 2 < f.Hp;
-    if (interior && f.tiled) {                                        // per row two aligned 16-byte tile rows
+    r0 = clampi(r0, -2, f.H); c0 = clampi(c0, -2, f.W);
+    if (f.tiled) {                                                    // per row two aligned 16-byte tile rows
         const int ca = c0 - 1, s = ca & 3;
         const int txa = ca >> 2, txb = (c0 + 2) >> 2;
         const bool s2 = s & 2, s1 = s & 1;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = r0 - 1 + k;
-            const float* trow = f.base + ((size_t)(r >> 2) * f.TW) * 16 + ((r & 3) << 2);
-            const float4 a = *reinterpret_cast<const float4*>(trow + (size_t)txa * 16);
-            const float4 b = *reinterpret_cast<const float4*>(trow + (size_t)txb * 16);
+            const float* trow = f.base + ((ptrdiff_t)(r >> 2) * f.TW) * 16 + ((r & 3) << 2);
+            const float4 a = *reinterpret_cast<const float4*>(trow + (ptrdiff_t)txa * 16);
+            const float4 b = *reinterpret_cast<const float4*>(trow + (ptrdiff_t)txb * 16);
             // 8 floats [a.x a.y a.z a.w b.x b.y b.z ..] shifted left by s in {0..3}: two-stage barrel shift
             const float t0 = s2 ? a.z : a.x, t1 = s2 ? a.w : a.y, t2 = s2 ? b.x : a.z, t3 = s2 ? b.y : a.w, t4 = s2 ? b.z : b.x;
             p[4 * k + 0] = s1 ? t1 : t0;
@@ -66,21 +76,13 @@ __device__ __forceinline__ void load_patch16(const FrameView& f, int r0, int c0,
             p[4 * k + 2] = s1 ? t3 : t2;
             p[4 * k + 3] = s1 ? t4 : t3;
         }
-    } else if (interior) {                                            // row-major: four dword-aligned 16-byte row segments
-        const float* base = f.base + (size_t)(r0 - 1) * f.Wp + (c0 - 1);
+    } else {                                                          // row-major: four dword-aligned 16-byte row segments
+        const float* base = f.base + (ptrdiff_t)(r0 - 1) * f.Wp + (c0 - 1);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float4u v = *reinterpret_cast<const float4u*>(base + (size_t)k * f.Wp);
+            const float4u v = *reinterpret_cast<const float4u*>(base + (ptrdiff_t)k * f.Wp);
             p[4 * k + 0] = v.x; p[4 * k + 1] = v.y; p[4 * k + 2] = v.z; p[4 * k + 3] = v.w;
         }
-    } else {
-        int rr[4], cc[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { rr[k] = clampi(r0 - 1 + k, 0, f.H - 1); cc[k] = clampi(c0 - 1 + k, 0, f.W - 1); }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) p[4 * k + j] = f.base[frame_index(f, rr[k], cc[j])];
     }
 }
 
@@ -94,17 +96,17 @@ __device__ __forceinline__ void bicubic_patch(const float (&p)[16], float ay, fl
     hermite(d[0], d[1], d[2], d[3], ay, Ecol, unused);
 }
 
+// 2x2 neighbourhood rows r0, r0+1, cols c0, c0+1 (clamped the same way)
 __device__ __forceinline__ void load_patch4(const FrameView& f, int r0, int c0, float (&p)[4]) {
-    if (!f.tiled && c0 >= 0 && c0 + 1 < f.Wp && r0 >= 0 && r0 + 1 < f.Hp) {
-        const float* base = f.base + (size_t)r0 * f.Wp + c0;
+    r0 = clampi(r0, -1, f.H - 1); c0 = clampi(c0, -1, f.W - 1);
+    if (!f.tiled) {
+        const float* base = f.base + (ptrdiff_t)r0 * f.Wp + c0;
         const float2u a = *reinterpret_cast<const float2u*>(base);
         const float2u b = *reinterpret_cast<const float2u*>(base + f.Wp);
         p[0] = a.x; p[1] = a.y; p[2] = b.x; p[3] = b.y;
     } else {
-        const int ra = clampi(r0, 0, f.H - 1), rb = clampi(r0 + 1, 0, f.H - 1);
-        const int ca = clampi(c0, 0, f.W - 1), cb = clampi(c0 + 1, 0, f.W - 1);
-        p[0] = f.base[frame_index(f, ra, ca)]; p[1] = f.base[frame_index(f, ra, cb)];
-        p[2] = f.base[frame_index(f, rb, ca)]; p[3] = f.base[frame_index(f, rb, cb)];
+        p[0] = f.base[frame_index(f, r0, c0)]; p[1] = f.base[frame_index(f, r0, c0 + 1)];
+        p[2] = f.base[frame_index(f, r0 + 1, c0)]; p[3] = f.base[frame_index(f, r0 + 1, c0 + 1)];
     }
 }
 __device__ __forceinline__ void bilinear_patch(const float (&p)[4], float ay, float ax, float& E, float& Erow, float& Ecol) {

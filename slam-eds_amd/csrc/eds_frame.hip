@@ -97,15 +97,14 @@ __global__ void k_sumsq(const double* __restrict__ src, size_t n, double* __rest
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
 }
-// frame / ||frame||_F -> fp32 in the handle's layout (padded with replicated borders, optionally 4x4-tiled)
+// frame / ||frame||_F -> fp32 in the handle's layout (padding and margin filled with the nearest border pixel)
 __global__ void k_store(const double* __restrict__ src, const double* __restrict__ sumsq, float* __restrict__ dst, int H, int W,
                         int Hp, int Wp, int tiled, int normalise) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= Wp) return;
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+    if (c >= Wp - EDS_FRAME_MARGIN) return;
     const double inv = normalise ? 1.0 / sqrt(*sumsq) : 1.0;     // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
-    const double v = src[(size_t)min(r, H - 1) * W + min(c, W - 1)] * inv;
-    const size_t o = tiled ? ((size_t)((r >> 2) * (Wp >> 2) + (c >> 2)) * 16 + ((r & 3) << 2) + (c & 3)) : ((size_t)r * Wp + c);
-    dst[o] = (float)v;
+    const double v = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
+    dst[eds_frame_index(r, c, Wp, tiled)] = (float)v;
 }
 
 }  // namespace

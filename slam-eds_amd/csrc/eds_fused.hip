@@ -68,9 +68,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    FrameView frame;
-    frame.base = A.frame + (size_t)slot * A.Hp * A.Wp;
-    frame.H = A.H; frame.W = A.W; frame.Hp = A.Hp; frame.Wp = A.Wp; frame.TW = A.Wp >> 2; frame.tiled = A.tiled;
+    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];

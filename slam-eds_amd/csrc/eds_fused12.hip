@@ -26,8 +26,10 @@ using namespace edsd;
 
 #define EDS12_THREADS 512
 #define EDS12_WAVES (EDS12_THREADS / 64)
-#define EDS12_CACHE_CAP 2048
-#define EDS12_NACC 96
+#ifndef EDS12_MFMA_F64
+#define EDS12_MFMA_F64 1
+#endif
+#define EDS12_CACHE_CAP 1536       // 96 KB of patches: the rest of the LDS holds the MFMA staging rows and the solver
 
 template <int SAMPLING, int PPT>
 __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
@@ -38,27 +40,28 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
     const int tid = threadIdx.x, nthr = EDS12_THREADS;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
-    constexpr int HALF = PPT > 1 ? PPT / 2 : 1;          // gathers in flight per lane (register budget: 2 x 16 taps)
+    constexpr int HALF = PPT > 1 ? PPT / 2 : 1;          // points whose gathers are in flight together, per lane
     __shared__ edss::Solver12 sv;
     __shared__ edss::Sums12Dev sums;
     __shared__ edsc::Work12 work;
     __shared__ double s_pose[EDS_POSE_STRIDE];
-    __shared__ float s_red[EDS12_WAVES][EDS_RED_K12];
+    __shared__ float s_stage[EDS12_WAVES][64 * 17];   // per wavefront: 64 rows [J | r] padded to 16 columns, stride 17 (bank-conflict-free)
     __shared__ int s_state;            // 0: iterate, 2: done
     __shared__ int s_accept;           // the evaluation just consumed became the accepted point
     __shared__ float s_patch[NTAP][EDS12_CACHE_CAP];
     __shared__ int s_cell[EDS12_CACHE_CAP];
+    __shared__ double s_G[EDS_DEV_MAX_BLOCKS * 36];   // per-block Gram matrices (constant per keyframe): read by every pose-block refill
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
-    const double* __restrict__ G = A.G + (size_t)slot * EDS_MAX_BLOCKS * 36;
+    const double* __restrict__ Gg = A.G + (size_t)slot * EDS_MAX_BLOCKS * 36;
+    const double* G = s_G;
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    FrameView frame;
-    frame.base = A.frame + (size_t)slot * A.Hp * A.Wp;
-    frame.H = A.H; frame.W = A.W; frame.Hp = A.Hp; frame.Wp = A.Wp; frame.TW = A.Wp >> 2; frame.tiled = A.tiled;
+    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
 
     if (wave == 0) {
+        for (int k = lane; k < nb * 36; k += 64) s_G[k] = Gg[k];
         if (lane == 0) {
             const EdsFusedIn& I = in[slot];
             for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
@@ -87,10 +90,9 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
         kgx[j] = A.gx[o]; kgy[j] = A.gy[o];
         if (i < EDS12_CACHE_CAP) s_cell[i] = 0x7fffffff;
     }
-    auto in_block = [&](int j, int blk) -> bool {
-        const int i = tid + j * nthr;
-        return i < N && block_of(i, ne, nb) == blk;
-    };
+    for (int k = tid; k < EDS12_WAVES * 64 * 17; k += nthr) (&s_stage[0][0])[k] = 0.0f;     // columns 13..15 stay zero for good
+    for (int k = tid; k < (int)(sizeof(sums) / sizeof(double)); k += nthr)
+        if (k > 0) reinterpret_cast<double*>(&sums)[k] = 0.0;                               // word 0 holds nb
     float rcand[PPT], racc[PPT];        // residuals of the evaluation in flight / of the accepted point
 #pragma unroll
     for (int j = 0; j < PPT; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
@@ -103,124 +105,153 @@ __global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A,
 #else
 #define EDS12_STAMP(k) do { } while (0)
 #endif
+#if EDS12_MFMA_F64
+    typedef double acc4 __attribute__((ext_vector_type(4)));     // v_mfma_f64_16x16x4_f64: products and sums in fp64
+#else
+    typedef float acc4 __attribute__((ext_vector_type(4)));      // v_mfma_f32_16x16x4_f32: exact fp32 fmaf chain
+#endif
+    float* const stage = &s_stage[wave][0];
+    // adds this wavefront's 16x16 tile (rows/cols 0..11: J^T J, column 12: J^T r, [12][12]: sum r^2) to block b's sums
+    auto flush = [&](const acc4& C, int b) {
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#if EDS12_MFMA_F64
+            const int row = (lane >> 4) + 4 * r;        // C/D layout of the f64 form
+#else
+            const int row = (lane >> 4) * 4 + r;
+#endif
+            const double v = (double)C[r];
+            if (row < 12 && col < 12) unsafeAtomicAdd(&sums.H[b][12 * row + col], v);
+            else if (row < 12 && col == 12) unsafeAtomicAdd(&sums.g[b][row], v);
+            else if (row == 12 && col == 12) unsafeAtomicAdd(&sums.s[b], v);
+        }
+    };
     for (;;) {
         PoseF ps;
         load_pose(s_pose, ps);
         float vf[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
-        for (int blk = 0; blk < nb; ++blk) {
-            const float inv_n = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk]);
-            float gvec[6];
+        acc4 C = {0, 0, 0, 0}, C2 = {0, 0, 0, 0};
+        int cb = -1;                    // residual block the tile C currently belongs to (wave-uniform)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) gvec[k] = uniformf((float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * blk + 1 + k]);
-            float acc[EDS12_NACC];          // 91 live sums: a 64-wide and a 32-wide butterfly instead of one 128-wide
+        for (int h0 = 0; h0 < PPT; h0 += HALF) {
+            // phase A: project this half's points, probe the patch cache, put every missing gather in flight
+            PointGeom pg[HALF];
+            float tap[HALF][NTAP];
+            bool miss[HALF];
 #pragma unroll
-            for (int j = 0; j < EDS12_NACC; ++j) acc[j] = 0.0f;
-#pragma unroll
-            for (int h0 = 0; h0 < PPT; h0 += HALF) {
-                // phase A: project this half's points, probe the patch cache, put every missing gather in flight
-                PointGeom pg[HALF];
-                float tap[HALF][NTAP];
-                bool miss[HALF];
-#pragma unroll
-                for (int jj = 0; jj < HALF; ++jj) {
-                    const int j = h0 + jj;
-                    const int i = tid + j * nthr;
-                    miss[jj] = false;
-                    if (!in_block(j, blk)) continue;
-                    project_point(ps, kf[j], pg[jj]);
-                    const bool cached = i < EDS12_CACHE_CAP;
-                    const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
-                    miss[jj] = !(cached && s_cell[i] == key);
-                    if (miss[jj]) {
-                        if (SAMPLING == 0) load_patch16(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[16]>(tap[jj]));
-                        else load_patch4(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[4]>(tap[jj]));
-                        if (cached) s_cell[i] = key;
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][i];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // phase B: refill the cache, residual, 1x12 row (closed forms of SURVEY §8a), running sums
-#pragma unroll
-                for (int jj = 0; jj < HALF; ++jj) {
-                    const int j = h0 + jj;
-                    const int i = tid + j * nthr;
-                    if (!in_block(j, blk)) continue;
-                    if (miss[jj] && i < EDS12_CACHE_CAP) {
-#pragma unroll
-                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
-                    }
-                    // pin this point's arithmetic behind the previous point's: without it the compiler interleaves the
-                    // unrolled bodies and the live temporaries of PPT points overflow the register file
-                    asm volatile("" : "+v"(pg[jj].ax), "+v"(pg[jj].ay), "+v"(acc[0]));
-                    float E, Er, Ec;
-                    if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                    else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                    PointProj pp;
-                    finish_point(ps, pg[jj], E, Er, Ec, pp);
-                    const float w = kw[j];
-                    float ka[6];
-                    model_row(kf[j].x, kf[j].y, kf[j].rhop - 1e-5f, kgx[j], kgy[j], ka);
-                    float m = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) m += ka[k] * vf[k];
-                    const float r = w * (m * inv_n - pp.E);
-                    float J[12];
-                    J[0] = -w * pp.g0; J[1] = -w * pp.g1; J[2] = -w * pp.g2;
-                    // quaternion local: -2 w (R X) x gradE_P with R X = P - t
-                    const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
-                    const float w2 = -2.0f * w;
-                    J[3] = w2 * (ry * pp.g2 - rz * pp.g1);
-                    J[4] = w2 * (rz * pp.g0 - rx * pp.g2);
-                    J[5] = w2 * (rx * pp.g1 - ry * pp.g0);
-                    // velocity local: w (a/n - m (G v)/n^3) (I - v v^T/|v|^2)/|v|; the projector is read from LDS
-                    // (wave-uniform broadcast) rather than held in 36 registers
-                    float row[6];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) row[k] = w * (ka[k] * inv_n - m * gvec[k]);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        float s = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) s += row[k] * (float)s_pose[EDS_PB_PV + 6 * k + c];
-                        J[6 + c] = s;
-                    }
-                    accumulate_normal<12>(acc, J, r, 1.0f, r * r);
-                    rcand[j] = r;
-                    __builtin_amdgcn_sched_barrier(0);      // keep one point's temporaries from overlapping the next one's
-                }
-            }
-            EDS12_STAMP(0);
-            wave_reduce_scatter<64>(acc, lane);
-            wave_reduce_scatter<32>(acc + 64, lane);
-            s_red[wave][wave_red_index<64>(lane, 0)] = acc[0];
-            if (lane < 32) s_red[wave][64 + wave_red_index<32>(lane, 0)] = acc[64];
-            __syncthreads();
-            if (tid < EDS_RED_N12) {            // cross-wavefront sum in fp64, unpacked into the solver's input
-                double s = 0.0;
-#pragma unroll
-                for (int wv = 0; wv < EDS12_WAVES; ++wv) s += (double)s_red[wv][tid];
-                if (tid < 78) {
-                    int a = 0, rem = tid;
-                    while (rem >= 12 - a) { rem -= 12 - a; ++a; }
-                    const int b = a + rem;
-                    sums.H[blk][12 * a + b] = s;
-                    sums.H[blk][12 * b + a] = s;
-                } else if (tid < 90) {
-                    sums.g[blk][tid - 78] = s;
+            for (int jj = 0; jj < HALF; ++jj) {
+                const int j = h0 + jj;
+                const int i = tid + j * nthr;
+                project_point(ps, kf[j], pg[jj]);
+                const bool cached = i < EDS12_CACHE_CAP;
+                const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
+                miss[jj] = !(cached && s_cell[i] == key);
+                if (miss[jj]) {
+                    if (SAMPLING == 0) load_patch16(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[16]>(tap[jj]));
+                    else load_patch4(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[4]>(tap[jj]));
+                    if (cached) s_cell[i] = key;
                 } else {
-                    sums.s[blk] = s;
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][i];
                 }
             }
-            __syncthreads();
-            EDS12_STAMP(1);
+            // phase B: refill the cache; residual and 1x12 row (closed forms of SURVEY §8a); then the wavefront's 64 rows
+            // go through LDS into the operand layout of v_mfma_f32_16x16x4_f32, which forms X^T X for X = [J | r] (64 x 13)
+            // with four accumulator registers per lane — instead of 91 running sums per lane and a 91-value butterfly.
+            // The matrix core is used as a register-free reduction primitive here (exact fp32, same as an fmaf chain),
+            // not for throughput: the kernel stays bound by the scattered frame reads.
+#pragma unroll
+            for (int jj = 0; jj < HALF; ++jj) {
+                const int j = h0 + jj;
+                const int i = tid + j * nthr;
+                const bool valid = i < N;
+                if (miss[jj] && i < EDS12_CACHE_CAP) {
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
+                }
+                float E, Er, Ec;
+                if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                PointProj pp;
+                finish_point(ps, pg[jj], E, Er, Ec, pp);
+                // residual blocks touched by this wavefront's 64 consecutive points (usually one: constants then wave-uniform)
+                const int i_first = j * nthr + wave * 64;
+                const int i_last = (i_first + 63 < N) ? i_first + 63 : N - 1;
+                const int b_lo = edsc::uniform_int(block_of(i_first < N ? i_first : 0, ne, nb));
+                const int b_hi = edsc::uniform_int(block_of(i_last > 0 ? i_last : 0, ne, nb));
+                int myb = b_lo;
+                float inv_n, gv[6];
+                if (b_lo == b_hi) {
+                    const double* bk = s_pose + EDS_PB_BLK + EDS_PB_BLK_STRIDE * b_lo;
+                    inv_n = uniformf((float)bk[0]);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) gv[k] = uniformf((float)bk[1 + k]);
+                } else {
+                    myb = block_of(valid ? i : 0, ne, nb);
+                    const double* bk = s_pose + EDS_PB_BLK + EDS_PB_BLK_STRIDE * myb;
+                    inv_n = (float)bk[0];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) gv[k] = (float)bk[1 + k];
+                }
+                const float w = kw[j];              // 0 for out-of-range lanes: their rows vanish
+                float ka[6];
+                model_row(kf[j].x, kf[j].y, kf[j].rhop - 1e-5f, kgx[j], kgy[j], ka);
+                float m = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) m += ka[k] * vf[k];
+                float x[13];
+                x[12] = w * (m * inv_n - pp.E);
+                x[0] = -w * pp.g0; x[1] = -w * pp.g1; x[2] = -w * pp.g2;
+                // quaternion local: -2 w (R X) x gradE_P with R X = P - t
+                const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];
+                const float w2 = -2.0f * w;
+                x[3] = w2 * (ry * pp.g2 - rz * pp.g1);
+                x[4] = w2 * (rz * pp.g0 - rx * pp.g2);
+                x[5] = w2 * (rx * pp.g1 - ry * pp.g0);
+                // velocity part WITHOUT the local-parameterisation projector (I - v v^T/|v|^2)/|v|: that factor is the same
+                // for every point, so the solver applies it to the 12 x 12 sums (edsc::coop12_on_eval) instead of 36 FMAs here
+#pragma unroll
+                for (int k = 0; k < 6; ++k) x[6 + k] = w * (ka[k] * inv_n - m * gv[k]);
+                rcand[j] = x[12];
+                if (i_first < N) {
+                    for (int b = b_lo; b <= b_hi; ++b) {
+                        if (b != cb) {
+                            if (cb >= 0) flush(C + C2, cb);
+                            C = acc4{0, 0, 0, 0}; C2 = acc4{0, 0, 0, 0};
+                            cb = b;
+                        }
+                        const bool on = valid && myb == b;
+#pragma unroll
+                        for (int c = 0; c < 13; ++c) stage[lane * 17 + c] = on ? x[c] : 0.0f;
+                        EDS_WSYNC();
+#pragma unroll
+                        for (int mm = 0; mm < 16; mm += 2) {       // two independent accumulator chains
+                            const float a0 = stage[(4 * mm + (lane >> 4)) * 17 + (lane & 15)];
+                            const float a1 = stage[(4 * mm + 4 + (lane >> 4)) * 17 + (lane & 15)];
+#if EDS12_MFMA_F64
+                            C = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0, (double)a0, C, 0, 0, 0);
+                            C2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1, (double)a1, C2, 0, 0, 0);
+#else
+                            C = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, a0, C, 0, 0, 0);
+                            C2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, a1, C2, 0, 0, 0);
+#endif
+                        }
+                        EDS_WSYNC();
+                    }
+                }
+            }
         }
+        if (cb >= 0) flush(C + C2, cb);
+        EDS12_STAMP(0);
+        __syncthreads();
+        EDS12_STAMP(1);
         if (wave == 0) {                        // the LM state machine, spread over this wavefront (eds_solver12_coop.hpp)
-            edsc::coop12_on_eval(sv, sums, work, lane);
+            edsc::coop12_on_eval(sv, sums, work, s_pose, lane);
             const int done = edsc::uniform_int(sv.done);
+            for (int k = 1 + lane; k < (int)(sizeof(sums) / sizeof(double)); k += 64) reinterpret_cast<double*>(&sums)[k] = 0.0;   // consumed
             if (!done) edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, G, nb, s_pose, lane);
 #ifdef EDS_FUSED_STAMPS
             if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); work.st[6] += n_ - work.st_t; work.st_t = n_; }

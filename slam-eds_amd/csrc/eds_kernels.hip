@@ -19,10 +19,7 @@
 using namespace edsd;
 
 __device__ __forceinline__ FrameView frame_view(const EdsArrays& A, int slot) {
-    FrameView f;
-    f.base = A.frame + (size_t)slot * A.Hp * A.Wp;
-    f.H = A.H; f.W = A.W; f.Hp = A.Hp; f.Wp = A.Wp; f.TW = A.Wp >> 2; f.tiled = A.tiled;
-    return f;
+    return make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
 }
 
 // linear workgroup id -> (slot, chunk); all chunks of a slot share id % 8 (one XCD)

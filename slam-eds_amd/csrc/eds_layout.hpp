@@ -11,7 +11,9 @@
 //                         (PhotometricError.hpp:114-122,136-137 use idp without eps)
 //   gx,gy,w f32 [B][Np]   log-image gradient and point weight (KeyFrame.hpp:80,90)
 //   mhat    f32 [B][Np]   normalised model a_i.v / n_block  (6-DoF solvers: velocity is fixed)
-//   frame   f32 [B][H*W]  brightness-increment frame, row-major (EventFrame.hpp:59)
+//   frame   f32 [B][Hp*Wp]  brightness-increment frame (EventFrame.hpp:59): H x W padded to multiples of 4 PLUS a margin of
+//                         EDS_FRAME_MARGIN replicated pixels on every side, in 4x4-pixel tiles of one 64-byte sector each
+//                         (or row-major); with the margin every clamped 4x4 neighbourhood is a plain interior read
 //   r       f32 [B][Np]   residuals of the last pass
 //   J       f32 [12][B][Np]  Jacobian planes (6 used by the pose-only solvers) — column-major
 //                         per point so the residual/Jacobian kernel's stores are coalesced
@@ -21,6 +23,7 @@
 //   part    f64 [B][nseg][EDS_RED_K]  per-workgroup partial sums of the reduction kernel
 //   ncstat  f64 [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC only: per block 1/||E||, then sum_j E_j J'_j (6) / ||E||^3
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define EDS_MAX_BLOCKS 16          // upper bound on options.num_threads residual blocks
@@ -51,3 +54,17 @@
 #define EDS_RED_N12 91             // 78 + 12 + 1
 #define EDS_RED_K12 128
 #define EDS_RED_K 128              // stride of the partial-sum records
+
+// ---- frame allocation ------------------------------------------------------------------------------------------
+#define EDS_FRAME_MARGIN 4         // replicated border pixels (= one tile) on every side of the padded frame
+#if defined(__HIPCC__)
+#define EDS_LAYOUT_HD __host__ __device__
+#else
+#define EDS_LAYOUT_HD
+#endif
+// padded extent of a frame dimension, and the element index of LOGICAL pixel (r, c), -MARGIN <= r < Hp - MARGIN
+EDS_LAYOUT_HD static inline int eds_frame_extent(int n) { return ((n + 3) & ~3) + 2 * EDS_FRAME_MARGIN; }
+EDS_LAYOUT_HD static inline size_t eds_frame_index(int r, int c, int Wp, int tiled) {
+    const int rr = r + EDS_FRAME_MARGIN, cc = c + EDS_FRAME_MARGIN;
+    return tiled ? ((size_t)((rr >> 2) * (Wp >> 2) + (cc >> 2)) * 16 + ((rr & 3) << 2) + (cc & 3)) : ((size_t)rr * Wp + cc);
+}

@@ -28,6 +28,7 @@ enum { M_RETURN = 0, M_LIN_ITER0 = 1, M_LIN_ACCEPT = 2, M_ADVANCE = 3, M_LOOP = 
 
 struct Work12 {                 // LDS scratch of the cooperative solver
     double y[12], t[12];
+    double T[144];              // A P while the velocity columns are being projected
     double r0[EDS_DEV_MAX_BLOCKS], r1[EDS_DEV_MAX_BLOCKS];
     double cost, rel;
     int mode, ok, accepted;     // accepted: the evaluation just consumed became the accepted point
@@ -52,7 +53,10 @@ __device__ __forceinline__ double bcast(double x, int src) {
 
 // edss::Solver12::on_eval + advance, cooperatively.  On return either sv.done is set, or (sv.cp, sv.cq, sv.cv) is
 // the next point to evaluate (sv.final_pass tells whether that evaluation is the residual pass at the solution).
-__device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const int lane) {
+// `pb` is the pose block the sums were evaluated at: the persistent kernel accumulates the velocity columns WITHOUT the
+// local-parameterisation factor Pv = (I - v v^T/|v|^2)/|v| (identical for all points), so linearising applies
+// J^T J -> P^T (J^T J) P, J^T r -> P^T (J^T r) with P = blockdiag(I_6, Pv) here, once, on the 12 x 12 sums.
+__device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
     using namespace edss;
     const int nb = S.nb;
 #ifdef EDS_FUSED_STAMPS
@@ -132,6 +136,38 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
             }
             EDS_WSYNC();
             return;
+        }
+        {
+            const double* Pv = pb + EDS_PB_PV;
+            for (int e = lane; e < 144; e += 64) {                  // W.T = A P
+                const int i = e / 12, j = e - 12 * i;
+                double t = sv.A[e];
+                if (j >= 6) {
+                    t = 0.0;
+                    for (int c = 0; c < 6; ++c) t += sv.A[12 * i + 6 + c] * Pv[6 * c + (j - 6)];
+                }
+                W.T[e] = t;
+            }
+            double gp = 0.0;
+            if (lane < 12) {
+                gp = sv.g[lane];
+                if (lane >= 6) {
+                    gp = 0.0;
+                    for (int c = 0; c < 6; ++c) gp += Pv[6 * c + (lane - 6)] * sv.g[6 + c];
+                }
+            }
+            EDS_WSYNC();
+            for (int e = lane; e < 144; e += 64) {                  // A = P^T W.T
+                const int i = e / 12, j = e - 12 * i;
+                double t = W.T[e];
+                if (i >= 6) {
+                    t = 0.0;
+                    for (int c = 0; c < 6; ++c) t += Pv[6 * c + (i - 6)] * W.T[12 * (6 + c) + j];
+                }
+                sv.A[e] = t;
+            }
+            if (lane < 12) sv.g[lane] = gp;
+            EDS_WSYNC();
         }
         if (!sv.have_scale && lane < 12) sv.scale[lane] = 1.0 / (1.0 + sqrt(sv.A[13 * lane]));
         EDS_WSYNC();
