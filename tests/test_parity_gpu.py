@@ -154,11 +154,9 @@ def test_pose_solvers_vs_oracle(gpu, capi, synth, po, solver, ex):
 
 @pytest.mark.parametrize("ex", [0, 1], ids=["host", "device"])
 @pytest.mark.parametrize("nb,loss", [(1, 0), (2, 1), (8, 2), (12, 1)])
-def test_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex, monkeypatch):
+def test_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
     """The reference's own problem (12 local parameters, Ceres-LM): host-driven loop and the persistent
     kernel (which handles up to 8 residual blocks; 12 blocks exercise its documented host fall-back)."""
-    if ex == 1:
-        monkeypatch.setenv("EDS_REF12_EXEC", "device")     # a single alignment would otherwise take the host loop
     al = synth.make_alignment(4321, start="ctor")          # v0 = normalize(0.001 * ones), Tracker.cpp:45-46
     ref = po.Oracle(al, num_blocks=nb, loss_type=loss, loss_param=0.2, max_num_iterations=15).solve_lm(al.p0, al.q0, al.v0)
     h = make_handle(capi, al, exec=ex, solver=capi.SOLVER_REF12, num_blocks=nb, loss_type=loss,
