@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--sampling", choices=["bicubic", "bilinear"], default="bicubic")
     ap.add_argument("--solver", choices=["lm6", "gn6"], default="lm6")
+    ap.add_argument("--no-ref12", dest="no_ref12", action="store_true", help="skip the informational REF12 measurement")
     ap.add_argument("--lambda0", type=float, default=0.01, help="initial LM6 damping (DSO template: 0.01)")
     ap.add_argument("--exec", dest="exec_", choices=["device", "host"], default="device")
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic alignments (replicated to fill the batch)")
@@ -221,6 +222,25 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj,
         }
+        if world == 1 and a.exec_ == "device" and N <= 2048 and not a.no_ref12:
+            # the reference's own problem on the same batch (12 local parameters, Ceres-LM rules; one residual block, no
+            # loss): informational, outside the timed region
+            h.set_config(capi.default_config(device=0, sampling=cfg.sampling, solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE,
+                                             max_num_iterations=a.iters, num_blocks=1))
+            r_ms, r_dev = [], []
+            for k in range(4):
+                h.set_states(0, p0, q0, v0)
+                t1 = time.perf_counter()
+                h.optimize_batch(0, 0, B, sync=True)
+                r_ms.append(1e3 * (time.perf_counter() - t1))
+                r_dev.append(h.info(0)["device_time_us"] * 1e-3)
+            rt = h.results(0, B)
+            r_it = float(np.mean(rt[:, 14]))
+            out["reference_problem"] = {"solver": "ref12", "lm_iterations_per_s": B * r_it / (float(np.median(r_ms[1:])) * 1e-3),
+                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_fused12_kernel",
+                                        "kernel_ms": float(np.median(r_dev[1:])), "iterations_per_alignment": r_it,
+                                        "success_fraction": float(np.mean(rt[:, 15]))}
+            h.set_config(cfg)
         if world == 1 and not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(als[:min(8, distinct)], a.iters, a.sampling, a.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
