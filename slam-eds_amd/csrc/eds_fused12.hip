@@ -24,15 +24,24 @@
 
 using namespace edsd;
 
+#ifndef EDS12_THREADS
 #define EDS12_THREADS 512
+#endif
 #define EDS12_WAVES (EDS12_THREADS / 64)
+#ifndef EDS12_MIN_WAVES_PER_SIMD
+#define EDS12_MIN_WAVES_PER_SIMD 2          // 8 wavefronts per CU: one 512-thread workgroup, or two of 256 threads
+#endif
+#define EDS12_MAX_POINTS 2048
+#define EDS12_MAX_PPT (EDS12_MAX_POINTS / EDS12_THREADS)
 #ifndef EDS12_MFMA_F64
 #define EDS12_MFMA_F64 1
 #endif
-#define EDS12_CACHE_CAP 1536       // 96 KB of patches: the rest of the LDS holds the MFMA staging rows and the solver
+#ifndef EDS12_CACHE_CAP
+#define EDS12_CACHE_CAP 1536
+#endif                             // 96 KB of patches: the rest of the LDS holds the MFMA staging rows and the solver
 
 template <int SAMPLING, int PPT>
-__global__ __launch_bounds__(EDS12_THREADS) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
+__global__ __launch_bounds__(EDS12_THREADS, EDS12_MIN_WAVES_PER_SIMD) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                                   EdsFused12Out* __restrict__ out, int first, int iters,
                                                                   int loss_type, double loss_a, double ftol, double gtol,
                                                                   double ptol, int nb) {
@@ -301,7 +310,7 @@ bool eds_fused12_supported(const eds_trk* h, int first, int count) {
     int nb = h->cfg.num_blocks < 1 ? 1 : h->cfg.num_blocks;
     if (nb > EDS_DEV_MAX_BLOCKS) return false;
     for (int s = first; s < first + count; ++s)
-        if (h->slots[s].N > 4 * EDS12_THREADS) return false;
+        if (h->slots[s].N > EDS12_MAX_POINTS) return false;
     return true;
 }
 
@@ -331,7 +340,12 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
                        h->cfg.parameter_tolerance, nb)
     if (ppt <= 1) { if (bicubic) EDS_LAUNCH12(0, 1); else EDS_LAUNCH12(1, 1); }
     else if (ppt <= 2) { if (bicubic) EDS_LAUNCH12(0, 2); else EDS_LAUNCH12(1, 2); }
+#if EDS12_MAX_PPT >= 8
+    else if (ppt <= 4) { if (bicubic) EDS_LAUNCH12(0, 4); else EDS_LAUNCH12(1, 4); }
+    else { if (bicubic) EDS_LAUNCH12(0, 8); else EDS_LAUNCH12(1, 8); }
+#else
     else { if (bicubic) EDS_LAUNCH12(0, 4); else EDS_LAUNCH12(1, 4); }
+#endif
 #undef EDS_LAUNCH12
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();

@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("eds_fused6_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
+    for k in ("eds_fused6_kernel", "eds_fused12_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
         if k in name:
             return k + name[name.find("<"):name.find(">") + 1] if "<" in name else k
     return name[:40]
@@ -73,7 +73,9 @@ lines += ["",
           "  `--pmc FETCH_SIZE`: 64 Mi random locations -> 4.32 GB whether 16, 32 or 64 B are read per location), i.e. correctly,",
           "  except that two sectors of one 128-B line fetched together are tallied once;",
           "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
-          "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound."]
+          "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound.",
+          "`eds_fused12_kernel` (the informational REF12 measurement of bench.py) writes far more than its 8 KB of residuals per",
+          "alignment: the excess is register-spill scratch traffic (696 B per lane, DESIGN.md 3.4)."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 print("\n".join(lines))
