@@ -117,9 +117,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    # test hooks (not used by the driver): EDS_BENCH_BACKEND=gloo and EDS_BENCH_DEVICE=<ordinal> let several ranks share
+    # one GPU, so that the sharded path can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("EDS_BENCH_BACKEND", "nccl")
+    if "EDS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["EDS_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     capi = importlib.import_module("slam-eds_amd.capi")
     synth = importlib.import_module("slam-eds_amd.synth")
     batchmod = importlib.import_module("slam-eds_amd.batch")
@@ -146,7 +154,7 @@ def main():
     p0 = np.stack([als[b % distinct].p0 for b in range(B)])
     q0 = np.stack([als[b % distinct].q0 for b in range(B)])
     v0 = np.stack([als[b % distinct].v0 for b in range(B)])
-    dev = torch.device("cuda", local_rank) if world > 1 else None
+    dev = torch.device("cuda", local_rank) if (world > 1 and backend == "nccl") else None
 
     def step():
         h.set_states(0, p0, q0, v0)                  # same start every step (host-side, 104 B per slot)
@@ -169,7 +177,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = 1e3 * elapsed / a.steps
