@@ -47,6 +47,10 @@ int  eds_fused_fetch_trace(eds_trk* h, int slot);                    // D2H of o
 bool eds_fused12_supported(const eds_trk* h, int first, int count);
 int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);
+struct EdsArrays;
+// eds_stream12.hip: 256-thread streaming variant (two alignments per CU; any number of points)
+void eds_stream12_launch(const EdsArrays& A, int sampling, const EdsFusedIn* d_in, EdsFused12Out* d_out, int first, int count, int iters,
+                         int loss_type, double loss_a, double ftol, double gtol, double ptol, int nb, hipStream_t st);
 
 // ---- event-frame construction on device (eds_frame.hip) ---------------------------------------------------
 struct EdsFrameBuffers {

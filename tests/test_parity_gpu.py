@@ -403,10 +403,12 @@ def test_coarse_to_fine_pyramid_levels(gpu, capi, synth, po):
         p, q = pg, qg
 
 
-def test_reference_problem_batched_on_device(gpu, capi, synth, po):
-    """B = 40 reference-problem solves in one launch of the persistent REF12 kernel (the default route
-    for batches), each checked against the oracle's Ceres-LM restatement."""
-    als = [synth.make_alignment(7000 + b, H=240, W=320, N=1200 + 13 * b) for b in range(40)]
+@pytest.mark.parametrize("B", [40, 104], ids=["resident-kernel", "streaming-kernel"])
+def test_reference_problem_batched_on_device(gpu, capi, synth, po, B):
+    """A batch of reference-problem solves in one launch of a persistent REF12 kernel — the register-resident one
+    below 96 alignments, the streaming one (two alignments per CU) from there on — each checked against the oracle's
+    Ceres-LM restatement."""
+    als = [synth.make_alignment(7000 + b, H=240, W=320, N=1200 + (13 * b) % 800) for b in range(B)]
     cfg = capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=2, loss_type=capi.LOSS_HUBER,
                               loss_param=0.25, max_num_iterations=8)
     hb = capi.Handle(cfg, len(als), max(a.N for a in als), 240, 320)
@@ -429,6 +431,22 @@ def test_reference_problem_batched_on_device(gpu, capi, synth, po):
         er = po.Oracle(a, num_blocks=2).eval12(table[b, 0:3], table[b, 3:7], table[b, 7:13], jac=False)["r_raw"]
         assert np.abs(r - er).max() <= TOL_R * np.abs(er).max()
     hb.close()
+
+
+def test_reference_problem_more_than_2048_points_on_device(gpu, capi, synth, po):
+    """Beyond 2 048 points the streaming REF12 kernel takes over (constants re-read per evaluation, any N)."""
+    al = synth.make_alignment(4555, N=5000)
+    ref = po.Oracle(al, num_blocks=3, loss_type=po.LOSS_CAUCHY, loss_param=0.3, max_num_iterations=8).solve_lm(al.p0, al.q0, al.v0)
+    h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=3, loss_type=capi.LOSS_CAUCHY,
+                    loss_param=0.3, max_num_iterations=8)
+    p, q, v, info = h.optimize(0)
+    assert info["success"] and info["device_time_us"] > 0 and info["num_points"] == 5000
+    assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
+    assert info["final_cost"] == pytest.approx(ref["final_cost"], rel=1e-4)
+    er = po.Oracle(al, num_blocks=3).eval12(p, q, v, jac=False)["r_raw"]
+    assert np.abs(h.residuals(0) - er).max() <= TOL_R * np.abs(er).max()
+    h.close()
 
 
 def test_reference_problem_device_equals_host_loop_on_hard_starts(gpu, capi, synth, po, monkeypatch):
