@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="alignments per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=4096, help="alignments per GPU (weak scaling)")
     ap.add_argument("--iters", type=int, default=10, help="tracker iterations per alignment")
     ap.add_argument("--points", type=int, default=2000)
     ap.add_argument("--height", type=int, default=480)
@@ -196,11 +196,12 @@ def main():
         if a.exec_ == "device":
             k_ms = float(np.mean(dev_us)) * 1e-3
             ach = B * N * passes * per_pt / (k_ms * 1e-3) / 1e9
-            roof = {"kernel": "eds_fused6_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kname = "eds_stream6_kernel" if (B >= 1536 and N <= 2048) else "eds_fused6_kernel"     # the rule of eds_fused_solve
+            roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": B * N * passes * per_pt,
                     "note": f"{per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch (J never materialised)"}
-            t = pmc_traffic("eds_fused6_kernel", a)
+            t = pmc_traffic(kname, a)
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
@@ -245,7 +246,7 @@ def main():
             rt = h.results(0, B)
             r_it = float(np.mean(rt[:, 14]))
             out["reference_problem"] = {"solver": "ref12", "lm_iterations_per_s": B * r_it / (float(np.median(r_ms[1:])) * 1e-3),
-                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_fused12_kernel",
+                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_stream12_kernel" if B >= 96 else "eds_fused12_kernel",
                                         "kernel_ms": float(np.median(r_dev[1:])), "iterations_per_alignment": r_it,
                                         "success_fraction": float(np.mean(rt[:, 15]))}
             h.set_config(cfg)

@@ -366,7 +366,14 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const double tau = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
     const int damped = h->cfg.solver == EDS_SOLVER_LM6;
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
+    // streaming variant (eds_stream6.hip: two alignments per CU, solver / reduction overlapped with the other's points):
+    // pays off once a launch keeps every CU busy for several rounds
+    bool stream = count >= 1536 && maxN <= 2048;
+    if (const char* ev = getenv("EDS_LM6_KERNEL")) stream = std::strcmp(ev, "stream") == 0;     // tuning knob: "resident" | "stream"
     hipEventRecord(h->ev0, h->st);
+    if (stream) {
+        eds_stream6_launch(A, h->cfg.sampling, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
+    } else {
     // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
     // lane variant needs to keep 4 x 16 taps + constants in registers without spilling
 #define EDS_LAUNCH_FUSED(S, P, T)                                                                                              \
@@ -379,6 +386,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         case 2: if (bicubic) EDS_LAUNCH_FUSED_T(0, 2); else EDS_LAUNCH_FUSED_T(1, 2); break;
         case 4: if (bicubic) EDS_LAUNCH_FUSED_T(0, 4); else EDS_LAUNCH_FUSED_T(1, 4); break;
         default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0); else EDS_LAUNCH_FUSED_T(1, 0); break;
+    }
     }
 #undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED

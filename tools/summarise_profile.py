@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("eds_fused6_kernel", "eds_fused12_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
+    for k in ("eds_fused6_kernel", "eds_fused12_kernel", "eds_stream6_kernel", "eds_stream12_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
         if k in name:
             return k + name[name.find("<"):name.find(">") + 1] if "<" in name else k
     return name[:40]
