@@ -74,8 +74,9 @@ lines += ["",
           "  except that two sectors of one 128-B line fetched together are tallied once;",
           "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
           "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound.",
-          "`eds_fused12_kernel` (the informational REF12 measurement of bench.py) writes far more than its 8 KB of residuals per",
-          "alignment: the excess is register-spill scratch traffic (696 B per lane, DESIGN.md 3.4)."]
+          "The streaming kernels (`eds_stream6_kernel`, `eds_stream12_kernel`: bench.py's headline and its informational REF12",
+          "measurement at this batch size) write the candidate residuals of every pass (8 KB per alignment and pass) plus the",
+          "accepted copies, which is what their WRITE_SIZE shows."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 print("\n".join(lines))
