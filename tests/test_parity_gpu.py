@@ -175,6 +175,53 @@ def test_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
     h.close()
 
 
+@pytest.mark.parametrize("solver,iters", [("lm6", 10), ("gn6", 3), ("lm6", 0)])
+@pytest.mark.parametrize("sampling", [0, 1], ids=["bicubic", "bilinear"])
+def test_streaming_pose_kernel_vs_oracle_and_resident_kernel(gpu, capi, synth, po, solver, iters, sampling, monkeypatch):
+    """eds_stream6_kernel (picked by optimize from 1 536 alignments per launch; forced here) against the oracle and
+    against the register-resident kernel, on ragged point counts, with and without per-point Huber."""
+    sv = capi.SOLVER_LM6 if solver == "lm6" else capi.SOLVER_GN6
+    als = [synth.make_alignment(6100 + b, H=240, W=320, N=n) for b, n in enumerate((1, 63, 257, 1000, 2000, 2048))]
+    als[3] = synth.make_alignment(6103, H=240, W=320, N=1000)
+    # a generic start: at the identity the projections sit exactly on pixel centres, where the bilinear gradient is
+    # discontinuous and accept / reject decisions become a coin toss between summation orders
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    P0, Q0, V0 = np.stack([ps] * len(als)), np.stack([qs] * len(als)), np.stack([a.v0 for a in als])
+    out = {}
+    for kern in ("resident", "stream"):
+        monkeypatch.setenv("EDS_LM6_KERNEL", kern)
+        for tau in (0.0, 0.01):
+            h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=sv, sampling=sampling, max_num_iterations=iters, huber_tau=tau),
+                            len(als), 2048, 240, 320)
+            for b, a in enumerate(als):
+                h.set_alignment(b, a)
+            h.set_states(0, P0, Q0, V0)
+            h.optimize_batch(0, 0, len(als))
+            tab = h.results(0, len(als))
+            out[(kern, tau)] = (tab, [h.residuals(b) if tab[b, 15] == 1.0 else None for b in range(len(als))],
+                                [h.trace(b) for b in range(len(als))])
+            h.close()
+    for tau in (0.0, 0.01):
+        (ta, ra, tra), (tb, rb, trb) = out[("resident", tau)], out[("stream", tau)]
+        for b, a in enumerate(als):
+            assert ta[b, 15] == tb[b, 15]           # a singular 6x6 system (one point, undamped) fails in both kernels alike
+            if tb[b, 15] != 1.0:
+                assert a.N < 6 and solver == "gn6"
+                continue
+            o = po.Oracle(a, sampling=sampling)
+            if solver == "lm6":
+                ref = o.pose6_lm(ps, qs, a.v0, iters=iters, lambda0=0.01, huber_tau=tau)
+                assert np.array_equal(trb[b]["accepted"], ref["accepted"]) and np.array_equal(tra[b]["accepted"], trb[b]["accepted"])
+            else:
+                ref = o.pose6_gn(ps, qs, a.v0, iters=iters, huber_tau=tau)
+            if a.N >= 257:                          # tiny problems are ill-conditioned: compare the kernels with each other only
+                assert po.se3_distance(tb[b, 0:3], tb[b, 3:7], ref["p"], ref["q"]) <= TOL_POSE
+            assert po.se3_distance(ta[b, 0:3], ta[b, 3:7], tb[b, 0:3], tb[b, 3:7]) <= (1e-6 if a.N >= 257 else 1e-3)
+            assert tb[b, 14] == iters and tb[b, 15] == 1.0
+            er = o.pose6_eval(tb[b, 0:3], tb[b, 3:7], a.v0)["r"]
+            assert rb[b].shape == (a.N,) and np.abs(rb[b] - er).max() <= TOL_R * max(np.abs(er).max(), 1e-30)
+
+
 def test_per_point_huber_1280x720(gpu, capi, synth, po):
     """BASELINE.json configs[2]: 1280x720, 8000 points, per-point Huber at tau = 1.345 MAD."""
     al = synth.make_alignment(2234, H=720, W=1280, N=8000)
