@@ -246,7 +246,7 @@ def main():
             rt = h.results(0, B)
             r_it = float(np.mean(rt[:, 14]))
             out["reference_problem"] = {"solver": "ref12", "lm_iterations_per_s": B * r_it / (float(np.median(r_ms[1:])) * 1e-3),
-                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_stream12_kernel" if B >= 96 else "eds_fused12_kernel",
+                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_fused12_kernel",
                                         "kernel_ms": float(np.median(r_dev[1:])), "iterations_per_alignment": r_it,
                                         "success_fraction": float(np.mean(rt[:, 15]))}
             h.set_config(cfg)

@@ -51,9 +51,7 @@ struct EdsArrays;
 // eds_stream6.hip: 256-thread streaming variant of the pose-only kernel (several alignments per CU)
 void eds_stream6_launch(const EdsArrays& A, int sampling, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first, int count,
                         int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
-// eds_stream12.hip: 256-thread streaming variant (two alignments per CU; any number of points)
-void eds_stream12_launch(const EdsArrays& A, int sampling, const EdsFusedIn* d_in, EdsFused12Out* d_out, int first, int count, int iters,
-                         int loss_type, double loss_a, double ftol, double gtol, double ptol, int nb, hipStream_t st);
+
 
 // ---- event-frame construction on device (eds_frame.hip) ---------------------------------------------------
 struct EdsFrameBuffers {

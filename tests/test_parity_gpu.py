@@ -450,11 +450,11 @@ def test_coarse_to_fine_pyramid_levels(gpu, capi, synth, po):
         p, q = pg, qg
 
 
-@pytest.mark.parametrize("B", [40, 104], ids=["resident-kernel", "streaming-kernel"])
+@pytest.mark.parametrize("B", [40, 300], ids=["wide-workgroups", "paired-workgroups"])
 def test_reference_problem_batched_on_device(gpu, capi, synth, po, B):
-    """A batch of reference-problem solves in one launch of a persistent REF12 kernel — the register-resident one
-    below 96 alignments, the streaming one (two alignments per CU) from there on — each checked against the oracle's
-    Ceres-LM restatement."""
+    """A batch of reference-problem solves in one launch of the persistent REF12 kernel — 512-thread workgroups up to
+    256 alignments, 256-thread ones (two alignments per CU) beyond — each checked against the oracle's Ceres-LM
+    restatement."""
     als = [synth.make_alignment(7000 + b, H=240, W=320, N=1200 + (13 * b) % 800) for b in range(B)]
     cfg = capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=2, loss_type=capi.LOSS_HUBER,
                               loss_param=0.25, max_num_iterations=8)
@@ -481,7 +481,7 @@ def test_reference_problem_batched_on_device(gpu, capi, synth, po, B):
 
 
 def test_reference_problem_more_than_2048_points_on_device(gpu, capi, synth, po):
-    """Beyond 2 048 points the streaming REF12 kernel takes over (constants re-read per evaluation, any N)."""
+    """The persistent REF12 kernel re-reads the point constants every evaluation: any number of points."""
     al = synth.make_alignment(4555, N=5000)
     ref = po.Oracle(al, num_blocks=3, loss_type=po.LOSS_CAUCHY, loss_param=0.3, max_num_iterations=8).solve_lm(al.p0, al.q0, al.v0)
     h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=3, loss_type=capi.LOSS_CAUCHY,

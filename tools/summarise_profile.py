@@ -21,7 +21,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
-    for k in ("eds_fused6_kernel", "eds_fused12_kernel", "eds_stream6_kernel", "eds_stream12_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
+    for k in ("eds_fused6_kernel", "eds_fused12_kernel", "eds_stream6_kernel", "eds_resjac_kernel", "eds_reduce_kernel", "eds_gram_kernel", "eds_model_kernel"):
         if k in name:
             return k + name[name.find("<"):name.find(">") + 1] if "<" in name else k
     return name[:40]
@@ -74,9 +74,8 @@ lines += ["",
           "  except that two sectors of one 128-B line fetched together are tallied once;",
           "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
           "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound.",
-          "The streaming kernels (`eds_stream6_kernel`, `eds_stream12_kernel`: bench.py's headline and its informational REF12",
-          "measurement at this batch size) write the candidate residuals of every pass (8 KB per alignment and pass) plus the",
-          "accepted copies, which is what their WRITE_SIZE shows."]
+          "`eds_stream6_kernel` and `eds_fused12_kernel` (bench.py's headline and its informational REF12 measurement) write the",
+          "candidate residuals of every pass (8 KB per alignment and pass) plus the accepted copies: that is their WRITE_SIZE."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 print("\n".join(lines))
