@@ -51,7 +51,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                                                           double huber_tau, int nb) {
     const int slot = first + blockIdx.x;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6, nwave = nthr >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];

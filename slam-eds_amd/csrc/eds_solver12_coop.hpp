@@ -2,10 +2,12 @@
 //
 // The state machine is the one the host-driven loop runs — same decisions, same constants, same order of the
 // floating-point sums inside every dot product — but the O(12^2)..O(12^3) pieces of an LM iteration (assembling the
-// corrected normal equations from the per-block sums, Jacobi scaling, the damped 12x12 Cholesky solve, the model-cost
-// quadratic form, the per-block constants of the next pose block) are spread over the 64 lanes of wavefront 0 with the
-// matrices in LDS, instead of running on one lane with 78 + 144 doubles in registers (which spilled to scratch and
-// cost ~60 us per iteration).  Scalar decisions stay on lane 0 and reach the other lanes through LDS.
+// corrected normal equations from the per-block sums, projecting the velocity columns, Jacobi scaling, the damped
+// 12x12 Cholesky solve, the model-cost quadratic form, the per-block constants of the next pose block) are spread over
+// the 64 lanes of wavefront 0 instead of running on one lane with 78 + 144 doubles in registers (which spilled to
+// scratch and cost ~60 us per iteration).  The factorisation keeps row i of the triangle in lane i's registers and
+// moves pivots by v_readlane; the other pieces exchange through a small LDS work area.  Scalar decisions stay on
+// lane 0 and reach the other lanes through LDS.
 //
 // All 64 lanes of ONE wavefront must call these functions together.  LDS operations of a wavefront retire in order,
 // so a wavefront-scope fence + wave barrier is all the synchronisation needed.
