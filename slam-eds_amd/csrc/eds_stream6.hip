@@ -30,6 +30,9 @@ using namespace edsd;
 #ifndef EDS6S_WG_PER_CU
 #define EDS6S_WG_PER_CU 2
 #endif
+#ifndef EDS6S_INFLIGHT
+#define EDS6S_INFLIGHT 2            // points per lane whose gathers are in flight together
+#endif
 
 template <int SAMPLING>
 __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
@@ -89,13 +92,13 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
         float acc[EDS_RED_K6];
 #pragma unroll
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
-        for (int j0 = 0; j0 < N; j0 += 2 * nthr) {
-            // phase A: two points per lane: constants, projection, cache probe, gathers in flight
-            PointGeom pg[2];
-            float tap[2][NTAP], kw[2], kmh[2];
-            bool miss[2];
+        for (int j0 = 0; j0 < N; j0 += EDS6S_INFLIGHT * nthr) {
+            // phase A: EDS6S_INFLIGHT points per lane: constants, projection, cache probe, gathers in flight
+            PointGeom pg[EDS6S_INFLIGHT];
+            float tap[EDS6S_INFLIGHT][NTAP], kw[EDS6S_INFLIGHT], kmh[EDS6S_INFLIGHT];
+            bool miss[EDS6S_INFLIGHT];
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < EDS6S_INFLIGHT; ++jj) {
                 const int i = j0 + jj * nthr + tid;
                 const bool valid = i < N;
                 const size_t o = base + (valid ? i : 0);
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
             }
             // phase B: refill the cache, residual, 1x6 row, running sums
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
+            for (int jj = 0; jj < EDS6S_INFLIGHT; ++jj) {
                 const int i = j0 + jj * nthr + tid;
                 if (miss[jj] && i < EDS6S_CACHE_CAP) {
 #pragma unroll
