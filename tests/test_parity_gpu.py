@@ -266,6 +266,40 @@ def test_points_leaving_the_frame_and_borders(gpu, capi, synth, po):
     h.close()
 
 
+@pytest.mark.parametrize("kernel", ["lm6-resident", "lm6-stream", "ref12"])
+def test_persistent_kernels_on_odd_frames_with_points_outside(gpu, capi, synth, po, kernel, monkeypatch):
+    """Frame sizes that are not multiples of the 4x4 tile, a start pose that puts a third of the points outside the
+    frame (all clamp cases of the patch read) and points in the last rows / columns, through the persistent kernels:
+    first evaluation, accept pattern / step counts and the residuals at the returned pose against the oracle."""
+    al = synth.make_alignment(78, H=61, W=83, N=700, margin=1)
+    p0 = np.array([0.25, -0.15, 0.02])
+    q0 = synth.quat_from_axis_angle([0.1, 1.0, -0.2], 0.04)
+    o = po.Oracle(al)
+    _, _, u, v = __import__("np_oracle").project(al, p0, q0)
+    outside = ((u < 0) | (u > al.W - 1) | (v < 0) | (v > al.H - 1)).mean()
+    assert 0.2 < outside < 0.85, outside
+    if kernel == "ref12":
+        h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=3, max_num_iterations=6)
+        p, q, vv, info = h.optimize(0, p=p0, q=q0, v=al.v_true)
+        ref = po.Oracle(al, num_blocks=3, max_num_iterations=6).solve_lm(p0, q0, al.v_true)
+        assert info["num_iterations"] == ref["num_iterations"] and info["num_successful_steps"] == ref["num_successful_steps"]
+        assert info["initial_cost"] == pytest.approx(ref["initial_cost"], rel=1e-5)
+        er = po.Oracle(al, num_blocks=3).eval12(p, q, vv, jac=False)["r_raw"]
+    else:
+        monkeypatch.setenv("EDS_LM6_KERNEL", kernel.split("-")[1])
+        h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=6)
+        p, q, vv, info = h.optimize(0, p=p0, q=q0, v=al.v_true)
+        ref = o.pose6_lm(p0, q0, al.v_true, iters=6, lambda0=0.01)
+        tr = h.trace(0)
+        assert np.array_equal(tr["accepted"], ref["accepted"])
+        assert np.allclose(tr["costs"], 0.5 * ref["costs"], rtol=2e-5)
+        er = o.pose6_eval(p, q, al.v_true)["r"]
+    assert po.se3_distance(p, q, ref["p"], ref["q"]) <= 1e-3        # ill-conditioned with so many points clamped: loose
+    r = h.residuals(0)
+    assert np.isfinite(r).all() and np.abs(r - er).max() <= 2e-5 * np.abs(er).max()
+    h.close()
+
+
 @pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 255, 257, 1000])
 def test_ragged_point_counts(gpu, capi, synth, po, N):
     al = synth.make_alignment(500 + N, H=96, W=128, N=N)
