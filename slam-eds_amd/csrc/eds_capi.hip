@@ -876,7 +876,6 @@ int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* c
     if (rc) return rc;
     Slot& s = h->slots[slot];
     if (!s.has_kf) return fail(EDS_ERR_STATE, "keyframe not set");
-    if (!eds_points_supported(h, slot, 1)) return fail(EDS_ERR_INVALID, "more than 4096 points: not supported by the device point maintenance");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     int n = 0;
     if ((rc = eds_points_update(h, slot, delete_out_points != 0, coord_xy, tracks_xy, kept_index, &n, mean_sq_flow))) return rc;

@@ -20,7 +20,8 @@
 using namespace edsd;
 
 #define EDS_PTS_THREADS 1024
-#define EDS_PTS_MAX 4096            // points per alignment these kernels handle (else the host path is used)
+#define EDS_PTS_CHUNK 4096          // points one sweep of k_update_points keeps in registers (4 per lane)
+#define EDS_SORT_MAX 16384          // points k_loss_param can sort in LDS (128 KB of fp64 keys); beyond: the host path
 
 namespace {
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_loss_param(EdsArrays A, int
     const int slot = first + blockIdx.x, tid = threadIdx.x, nthr = EDS_PTS_THREADS;
     const int N = (int)A.pose[(size_t)slot * EDS_POSE_STRIDE + EDS_PB_N];
     const float* __restrict__ r = A.r + (size_t)slot * A.Np;
-    __shared__ double s[EDS_PTS_MAX];
+    extern __shared__ double s[];       // next power of two >= N keys, sized by the launcher
     __shared__ double s_part[EDS_PTS_THREADS / 64];
     __shared__ double s_bcast;
     if (method == 2) {                  // mean_std_vector returns the VARIANCE (Utils.hpp:272-290)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_loss_param(EdsArrays A, int
     if (tid == 0) out[blockIdx.x] = 1.345 * (1.4826 * s[N / 2]);
 }
 
-// One workgroup per alignment; lane t owns the CONTIGUOUS points [t*ppt, (t+1)*ppt) so that an exclusive scan of the
+// One workgroup per alignment; per sweep lane t owns the CONTIGUOUS points [t*cppt, (t+1)*cppt) so that an exclusive scan of the
 // per-lane keep counts gives order-preserving destinations.
 __global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, int slot, int ppt, int delete_out, const double* __restrict__ pose_in,
                                                                   double* __restrict__ coord, double* __restrict__ track,
@@ -103,60 +104,75 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, 
     ps.fx = (float)s_pose[12]; ps.fy = (float)s_pose[13];
     const double cols = s_pose[14], rows = s_pose[15];
 
-    constexpr int MAXP = EDS_PTS_MAX / EDS_PTS_THREADS;
-    float fx_[MAXP], fy_[MAXP], frho[MAXP], fgx[MAXP], fgy[MAXP], fw[MAXP], ff0x[MAXP], ff0y[MAXP];
-    int fcell[MAXP];
-    double xp[MAXP], yp[MAXP];
-    bool keep[MAXP];
-    int mine = 0;
+    constexpr int MAXP = EDS_PTS_CHUNK / EDS_PTS_THREADS;
+    __shared__ int s_run;
+    if (tid == 0) s_run = 0;
     double flow = 0.0;
+    // Sweeps of EDS_PTS_CHUNK points.  A sweep reads its points completely before it writes, and a destination never
+    // lies beyond the source (points only move towards the front), so the in-place compaction stays order-preserving
+    // for any N.
+    for (int c0 = 0; c0 < N; c0 += EDS_PTS_CHUNK) {
+        const int nc = (N - c0 < EDS_PTS_CHUNK) ? N - c0 : EDS_PTS_CHUNK;
+        const int cppt = (nc + EDS_PTS_THREADS - 1) / EDS_PTS_THREADS;
+        float fx_[MAXP], fy_[MAXP], frho[MAXP], fgx[MAXP], fgy[MAXP], fw[MAXP], ff0x[MAXP], ff0y[MAXP];
+        int fcell[MAXP];
+        double xp[MAXP], yp[MAXP];
+        bool keep[MAXP];
+        int mine = 0;
 #pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-        const int i = tid * ppt + k;
-        keep[k] = false;
-        if (k < ppt && i < N) {
-            const size_t o = base + i;
-            fx_[k] = A.x[o]; fy_[k] = A.y[o]; frho[k] = A.rho[o]; fgx[k] = A.gx[o]; fgy[k] = A.gy[o]; fw[k] = A.w[o];
-            ff0x[k] = A.f0x[o]; ff0y[k] = A.f0y[o]; fcell[k] = A.cell0[o];
-            // p = R (x, y, 1)/mu + t with the RAW inverse depth (Tracker.cpp:343-347), projected (:350-351)
-            const float rho = frho[k];
-            const float d0 = ps.D[0] * fx_[k] + ps.D[1] * fy_[k] + ps.D[2] + ps.t[0] * rho;
-            const float d1 = ps.D[3] * fx_[k] + ps.D[4] * fy_[k] + ps.D[5] + ps.t[1] * rho;
-            const float d2 = ps.D[6] * fx_[k] + ps.D[7] * fy_[k] + ps.D[8] + ps.t[2] * rho;
-            const float is = 1.0f / (1.0f + d2);
-            const double du = (double)(ps.fx * (d0 - fx_[k] * d2) * is), dv = (double)(ps.fy * (d1 - fy_[k] * d2) * is);
-            const double u0 = (double)(short)(fcell[k] & 0xffff) + (double)ff0x[k], v0 = (double)(fcell[k] >> 16) + (double)ff0y[k];
-            xp[k] = u0 + du; yp[k] = v0 + dv;
-            const bool outlier = (xp[k] < 0.0 || xp[k] > cols) || (yp[k] < 0.0 || yp[k] > rows);      // Tracker.cpp:354
-            keep[k] = !(delete_out && outlier);
-            if (keep[k]) { ++mine; flow += du * du + dv * dv; }                                     // track = new - old pixel (:364-366)
+        for (int k = 0; k < MAXP; ++k) {
+            const int li = tid * cppt + k;
+            const int i = c0 + li;
+            keep[k] = false;
+            if (k < cppt && li < nc) {
+                const size_t o = base + i;
+                fx_[k] = A.x[o]; fy_[k] = A.y[o]; frho[k] = A.rho[o]; fgx[k] = A.gx[o]; fgy[k] = A.gy[o]; fw[k] = A.w[o];
+                ff0x[k] = A.f0x[o]; ff0y[k] = A.f0y[o]; fcell[k] = A.cell0[o];
+                // p = R (x, y, 1)/mu + t with the RAW inverse depth (Tracker.cpp:343-347), projected (:350-351)
+                const float rho = frho[k];
+                const float d0 = ps.D[0] * fx_[k] + ps.D[1] * fy_[k] + ps.D[2] + ps.t[0] * rho;
+                const float d1 = ps.D[3] * fx_[k] + ps.D[4] * fy_[k] + ps.D[5] + ps.t[1] * rho;
+                const float d2 = ps.D[6] * fx_[k] + ps.D[7] * fy_[k] + ps.D[8] + ps.t[2] * rho;
+                const float is = 1.0f / (1.0f + d2);
+                const double du = (double)(ps.fx * (d0 - fx_[k] * d2) * is), dv = (double)(ps.fy * (d1 - fy_[k] * d2) * is);
+                const double u0 = (double)(short)(fcell[k] & 0xffff) + (double)ff0x[k], v0 = (double)(fcell[k] >> 16) + (double)ff0y[k];
+                xp[k] = u0 + du; yp[k] = v0 + dv;
+                const bool outlier = (xp[k] < 0.0 || xp[k] > cols) || (yp[k] < 0.0 || yp[k] > rows);      // Tracker.cpp:354
+                keep[k] = !(delete_out && outlier);
+                if (keep[k]) { ++mine; flow += du * du + dv * dv; }                                     // track = new - old pixel (:364-366)
+            }
         }
-    }
-    s_cnt[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < EDS_PTS_THREADS; off <<= 1) {       // inclusive Hillis-Steele scan of the keep counts
-        const int v = tid >= off ? s_cnt[tid - off] : 0;
+        s_cnt[tid] = mine;
         __syncthreads();
-        s_cnt[tid] += v;
+        for (int off = 1; off < EDS_PTS_THREADS; off <<= 1) {       // inclusive Hillis-Steele scan of the keep counts
+            const int v = tid >= off ? s_cnt[tid - off] : 0;
+            __syncthreads();
+            s_cnt[tid] += v;
+            __syncthreads();
+        }
+        const int run = s_run;
+        int dst = run + s_cnt[tid] - mine;
+        const int ctotal = s_cnt[EDS_PTS_THREADS - 1];
+        __syncthreads();        // every lane has read its points and the running offset: the planes can be overwritten in place
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            if (!keep[k]) continue;
+            const size_t o = base + dst;
+            const_cast<float*>(A.x)[o] = fx_[k]; const_cast<float*>(A.y)[o] = fy_[k]; const_cast<float*>(A.rho)[o] = frho[k]; const_cast<float*>(A.gx)[o] = fgx[k]; const_cast<float*>(A.gy)[o] = fgy[k]; const_cast<float*>(A.w)[o] = fw[k];
+            const_cast<float*>(A.f0x)[o] = ff0x[k]; const_cast<float*>(A.f0y)[o] = ff0y[k]; const_cast<int*>(A.cell0)[o] = fcell[k];
+            coord[2 * dst] = xp[k]; coord[2 * dst + 1] = yp[k];
+            const double u0 = (double)(short)(fcell[k] & 0xffff) + (double)ff0x[k], v0 = (double)(fcell[k] >> 16) + (double)ff0y[k];
+            track[2 * dst] = xp[k] - u0; track[2 * dst + 1] = yp[k] - v0;
+            kept[dst] = c0 + tid * cppt + k;
+            ++dst;
+        }
+        if (tid == 0) s_run = run + ctotal;
         __syncthreads();
     }
-    int dst = s_cnt[tid] - mine;
-    const int total = s_cnt[EDS_PTS_THREADS - 1];
+    const int total = s_run;
     for (int off = 32; off > 0; off >>= 1) flow += __shfl_down(flow, off, 64);
     if ((tid & 63) == 0) s_flow[tid >> 6] = flow;
-    __syncthreads();        // every lane has read its points: the planes can now be overwritten in place
-#pragma unroll
-    for (int k = 0; k < MAXP; ++k) {
-        if (!keep[k]) continue;
-        const size_t o = base + dst;
-        const_cast<float*>(A.x)[o] = fx_[k]; const_cast<float*>(A.y)[o] = fy_[k]; const_cast<float*>(A.rho)[o] = frho[k]; const_cast<float*>(A.gx)[o] = fgx[k]; const_cast<float*>(A.gy)[o] = fgy[k]; const_cast<float*>(A.w)[o] = fw[k];
-        const_cast<float*>(A.f0x)[o] = ff0x[k]; const_cast<float*>(A.f0y)[o] = ff0y[k]; const_cast<int*>(A.cell0)[o] = fcell[k];
-        coord[2 * dst] = xp[k]; coord[2 * dst + 1] = yp[k];
-        const double u0 = (double)(short)(fcell[k] & 0xffff) + (double)ff0x[k], v0 = (double)(fcell[k] >> 16) + (double)ff0y[k];
-        track[2 * dst] = xp[k] - u0; track[2 * dst + 1] = yp[k] - v0;
-        kept[dst] = tid * ppt + k;
-        ++dst;
-    }
+    __syncthreads();
     if (tid == 0) {
         double f = 0.0;
         for (int w = 0; w < EDS_PTS_THREADS / 64; ++w) f += s_flow[w];
@@ -186,9 +202,10 @@ static int ensure(eds_trk* h) {
     return EDS_OK;
 }
 
+// the device loss scale sorts in LDS: up to EDS_SORT_MAX points per alignment (else the host nth_element path is used)
 bool eds_points_supported(const eds_trk* h, int first, int count) {
     for (int s = first; s < first + count; ++s)
-        if (h->slots[s].N > EDS_PTS_MAX || h->slots[s].N < 1) return false;
+        if (h->slots[s].N > EDS_SORT_MAX || h->slots[s].N < 1) return false;
     return true;
 }
 
@@ -197,7 +214,13 @@ int eds_points_loss_param(eds_trk* h, int first, int count, int method, double* 
     int rc = ensure(h);
     if (rc) return rc;
     EdsPointBuffers& pb = h->point_ops;
-    hipLaunchKernelGGL(k_loss_param, dim3(count), dim3(EDS_PTS_THREADS), 0, h->st, h->arrays(), first, method, pb.d_tau);
+    int maxN = 1;
+    for (int s = first; s < first + count; ++s) maxN = h->slots[s].N > maxN ? h->slots[s].N : maxN;
+    size_t M = 1;
+    while ((int)M < maxN) M <<= 1;
+    if (M * 8 > 64 * 1024)              // more LDS than the default per-kernel limit: ask for it explicitly
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_loss_param), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(M * 8));
+    hipLaunchKernelGGL(k_loss_param, dim3(count), dim3(EDS_PTS_THREADS), M * 8, h->st, h->arrays(), first, method, pb.d_tau);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(tau_out, pb.d_tau, (size_t)count * 8, hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);

@@ -95,3 +95,37 @@ def test_tracker_mirror_get_coord(gpu, capi, synth):
     assert t.squared_norm_flow == pytest.approx(ref["mean_sq_flow"], rel=1e-5)
     assert t.needNewKeyframe(0.03) == pto.need_new_keyframe(ref["mean_sq_flow"], al.H, al.W, 0.03)
     t.close()
+
+
+@pytest.mark.parametrize("N", [4097, 9000, 16000])
+def test_point_maintenance_and_loss_scale_beyond_4096_points(gpu, capi, synth, po, N):
+    """The pyramid configurations carry 8 000 - 16 000 points: culling sweeps 4 096 points at a time (order-preserving
+    across sweeps), the MAD sort takes up to 16 384 keys in LDS."""
+    import np_points_oracle as pto
+    al = synth.make_alignment(64, H=480, W=640, N=N, margin=2)
+    K = (al.fx, al.fy, al.cx, al.cy)
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=3), 1, N, al.H, al.W)
+    h.set_alignment(0, al)
+    h.optimize_batch(0, 0, 1)
+    tau = h.loss_param_batch(capi.LP_MAD)[0]                                # residuals still on the device
+    r = h.residuals(0)
+    assert tau == pytest.approx(po.loss_param(r, po.LP_MAD)[0], rel=1e-12)
+    p = np.array([0.08, -0.05, 0.01])
+    q = synth.quat_from_axis_angle([0.1, 1.0, 0.2], 0.04)
+    ref = pto.get_coord(al.norm_coord, al.idp, al.coord, K, al.H, al.W, p, q, True)
+    assert 100 < N - len(ref["kept"]) < N - 100
+    h.set_state(0, p, q, al.v0)
+    out = h.update_points(0, True)
+    assert np.array_equal(out["kept"], ref["kept"])
+    assert np.abs(out["coord"] - ref["coord"]).max() < 1e-4
+    assert out["mean_sq_flow"] == pytest.approx(ref["mean_sq_flow"], rel=1e-5)
+    # the compacted planes behave like a fresh upload of the kept points
+    keep = ref["kept"]
+    al2 = type(al)(**{**al.__dict__, "norm_coord": al.norm_coord[keep], "grad": al.grad[keep], "idp": al.idp[keep],
+                      "weights": al.weights[keep], "coord": al.coord[keep]})
+    pe, qe = np.array([0.001, 0.002, -0.001]), synth.quat_from_axis_angle([0.3, -0.2, 0.9], 0.004)
+    h.set_config(capi.default_config(exec=capi.EXEC_HOST))
+    g = h.eval(0, pe, qe, al.v0, ncols=6)
+    e = po.Oracle(al2).pose6_eval(pe, qe, al.v0)
+    assert g["r"].shape == (len(keep),) and np.abs(g["r"] - e["r"]).max() <= 1e-5 * np.abs(e["r"]).max()
+    h.close()
