@@ -367,8 +367,10 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const int damped = h->cfg.solver == EDS_SOLVER_LM6;
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
     // streaming variant (eds_stream6.hip: two alignments per CU, solver / reduction overlapped with the other's points):
-    // pays off once a launch keeps every CU busy for several rounds
-    bool stream = count >= 1536 && maxN <= 2048;
+    // for N <= 2 048 it pays off once a launch keeps every CU busy for several rounds (+3 % at 1 536 alignments, +8 % at
+    // 4 096); for larger keyframes, where the resident kernel needs 1 024 threads at 128 registers, much earlier
+    // (N = 4 000: +26 % at 64 alignments, +36 % at 1 024; N = 8 000: equal at 64, +18 % at 1 024)
+    bool stream = maxN <= 2048 ? count >= 1536 : count >= 32;
     if (const char* ev = getenv("EDS_LM6_KERNEL")) stream = std::strcmp(ev, "stream") == 0;     // tuning knob: "resident" | "stream"
     hipEventRecord(h->ev0, h->st);
     if (stream) {
