@@ -189,14 +189,14 @@ def main():
         # residual/Jacobian passes per solve: LM6 = initial linearisation + one per iteration (the persistent kernel keeps
         # the accepted pose's residuals in registers; the host-driven loop and N > 2048 add a final residual pass);
         # GN6 = one per iteration + the final residual pass
-        in_regs = a.exec_ == "device" and (N <= 2048 or B >= 32)
+        in_regs = a.exec_ == "device" and (N <= 2048 or not (N > 4096 and B < 16))
         passes = a.iters + (1 if (a.solver == "lm6" and in_regs) else (2 if a.solver == "lm6" else 1))
         per_pt = BYTES_RESJAC[a.sampling] + BYTES_REDUCE
         roof = None
         if a.exec_ == "device":
             k_ms = float(np.mean(dev_us)) * 1e-3
             ach = B * N * passes * per_pt / (k_ms * 1e-3) / 1e9
-            kname = "eds_stream6_kernel" if (B >= 1536 if N <= 2048 else B >= 32) else "eds_fused6_kernel"     # the rule of eds_fused_solve
+            kname = "eds_stream6_kernel" if (B >= 1536 if N <= 2048 else not (N > 4096 and B < 16)) else "eds_fused6_kernel"   # eds_fused_solve's rule
             roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": B * N * passes * per_pt,

@@ -366,15 +366,21 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const double tau = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
     const int damped = h->cfg.solver == EDS_SOLVER_LM6;
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
-    // streaming variant (eds_stream6.hip: two alignments per CU, solver / reduction overlapped with the other's points):
-    // for N <= 2 048 it pays off once a launch keeps every CU busy for several rounds (+3 % at 1 536 alignments, +8 % at
-    // 4 096); for larger keyframes, where the resident kernel needs 1 024 threads at 128 registers, much earlier
-    // (N = 4 000: +26 % at 64 alignments, +36 % at 1 024; N = 8 000: equal at 64, +18 % at 1 024)
-    bool stream = maxN <= 2048 ? count >= 1536 : count >= 32;
-    if (const char* ev = getenv("EDS_LM6_KERNEL")) stream = std::strcmp(ev, "stream") == 0;     // tuning knob: "resident" | "stream"
+    // Streaming variants (eds_stream6.hip: constants re-read per pass, any N).
+    //  * N <= 2 048: "paired" — two 256-thread workgroups per CU, reduction / solver overlapped with the other's points —
+    //    pays off once a launch keeps every CU busy for several rounds (+3 % at 1 536 alignments, +8 % at 4 096).
+    //  * N > 2 048, where the resident kernel needs 1 024 threads at 128 registers: "wide" — one 512-thread workgroup
+    //    with the whole patch cache (N = 4 000: 0.21 vs 0.30 ms for one alignment, 4.1 M vs 2.5 M it/s at 256; N = 8 000:
+    //    2.1 M vs 1.7 M at 256); only a handful of very large alignments is still faster with 1 024 threads.
+    bool stream = maxN <= 2048 ? count >= 1536 : !(maxN > 4096 && count < 16);
+    bool wide = maxN > 2048;
+    if (const char* ev = getenv("EDS_LM6_KERNEL")) {                 // tuning knob: "resident" | "paired" | "wide"
+        stream = std::strcmp(ev, "paired") == 0 || std::strcmp(ev, "wide") == 0 || std::strcmp(ev, "stream") == 0;
+        wide = std::strcmp(ev, "wide") == 0;
+    }
     hipEventRecord(h->ev0, h->st);
     if (stream) {
-        eds_stream6_launch(A, h->cfg.sampling, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
+        eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
     } else {
     // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
     // lane variant needs to keep 4 x 16 taps + constants in registers without spilling

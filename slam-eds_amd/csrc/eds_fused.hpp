@@ -49,8 +49,8 @@ int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);
 struct EdsArrays;
 // eds_stream6.hip: 256-thread streaming variant of the pose-only kernel (several alignments per CU)
-void eds_stream6_launch(const EdsArrays& A, int sampling, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first, int count,
-                        int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
+void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,
+                        int count, int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
 
 
 // ---- event-frame construction on device (eds_frame.hip) ---------------------------------------------------

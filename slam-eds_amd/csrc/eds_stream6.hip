@@ -23,10 +23,7 @@
 using namespace edsd;
 
 #define EDS6S_THREADS 256
-#define EDS6S_WAVES (EDS6S_THREADS / 64)
-#ifndef EDS6S_CACHE_CAP
 #define EDS6S_CACHE_CAP 1024        // 64 KB of patches per workgroup: the most that lets two workgroups share a CU
-#endif
 #ifndef EDS6S_WG_PER_CU
 #define EDS6S_WG_PER_CU 2
 #endif
@@ -34,24 +31,24 @@ using namespace edsd;
 #define EDS6S_INFLIGHT 2            // points per lane whose gathers are in flight together
 #endif
 
-template <int SAMPLING>
-__global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
+template <int SAMPLING, int NTHR, int CAP>
+__global__ __launch_bounds__(NTHR, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                                                   EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                                                   int first, int iters, int damped, double lambda0,
                                                                                   double huber_tau, int nb) {
     const int slot = first + blockIdx.x;
     const int tid = threadIdx.x;
-    constexpr int nthr = EDS6S_THREADS;
+    constexpr int nthr = NTHR;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
-    __shared__ float s_red[EDS6S_WAVES][EDS_RED_K6];
+    __shared__ float s_red[(NTHR / 64)][EDS_RED_K6];
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
     __shared__ int s_accept;           // the pass just consumed is at the accepted pose
-    __shared__ float s_patch[NTAP][EDS6S_CACHE_CAP];
-    __shared__ int s_cell[EDS6S_CACHE_CAP];
+    __shared__ float s_patch[NTAP][CAP];
+    __shared__ int s_cell[CAP];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const int N = (int)gpb[EDS_PB_N];
@@ -68,7 +65,7 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
         s_state = sv.final_pass ? 1 : 0;
         s_accept = 0;
     }
-    for (int i = tid; i < EDS6S_CACHE_CAP; i += nthr) s_cell[i] = 0x7fffffff;
+    for (int i = tid; i < CAP; i += nthr) s_cell[i] = 0x7fffffff;
     __syncthreads();
     {   // normalised model for the fixed velocity, mhat_i = a_i.v / n_block(i), once per solve
         float vf[6];
@@ -108,7 +105,7 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
                 kw[jj] = valid ? A.w[o] : 0.0f;                             // w = 0 silences out-of-range lanes
                 kmh[jj] = A.mhat[o];
                 project_point(ps, kf, pg[jj]);
-                const bool cached = i < EDS6S_CACHE_CAP;
+                const bool cached = i < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
                 miss[jj] = !(cached && s_cell[i] == key);
                 if (miss[jj]) {
@@ -124,7 +121,7 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
 #pragma unroll
             for (int jj = 0; jj < EDS6S_INFLIGHT; ++jj) {
                 const int i = j0 + jj * nthr + tid;
-                if (miss[jj] && i < EDS6S_CACHE_CAP) {
+                if (miss[jj] && i < CAP) {
 #pragma unroll
                     for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
                 }
@@ -153,7 +150,7 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
         if (tid < EDS_RED_N6) {          // cross-wavefront sum in fp64, unpacked straight into the solver's input
             double s = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < EDS6S_WAVES; ++wv) s += (double)s_red[wv][tid];
+            for (int wv = 0; wv < (NTHR / 64); ++wv) s += (double)s_red[wv][tid];
             if (tid < 21) {
                 int a = 0, rem = tid;           // record index -> (a, b) of the upper triangle
                 while (rem >= 6 - a) { rem -= 6 - a; ++a; }
@@ -205,13 +202,15 @@ __global__ __launch_bounds__(EDS6S_THREADS, EDS6S_WG_PER_CU) void eds_stream6_ke
     }
 }
 
-void eds_stream6_launch(const EdsArrays& A, int sampling, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first, int count,
-                        int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st) {
+void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,
+                        int count, int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st) {
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(d_sv);
-    if (sampling == 0)
-        hipLaunchKernelGGL((eds_stream6_kernel<0>), dim3(count), dim3(EDS6S_THREADS), 0, st, A, d_in, d_out, svp, first, iters, damped, lambda0,
-                           huber_tau, nb);
-    else
-        hipLaunchKernelGGL((eds_stream6_kernel<1>), dim3(count), dim3(EDS6S_THREADS), 0, st, A, d_in, d_out, svp, first, iters, damped, lambda0,
-                           huber_tau, nb);
+#define EDS_LAUNCH6S(S, T, C)                                                                                                    \
+    hipLaunchKernelGGL((eds_stream6_kernel<S, T, C>), dim3(count), dim3(T), 0, st, A, d_in, d_out, svp, first, iters, damped, lambda0, \
+                       huber_tau, nb)
+    // paired: two 256-thread workgroups per CU; wide: one 512-thread workgroup with the whole patch cache (few alignments
+    // of a large keyframe, where the register-resident kernel would need 1 024 threads at 128 registers)
+    if (wide) { if (sampling == 0) EDS_LAUNCH6S(0, 512, 2048); else EDS_LAUNCH6S(1, 512, 2048); }
+    else { if (sampling == 0) EDS_LAUNCH6S(0, EDS6S_THREADS, EDS6S_CACHE_CAP); else EDS_LAUNCH6S(1, EDS6S_THREADS, EDS6S_CACHE_CAP); }
+#undef EDS_LAUNCH6S
 }

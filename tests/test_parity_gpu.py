@@ -189,7 +189,7 @@ def test_streaming_pose_kernel_vs_oracle_and_resident_kernel(gpu, capi, synth, p
     P0, Q0, V0 = np.stack([ps] * len(als)), np.stack([qs] * len(als)), np.stack([a.v0 for a in als])
     out = {}
     for kern in ("resident", "stream"):
-        monkeypatch.setenv("EDS_LM6_KERNEL", kern)
+        monkeypatch.setenv("EDS_LM6_KERNEL", "paired" if kern == "stream" else kern)
         for tau in (0.0, 0.01):
             h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=sv, sampling=sampling, max_num_iterations=iters, huber_tau=tau),
                             len(als), 2048, 240, 320)
@@ -266,7 +266,7 @@ def test_points_leaving_the_frame_and_borders(gpu, capi, synth, po):
     h.close()
 
 
-@pytest.mark.parametrize("kernel", ["lm6-resident", "lm6-stream", "ref12"])
+@pytest.mark.parametrize("kernel", ["lm6-resident", "lm6-paired", "lm6-wide", "ref12"])
 def test_persistent_kernels_on_odd_frames_with_points_outside(gpu, capi, synth, po, kernel, monkeypatch):
     """Frame sizes that are not multiples of the 4x4 tile, a start pose that puts a third of the points outside the
     frame (all clamp cases of the patch read) and points in the last rows / columns, through the persistent kernels:
