@@ -6,6 +6,7 @@
 
 #include "../../oracle/eds_oracle.hpp"
 #include "../../slam-eds_amd/csrc/eds_math.hpp"
+#include "../../slam-eds_amd/csrc/eds_layout.hpp"
 #include "../../slam-eds_amd/csrc/eds_solver.hpp"
 
 using namespace eds_oracle;
@@ -85,5 +86,23 @@ void hl_quat_to_R(const double* q, double* R) { edsm::quat_to_R(q, R); }
 void hl_fill_pose_block(const double* p, const double* q, const double* v, const double* G, int nb, double* pb) { edsm::fill_pose_block(p, q, v, G, nb, pb); }
 void hl_loss_eval(int type, double a, double s, double* out2) { edss::loss_eval(type, a, s, &out2[0], &out2[1]); }
 int hl_pose_stride(void) { return EDS_POSE_STRIDE; }
+
+// Frame allocation of the product (eds_layout.hpp): walks every logical pixel of the padded + margin range through
+// eds_frame_index and reports how many elements of the Hp x Wp allocation were not hit exactly once, plus the index of
+// logical pixel (r, c) for spot checks.
+int hl_frame_layout(int H, int W, int tiled, int* Hp_out, int* Wp_out, int r, int c, long long* index_rc) {
+    const int Hp = eds_frame_extent(H), Wp = eds_frame_extent(W);
+    *Hp_out = Hp; *Wp_out = Wp;
+    std::vector<int> hits((size_t)Hp * Wp, 0);
+    int bad = 0;
+    for (int y = -EDS_FRAME_MARGIN; y < Hp - EDS_FRAME_MARGIN; ++y)
+        for (int x = -EDS_FRAME_MARGIN; x < Wp - EDS_FRAME_MARGIN; ++x) {
+            const size_t o = eds_frame_index(y, x, Wp, tiled);
+            if (o >= hits.size()) ++bad; else ++hits[o];
+        }
+    for (int h : hits) bad += (h != 1);
+    *index_rc = (long long)eds_frame_index(r, c, Wp, tiled);
+    return bad;
+}
 
 }  // extern "C"

@@ -149,3 +149,25 @@ def test_pose_block_closed_form_norm(hl, npo, synth):
         assert np.allclose(blk[1:7], (A[s:s + n].T @ m) / S ** 1.5, rtol=1e-10)
     assert np.allclose(pbk[0:9].reshape(3, 3), np.eye(3))
     assert np.allclose(pbk[32:68].reshape(6, 6), np.eye(6) - np.outer(v, v), atol=1e-14)
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (61, 83), (4, 4), (5, 1023)])
+@pytest.mark.parametrize("tiled", [1, 0])
+def test_frame_allocation_index_is_a_bijection(hl, H, W, tiled):
+    """eds_layout.hpp: padded extent + one-tile margin; every logical pixel of the allocation maps to its own element,
+    and a 4x4 tile is 16 consecutive floats (one 64-byte sector)."""
+    Hp, Wp, idx = C.c_int(0), C.c_int(0), C.c_longlong(0)
+    hl.hl_frame_layout.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    assert hl.hl_frame_layout(H, W, tiled, C.byref(Hp), C.byref(Wp), 0, 0, C.byref(idx)) == 0
+    assert Hp.value == ((H + 3) // 4) * 4 + 8 and Wp.value == ((W + 3) // 4) * 4 + 8
+    origin = idx.value
+    assert origin == ((Wp.value // 4) + 1) * 16 if tiled else origin == 4 * Wp.value + 4       # one tile row down, one tile right
+    if tiled:
+        got = []
+        for r in range(4):
+            for c in range(4):
+                hl.hl_frame_layout(H, W, 1, C.byref(Hp), C.byref(Wp), r, c, C.byref(idx))
+                got.append(idx.value - origin)
+        assert got == list(range(16))
+        hl.hl_frame_layout(H, W, 1, C.byref(Hp), C.byref(Wp), -1, -1, C.byref(idx))           # margin pixel: last element of the tile up-left
+        assert idx.value == origin - (Wp.value // 4 + 1) * 16 + 15
