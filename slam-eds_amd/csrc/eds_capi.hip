@@ -284,7 +284,7 @@ int materialise_residuals(eds_trk* h, int slot) {
 void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
-    void* dptrs[] = {h->df0x, h->df0y, h->dcell0, h->dpose, h->dG, h->dpart, h->dncstat, h->dx, h->dy, h->drho, h->dgx, h->dgy, h->dw,
+    void* dptrs[] = {h->dkf, h->dpose, h->dG, h->dpart, h->dncstat,
                      h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
@@ -390,9 +390,11 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("stream/event: ") + hipGetErrorString(e)); }
-    EDS_ALLOC(h->df0x, BN * 4); EDS_ALLOC(h->df0y, BN * 4); EDS_ALLOC(h->dcell0, BN * 4);
-    EDS_ALLOC(h->dx, BN * 4); EDS_ALLOC(h->dy, BN * 4); EDS_ALLOC(h->drho, BN * 4);
-    EDS_ALLOC(h->dgx, BN * 4); EDS_ALLOC(h->dgy, BN * 4); EDS_ALLOC(h->dw, BN * 4);
+    EDS_ALLOC(h->dkf, BN * 4 * EDS_KF_PLANES);
+    h->dx = h->dkf + EDS_KF_X * BN; h->dy = h->dkf + EDS_KF_Y * BN; h->drho = h->dkf + EDS_KF_RHO * BN;
+    h->dgx = h->dkf + EDS_KF_GX * BN; h->dgy = h->dkf + EDS_KF_GY * BN; h->dw = h->dkf + EDS_KF_W * BN;
+    h->df0x = h->dkf + EDS_KF_F0X * BN; h->df0y = h->dkf + EDS_KF_F0Y * BN;
+    h->dcell0 = reinterpret_cast<int*>(h->dkf + EDS_KF_CELL0 * BN);
     EDS_ALLOC(h->dmhat, BN * 4); EDS_ALLOC(h->dr, BN * 4); EDS_ALLOC(h->dJ, BN * 4 * 12);
     EDS_ALLOC(h->dframe, (size_t)batch * h->Hp * h->Wp * 4);
     EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);

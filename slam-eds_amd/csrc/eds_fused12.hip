@@ -128,10 +128,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const int i = j0 + jj * nthr + tid;
                 const bool valid = i < N;
                 const size_t o = base + (valid ? i : 0);
-                kf[jj].x = A.x[o]; kf[jj].y = A.y[o]; kf[jj].rhop = A.rho[o] + 1e-5f;
-                kf[jj].f0x = A.f0x[o]; kf[jj].f0y = A.f0y[o]; kf[jj].cell0 = A.cell0[o];
-                kw[jj] = valid ? A.w[o] : 0.0f;
-                kgx[jj] = A.gx[o]; kgy[jj] = A.gy[o];
+                const float* __restrict__ c = A.kf + o;                 // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
+                const size_t pl = A.kf_plane;
+                kf[jj].x = c[EDS_KF_X * pl]; kf[jj].y = c[EDS_KF_Y * pl]; kf[jj].rhop = c[EDS_KF_RHO * pl] + 1e-5f;
+                kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
+                kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;
+                kgx[jj] = c[EDS_KF_GX * pl]; kgy[jj] = c[EDS_KF_GY * pl];
                 project_point(ps, kf[jj], pg[jj]);
                 const bool cached = i < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);

@@ -33,6 +33,7 @@ struct eds_trk {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // device
     double *dpose = nullptr, *dG = nullptr, *dpart = nullptr, *dncstat = nullptr;
+    float* dkf = nullptr;               // ONE allocation holding the nine per-point planes below, [9][B][Np] (eds_layout.hpp)
     float *dx = nullptr, *dy = nullptr, *drho = nullptr, *dgx = nullptr, *dgy = nullptr, *dw = nullptr;
     float *df0x = nullptr, *df0y = nullptr;
     int* dcell0 = nullptr;
@@ -51,6 +52,7 @@ struct eds_trk {
         EdsArrays A;
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
+        A.kf = dkf; A.kf_plane = (size_t)B * Np;
         A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;

@@ -9,6 +9,9 @@ struct EdsArrays {
     const float* x; const float* y; const float* rho;      // normalised coords, raw inverse depth
     const float* gx; const float* gy; const float* w;      // log-image gradient, point weight
     const float* f0x; const float* f0y; const int* cell0;  // keyframe pixel u0 = fx x + cx split into cell + fraction
+    // the nine planes above are consecutive slices of ONE allocation, in the order of EDS_KF_* (eds_layout.hpp): kernels that
+    // read all of them address kf + k * kf_plane and keep one base pointer in scalar registers instead of nine
+    const float* kf; size_t kf_plane;
     float* mhat;                                            // normalised model (pose-only solvers)
     // frames [B][Hp*Wp]
     const float* frame;

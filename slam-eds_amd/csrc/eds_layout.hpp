@@ -55,6 +55,18 @@
 #define EDS_RED_K12 128
 #define EDS_RED_K 128              // stride of the partial-sum records
 
+// ---- per-point planes of a keyframe: slices of one [EDS_KF_PLANES][B][Np] allocation ---------------------------------
+#define EDS_KF_X 0
+#define EDS_KF_Y 1
+#define EDS_KF_RHO 2
+#define EDS_KF_GX 3
+#define EDS_KF_GY 4
+#define EDS_KF_W 5
+#define EDS_KF_F0X 6
+#define EDS_KF_F0Y 7
+#define EDS_KF_CELL0 8             // int32 bit patterns
+#define EDS_KF_PLANES 9
+
 // ---- frame allocation ------------------------------------------------------------------------------------------
 #define EDS_FRAME_MARGIN 4         // replicated border pixels (= one tile) on every side of the padded frame
 #if defined(__HIPCC__)

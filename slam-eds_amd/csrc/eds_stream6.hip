@@ -100,9 +100,11 @@ __global__ __launch_bounds__(NTHR, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsA
                 const bool valid = i < N;
                 const size_t o = base + (valid ? i : 0);
                 PointKf kf;
-                kf.x = A.x[o]; kf.y = A.y[o]; kf.rhop = A.rho[o] + 1e-5f;   // rho' = idp + eps (PhotometricError.hpp:100,200)
-                kf.f0x = A.f0x[o]; kf.f0y = A.f0y[o]; kf.cell0 = A.cell0[o];
-                kw[jj] = valid ? A.w[o] : 0.0f;                             // w = 0 silences out-of-range lanes
+                const float* __restrict__ c = A.kf + o;                     // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
+                const size_t pl = A.kf_plane;
+                kf.x = c[EDS_KF_X * pl]; kf.y = c[EDS_KF_Y * pl]; kf.rhop = c[EDS_KF_RHO * pl] + 1e-5f;   // rho' = idp + eps (PhotometricError.hpp:100,200)
+                kf.f0x = c[EDS_KF_F0X * pl]; kf.f0y = c[EDS_KF_F0Y * pl]; kf.cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
+                kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;                   // w = 0 silences out-of-range lanes
                 kmh[jj] = A.mhat[o];
                 project_point(ps, kf, pg[jj]);
                 const bool cached = i < CAP;
