@@ -302,4 +302,28 @@ __device__ __forceinline__ void accumulate_normal(float* acc, const float (&J)[N
     acc[o] += cost_term;
 }
 
+// One point of a pose-only pass, shared by the persistent kernels (eds_fused.hip, eds_stream6.hip): sample from the
+// register-resident taps, residual r = w (mhat - E), 1x6 SE(3) row, optional per-point Huber weight (extension, cf.
+// reference CoarseTracker.cpp:445), and the contribution to the 28 running sums.  Returns r.
+template <int SAMPLING, int NTAP>
+__device__ __forceinline__ float point_row6(const PoseF& ps, const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, float tau,
+                                            float* acc) {
+    float E, Er, Ec;
+    if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
+    else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
+    PointProj pp;
+    finish_point(ps, pg, E, Er, Ec, pp);
+    const float r = w * (mhat - pp.E);
+    float J[6];
+    jacobian6(pp, w, J);
+    float hw = 1.0f, ct = r * r;
+    if (tau > 0.0f) {
+        const float ar = fabsf(r);
+        if (ar > tau) hw = tau / ar;
+        ct = hw * r * r * (2.0f - hw);
+    }
+    accumulate_normal<6>(acc, J, r, hw, ct);
+    return r;
+}
+
 }  // namespace edsd

@@ -142,21 +142,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
         // Consumes one point: sample from its (register-resident) taps, residual, 1x6 row, running sums.
         auto consume = [&](const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, int i) -> float {
-            float E, Er, Ec;
-            if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
-            else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
-            PointProj pp;
-            finish_point(ps, pg, E, Er, Ec, pp);
-            const float r = w * (mhat - pp.E);
-            float J[6];
-            jacobian6(pp, w, J);
-            float hw = 1.0f, ct = r * r;
-            if (tau > 0.0f) {
-                const float ar = fabsf(r);
-                if (ar > tau) hw = tau / ar;
-                ct = hw * r * r * (2.0f - hw);
-            }
-            accumulate_normal<6>(acc, J, r, hw, ct);
+            const float r = point_row6<SAMPLING, NTAP>(ps, pg, tap, w, mhat, tau, acc);
             if (PPT == 0 && state == 1 && i < N) A.r[base + i] = r;      // streaming variant: residuals stored by a final pass
             return r;
         };

@@ -127,22 +127,7 @@ __global__ __launch_bounds__(NTHR, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsA
 #pragma unroll
                     for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
                 }
-                float E, Er, Ec;
-                if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                PointProj pp;
-                finish_point(ps, pg[jj], E, Er, Ec, pp);
-                const float w = kw[jj];
-                const float r = w * (kmh[jj] - pp.E);
-                float J[6];
-                jacobian6(pp, w, J);
-                float hw = 1.0f, ct = r * r;
-                if (tau > 0.0f) {                   // per-point Huber (extension; cf. CoarseTracker.cpp:445)
-                    const float ar = fabsf(r);
-                    if (ar > tau) hw = tau / ar;
-                    ct = hw * r * r * (2.0f - hw);
-                }
-                accumulate_normal<6>(acc, J, r, hw, ct);
+                const float r = point_row6<SAMPLING, NTAP>(ps, pg[jj], tap[jj], kw[jj], kmh[jj], tau, acc);
                 if (i < N) rcand[i] = r;
             }
         }
