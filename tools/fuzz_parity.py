@@ -1,0 +1,111 @@
+"""Randomised cross-check of every solve path on the GPU box (a one-off hunt for rare divergences, not a test):
+random frame sizes (incl. odd ones), point counts, residual blocks, losses, samplers, start poses with points outside
+the frame — each problem solved by the persistent kernel(s) that would be picked plus the forced alternatives, by the
+host-driven loop, and by the CPU oracle.  Prints one line per disagreement and a summary.
+
+    python tools/fuzz_parity.py [cases] [seed]
+"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+
+capi = importlib.import_module("slam-eds_amd.capi")
+synth = importlib.import_module("slam-eds_amd.synth")
+import pyoracle as po
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+stats = {"lm6": 0, "gn6": 0, "ref12": 0}
+
+
+def solve(al, env, **cfg):
+    for k in ("EDS_LM6_KERNEL", "EDS_REF12_KERNEL", "EDS_REF12_EXEC"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    h = capi.Handle(capi.default_config(**cfg), 1, al.N, al.H, al.W)
+    h.set_alignment(0, al)
+    try:
+        p, q, v, info = h.optimize(0, p=cfg_start[0], q=cfg_start[1], v=cfg_start[2])
+        out = (p, q, v, info, h.residuals(0))
+    except capi.EdsError as e:
+        out = ("fail", e.code)
+    h.close()
+    return out
+
+
+for c in range(cases):
+    H, W = int(rng.integers(40, 500)), int(rng.integers(48, 660))
+    N = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), rng.integers(600, 2100), rng.integers(2100, 5200)], p=[0.1, 0.3, 0.45, 0.15]))
+    N = min(N, (H - 4) * (W - 4) // 3)
+    al = synth.make_alignment(int(rng.integers(1 << 30)), H=H, W=W, N=N, margin=2, rot_deg=float(rng.uniform(0.05, 1.0)),
+                              trans_norm=float(rng.uniform(0.001, 0.02)))
+    sampling = int(rng.integers(0, 2))
+    solver = str(rng.choice(["lm6", "gn6", "ref12"], p=[0.45, 0.1, 0.45]))
+    iters = int(rng.integers(1, 14)) if solver != "gn6" else int(rng.integers(1, 4))
+    far = rng.random() < 0.25
+    p0 = (0.2 if far else 0.004) * rng.standard_normal(3)
+    q0 = synth.quat_from_axis_angle(rng.standard_normal(3), (0.05 if far else 0.003) * rng.random())
+    cfg_start = (p0, q0, al.v_true if rng.random() < 0.7 else al.v0)
+    stats[solver] += 1
+    tag = f"case {c:3d} {H}x{W} N={N} {solver} it={iters} {'bilinear' if sampling else 'bicubic'}{' far' if far else ''}"
+    if solver == "ref12":
+        nb, loss, lp = int(rng.integers(1, 9)), int(rng.integers(0, 3)), float(rng.uniform(0.05, 1.0))
+        kw = dict(solver=capi.SOLVER_REF12, sampling=sampling, num_blocks=nb, loss_type=loss, loss_param=lp, max_num_iterations=iters)
+        runs = {"host": solve(al, {"EDS_REF12_EXEC": "host"}, exec=capi.EXEC_DEVICE, **kw),
+                "wide": solve(al, {"EDS_REF12_KERNEL": "wide"}, exec=capi.EXEC_DEVICE, **kw),
+                "paired": solve(al, {"EDS_REF12_KERNEL": "paired"}, exec=capi.EXEC_DEVICE, **kw)}
+        ref = po.Oracle(al, sampling=sampling, num_blocks=nb, loss_type=loss, loss_param=lp, max_num_iterations=iters).solve_lm(*cfg_start)
+        base = runs["host"]
+        for name, r in runs.items():
+            if isinstance(r[0], str) != (not ref["usable"]):
+                print(tag, f"nb={nb} loss={loss}: {name} usable mismatch vs oracle ({r[:2]}, oracle usable {ref['usable']})"); bad += 1
+                continue
+            if isinstance(r[0], str):
+                continue
+            same_path = r[3]["num_iterations"] == ref["num_iterations"] and r[3]["termination"] == ref["termination"]
+            if not same_path:
+                # legit only when a tolerance decision fell the other way: costs must then agree to the tolerance
+                if abs(r[3]["final_cost"] - ref["final_cost"]) > 2e-4 * max(ref["final_cost"], 1e-12):
+                    print(tag, f"nb={nb} loss={loss}: {name} path differs: it {r[3]['num_iterations']} vs {ref['num_iterations']}, cost {r[3]['final_cost']:.6e} vs {ref['final_cost']:.6e}"); bad += 1
+                continue
+            d = po.se3_distance(r[0], r[1], ref["p"], ref["q"])
+            if d > 5e-4 and N >= 100 and not far and sampling == 0:   # bilinear: kinks make trajectories chaotic
+                print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e}"); bad += 1
+            er = po.Oracle(al, sampling=sampling, num_blocks=nb).eval12(r[0], r[1], r[2], jac=False)["r_raw"]
+            if np.abs(r[4] - er).max() > 5e-5 * max(np.abs(er).max(), 1e-30):
+                print(tag, f"nb={nb} loss={loss}: {name} residuals at the returned state off by {np.abs(r[4] - er).max() / np.abs(er).max():.2e}"); bad += 1
+    else:
+        sv = capi.SOLVER_LM6 if solver == "lm6" else capi.SOLVER_GN6
+        tau = float(rng.choice([0.0, 0.0, 0.005, 0.05]))
+        kw = dict(solver=sv, sampling=sampling, huber_tau=tau, max_num_iterations=iters)
+        runs = {"host": solve(al, {}, exec=capi.EXEC_HOST, **kw), "default": solve(al, {}, exec=capi.EXEC_DEVICE, **kw),
+                "resident": solve(al, {"EDS_LM6_KERNEL": "resident"}, exec=capi.EXEC_DEVICE, **kw),
+                "paired": solve(al, {"EDS_LM6_KERNEL": "paired"}, exec=capi.EXEC_DEVICE, **kw),
+                "wide": solve(al, {"EDS_LM6_KERNEL": "wide"}, exec=capi.EXEC_DEVICE, **kw)}
+        o = po.Oracle(al, sampling=sampling)
+        ref = o.pose6_lm(p0, q0, cfg_start[2], iters=iters, lambda0=0.01, huber_tau=tau) if solver == "lm6" else \
+            o.pose6_gn(p0, q0, cfg_start[2], iters=iters, huber_tau=tau)
+        fails = {k: isinstance(r[0], str) for k, r in runs.items()}
+        if len(set(fails.values())) > 1:
+            print(tag, f"tau={tau}: usable mismatch between paths {fails}"); bad += 1
+            continue
+        if fails["host"]:
+            continue
+        for name, r in runs.items():
+            er = o.pose6_eval(r[0], r[1], cfg_start[2])["r"]
+            if np.abs(r[4] - er).max() > 5e-5 * max(np.abs(er).max(), 1e-30):
+                print(tag, f"tau={tau}: {name} residuals at the returned pose off by {np.abs(r[4] - er).max() / np.abs(er).max():.2e}"); bad += 1
+            d = po.se3_distance(r[0], r[1], runs["host"][0], runs["host"][1])
+            if d > 1e-4 and N >= 100 and not far and sampling == 0:
+                print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e}"); bad += 1
+        if solver == "lm6" and sampling == 0 and not far and N >= 100:
+            from_dev = po.se3_distance(runs["default"][0], runs["default"][1], ref["p"], ref["q"])
+            if from_dev > 5e-4:
+                print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
+print(f"{cases} cases ({stats}), {bad} disagreements")
