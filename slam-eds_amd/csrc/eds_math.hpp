@@ -112,8 +112,10 @@ EDS_HD void state_plus12(const double* p, const double* q, const double* v, cons
     for (int i = 0; i < 3; ++i) po[i] = p[i] + d[i];
     const double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     if (nd > 0.0) {
-        const double s = sin(nd) / nd;
-        const double qd[4] = {s * d[3], s * d[4], s * d[5], cos(nd)};
+        double sn, cs;
+        sincos(nd, &sn, &cs);           // one range reduction for both (the serial solver lane pays for every instruction)
+        const double s = sn / nd;
+        const double qd[4] = {s * d[3], s * d[4], s * d[5], cs};
         double nq[4];
         quat_mul(qd, q, nq);
         EDS_UNROLL

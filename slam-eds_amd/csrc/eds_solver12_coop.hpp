@@ -346,16 +346,14 @@ __device__ inline void coop_fill_pose_block(const double* p, const double* q, co
         o[1 + i6] = s;
     }
     EDS_WSYNC();
-    if (k < nb && i6 == 0) {
+    if (k < nb) {                       // the six lanes of a block all form S, n (same operation order as the serial code);
+        double raw[6];                  // every read of the raw dots precedes the writes below: one wavefront, in lockstep
+        for (int i = 0; i < 6; ++i) raw[i] = o[1 + i];
         double S = 1e-3;
-        for (int i = 0; i < 6; ++i) S += v[i] * o[1 + i];
-        o[0] = 1.0 / sqrt(S);
-        o[7] = S;
-    }
-    EDS_WSYNC();
-    if (k < nb) {
-        const double n = sqrt(o[7]);
-        o[1 + i6] = o[1 + i6] / (n * n * n);
+        for (int i = 0; i < 6; ++i) S += v[i] * raw[i];
+        const double n = sqrt(S);
+        o[1 + i6] = raw[i6] / (n * n * n);
+        if (i6 == 0) { o[0] = 1.0 / n; o[7] = S; }
     }
     EDS_WSYNC();
 }
