@@ -8,9 +8,10 @@
 // image) the minimal stand-ins below provide the same member names and memory layouts.
 //
 // Mirrored members:   Tracker(kf, config), Tracker(config), reset (both overloads), set, optimize (all three
-// overloads), getTransform, getVelocity, linearVelocity, angularVelocity, getLossParams, getInfo, public config.
-// Not mirrored (outside the hot path, reference Tracker.cpp:319-654): getCoord, trackPoints*, getEMatrix,
-// getFMatrix, getFilteredPose, needNewKeyframe — keep the reference implementation for those.
+// overloads), getTransform, getVelocity, linearVelocity, angularVelocity, getLossParams, getInfo, getCoord,
+// needNewKeyframe, public config.
+// Not mirrored (outside the hot path, reference Tracker.cpp:378-648): trackPoints*, getEMatrix, getFMatrix,
+// getFilteredPose — keep the reference implementation for those.
 #pragma once
 #include <algorithm>
 #include <array>
@@ -82,6 +83,8 @@ struct TrackerInfo {                                                            
 // the members of eds::tracking::KeyFrame the tracker touches (KeyFrame.hpp:60-96)
 struct KeyFrame {
     std::vector<cv::Point2d> norm_coord, grad;
+    std::vector<cv::Point2d> coord;         // pixel coordinates (KeyFrame.hpp:80); optional here, kept index-aligned if present
+    std::vector<std::array<double, 2>> tracks;   // Eigen::Vector2d per point (KeyFrame.hpp:92); filled by Tracker::getCoord
     std::vector<double> weights, residuals;
     std::vector<double> inv_depth;          // stand-in for DepthPoints::getIDepth()
     double K_ref[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // row-major 3x3
@@ -244,6 +247,53 @@ class Tracker {
         return std::vector<double>{tau};
     }
     eds::tracking::TrackerInfo getInfo() const { return info; }
+
+    double squared_norm_flow = 0.0;                                                                                             // Tracker.hpp:58
+    /** Tracker::getCoord (Tracker.cpp:319-376): the points re-projected under the current pose; with delete_out_point the
+     *  ones that left the frame are erased from the keyframe (all index-aligned vectors) and from the device copy. */
+    std::vector<cv::Point2d> getCoord(const bool& delete_out_point = false) {
+        std::vector<cv::Point2d> coord;
+        if (!kf || !h) return coord;
+        const int N = (int)kf->norm_coord.size();
+        double p[3] = {px[0], px[1], px[2]}, q[4] = {qx.x(), qx.y(), qx.z(), qx.w()}, v[6];
+        for (int i = 0; i < 6; ++i) v[i] = vx_[i];
+        if (eds_trk_set_state(h, 0, p, q, v) != EDS_OK) throw std::runtime_error(std::string("eds_trk_set_state: ") + eds_last_error());
+        coord.resize(N);
+        std::vector<double> tracks(2 * (size_t)N);
+        std::vector<int32_t> kept(N);
+        int n = 0;
+        if (eds_trk_update_points(h, 0, delete_out_point ? 1 : 0, &coord[0].x, tracks.data(), kept.data(), &n, &squared_norm_flow) != EDS_OK)
+            throw std::runtime_error(std::string("eds_trk_update_points: ") + eds_last_error());
+        coord.resize(n);
+        if (n != N) {                        // what repeated KeyFrame::erasePoint does (KeyFrame.cpp:1060-1106), in one sweep
+#ifdef EDS_HIP_WITH_EDS_TYPES
+            std::vector<char> keep(N, 0);
+            for (int k = 0; k < n; ++k) keep[kept[k]] = 1;
+            for (int i = N - 1; i >= 0; --i) if (!keep[i]) kf->erasePoint(i);
+#else
+            auto compact = [&](auto& vec) {
+                if ((int)vec.size() != N) return;
+                for (int k = 0; k < n; ++k) vec[k] = vec[kept[k]];
+                vec.resize(n);
+            };
+            compact(kf->norm_coord); compact(kf->grad); compact(kf->coord); compact(kf->weights); compact(kf->residuals); compact(kf->inv_depth);
+            kf->tracks.resize(N); compact(kf->tracks);
+#endif
+        }
+        kf->tracks.resize(n);
+        for (int k = 0; k < n; ++k) { kf->tracks[k][0] = tracks[2 * k]; kf->tracks[k][1] = tracks[2 * k + 1]; }                 // Tracker.cpp:364-366
+        return coord;
+    }
+    /** Tracker::needNewKeyframe (Tracker.cpp:650-654). */
+    bool needNewKeyframe(const double& weight_factor = 0.03) const {
+#ifdef EDS_HIP_WITH_EDS_TYPES
+        const int rows = kf->img.rows, cols = kf->img.cols;
+#else
+        const int rows = kf->rows, cols = kf->cols;
+#endif
+        const double image_weight = (cols + rows) * weight_factor;
+        return (image_weight * std::sqrt((float)squared_norm_flow) / (cols + rows)) > 1;
+    }
 };
 
 }}  // namespace eds::tracking

@@ -39,9 +39,21 @@ int main(int argc, char** argv) {
     const eds::tracking::TrackerInfo info = tracker.getInfo();
     double id_err = 0;                       // T_kf_ef * T_ef_kf must be the identity (Tracker.cpp:220)
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += T(r, k) * Tef(k, c); id_err = std::max(id_err, std::fabs(s - (r == c))); }
+    // post-solve point maintenance through the shim (Tracker::getCoord(true) + needNewKeyframe), from a pose that pushes part
+    // of the points out of the frame
+    std::vector<double> res_before = kf->residuals;
+    const double an = std::sqrt(0.1 * 0.1 + 1.0 + 0.2 * 0.2), sh = std::sin(0.025), ch = std::cos(0.025);       // 0.05 rad about (0.1, 1, 0.2)
+    tracker.reset(kf, Eigen::Vector3d{{0.06, -0.03, 0.01}}, Eigen::Quaterniond{{sh * 0.1 / an, sh * 1.0 / an, sh * 0.2 / an, ch}}, true);
+    const std::vector<cv::Point2d> moved = tracker.getCoord(true);
+    const size_t n_after = kf->norm_coord.size();
+    const bool consistent = moved.size() == n_after && kf->grad.size() == n_after && kf->weights.size() == n_after &&
+                            kf->inv_depth.size() == n_after && kf->residuals.size() == n_after && kf->tracks.size() == n_after;
+    double c0 = moved.empty() ? 0 : moved[0].x, c1 = moved.empty() ? 0 : moved.back().y;
     std::printf("{\"ok\": %d, \"t\": [%.17g, %.17g, %.17g], \"R\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], "
-                "\"v\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"num_points\": %u, \"tau\": %.17g, \"residuals\": %zu, \"inverse_err\": %.3g}\n",
+                "\"v\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"num_points\": %u, \"tau\": %.17g, \"residuals\": %zu, \"inverse_err\": %.3g, "
+                "\"kept\": %zu, \"consistent\": %d, \"first_x\": %.17g, \"last_y\": %.17g, \"sq_flow\": %.17g, \"need_kf\": %d, \"first_idp\": %.17g}\n",
                 good ? 1 : 0, Tef(0, 3), Tef(1, 3), Tef(2, 3), Tef(0, 0), Tef(0, 1), Tef(0, 2), Tef(1, 0), Tef(1, 1), Tef(1, 2), Tef(2, 0), Tef(2, 1), Tef(2, 2),
-                v[0], v[1], v[2], v[3], v[4], v[5], info.num_iterations, info.num_points, tracker.config.loss_params[0], kf->residuals.size(), id_err);
+                v[0], v[1], v[2], v[3], v[4], v[5], info.num_iterations, info.num_points, tracker.config.loss_params[0], res_before.size(), id_err,
+                n_after, consistent ? 1 : 0, c0, c1, tracker.squared_norm_flow, tracker.needNewKeyframe(0.03) ? 1 : 0, kf->inv_depth.empty() ? 0.0 : kf->inv_depth[0]);
     return good ? 0 : 1;
 }

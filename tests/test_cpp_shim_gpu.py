@@ -52,3 +52,13 @@ def test_shim_optimize_matches_oracle(gpu, capi, synth, po, tmp_path, nb, loss):
     assert r["inverse_err"] < 1e-12                      # optimize returns T_kf_ef = getTransform().inverse()
     r_fin = po.Oracle(al, num_blocks=nb).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
     assert r["tau"] == pytest.approx(po.loss_param(r_fin, po.LP_MAD)[0], rel=1e-3)       # loss_params rewritten (Tracker.cpp:233)
+    # Tracker::getCoord(true) + needNewKeyframe through the shim, against the point-maintenance oracle
+    import np_points_oracle as pto
+    pm = np.array([0.06, -0.03, 0.01])
+    qm = synth.quat_from_axis_angle([0.1, 1.0, 0.2], 0.05)
+    refp = pto.get_coord(al.norm_coord, al.idp, al.coord, (al.fx, al.fy, al.cx, al.cy), al.H, al.W, pm, qm, True)
+    assert r["consistent"] == 1 and r["kept"] == len(refp["kept"]) and 0 < r["kept"] < al.N
+    assert r["first_x"] == pytest.approx(refp["coord"][0, 0], abs=1e-4) and r["last_y"] == pytest.approx(refp["coord"][-1, 1], abs=1e-4)
+    assert r["sq_flow"] == pytest.approx(refp["mean_sq_flow"], rel=1e-4)
+    assert bool(r["need_kf"]) == pto.need_new_keyframe(refp["mean_sq_flow"], al.H, al.W, 0.03)
+    assert r["first_idp"] == al.idp[refp["kept"][0]]
