@@ -1,8 +1,10 @@
 // Persistent on-device solve (EDS_EXEC_DEVICE): one workgroup per alignment runs the whole
 // iteration loop — residual+Jacobian pass, wavefront reduction, small dense solve, pose update,
 // accept test — without returning to the host between iterations.
-//   eds_fused.hip    pose-only solvers (GN6 / LM6)
-//   eds_fused12.hip  the reference problem (REF12: 12 local parameters, Ceres-LM semantics)
+//   eds_fused.hip    pose-only solvers (GN6 / LM6), point constants in registers: the lowest latency
+//   eds_stream6.hip  the same with constants re-read per pass, in two shapes: two alignments per CU (large batches) and
+//                    one 512-thread workgroup (keyframes with more than 2 048 points)
+//   eds_fused12.hip  the reference problem (REF12: 12 local parameters, Ceres-LM semantics), same two shapes
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -48,7 +50,7 @@ bool eds_fused12_supported(const eds_trk* h, int first, int count);
 int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);
 struct EdsArrays;
-// eds_stream6.hip: 256-thread streaming variant of the pose-only kernel (several alignments per CU)
+// eds_stream6.hip (wide = 1: one 512-thread workgroup per CU; 0: two 256-thread workgroups per CU)
 void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,
                         int count, int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
 
