@@ -96,6 +96,35 @@ def _flow_rows(x, y, rho):
     return f0, f1
 
 
+def render_frame(H, W, K, norm_coord, grad, idp, p, q, v, *, blur_ksize: int = 7, blur_sigma: float = 1.5, noise: float = 0.05, rng=None):
+    """The brightness-increment frame the event camera would integrate for keyframe points seen under pose (p, q) with
+    velocity v: the normalised model m_hat = A v / ||A v|| splatted at the projections with 4-tap bilinear voting
+    (Utils.cpp:83-107), blurred, optionally noised, divided by its Frobenius norm (EventFrame.cpp:359-383)."""
+    fx, fy, cx, cy = K
+    x, y = norm_coord[:, 0], norm_coord[:, 1]
+    f0, f1 = _flow_rows(x, y, idp)
+    A = -(grad[:, :1] * f0 + grad[:, 1:] * f1)
+    m = A @ v
+    m_hat = m / np.sqrt(1e-3 + np.sum(m * m))       # global norm = one block
+    z = 1.0 / (idp + 1e-5)
+    P = (_quat_to_R(q) @ np.stack([x * z, y * z, z], axis=0)).T + p
+    u = fx * P[:, 0] / P[:, 2] + cx
+    vv = fy * P[:, 1] / P[:, 2] + cy
+    img = np.zeros((H, W))
+    x0 = np.floor(u).astype(np.int64)
+    y0 = np.floor(vv).astype(np.int64)
+    ax = u - x0
+    ay = vv - y0
+    for dx, dy, wgt in ((0, 0, (1 - ax) * (1 - ay)), (0, 1, (1 - ax) * ay), (1, 0, ax * (1 - ay)), (1, 1, ax * ay)):
+        xi, yi = x0 + dx, y0 + dy
+        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
+        np.add.at(img, (yi[ok], xi[ok]), (wgt * m_hat)[ok])
+    img = gaussian_blur(img, blur_ksize, blur_sigma)
+    if noise > 0:
+        img = img + (rng or np.random.default_rng(0)).normal(0.0, noise * np.abs(img).max(), size=img.shape)
+    return img / np.linalg.norm(img)
+
+
 def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, *,
                    rot_deg: float = 0.2, trans_norm: float = 0.004,
                    blur_ksize: int = 7, blur_sigma: float = 1.5, noise: float = 0.05,
@@ -133,31 +162,8 @@ def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, 
     t_dir = rng.standard_normal(3)
     p_true = trans_norm * t_dir / np.linalg.norm(t_dir)
 
-    # normalised model at the truth velocity (global norm = one block)
-    x, y = norm_coord[:, 0], norm_coord[:, 1]
-    f0, f1 = _flow_rows(x, y, idp)
-    A = -(grad[:, :1] * f0 + grad[:, 1:] * f1)
-    m = A @ v_true
-    m_hat = m / np.sqrt(1e-3 + np.sum(m * m))
-
-    # project under the truth pose and splat with 4-tap bilinear voting (Utils.cpp:83-107)
-    z = 1.0 / (idp + 1e-5)
-    P = (_quat_to_R(q_true) @ np.stack([x * z, y * z, z], axis=0)).T + p_true
-    u = fx * P[:, 0] / P[:, 2] + cx
-    vv = fy * P[:, 1] / P[:, 2] + cy
-    img = np.zeros((H, W))
-    x0 = np.floor(u).astype(np.int64)
-    y0 = np.floor(vv).astype(np.int64)
-    ax = u - x0
-    ay = vv - y0
-    for dx, dy, wgt in ((0, 0, (1 - ax) * (1 - ay)), (0, 1, (1 - ax) * ay), (1, 0, ax * (1 - ay)), (1, 1, ax * ay)):
-        xi, yi = x0 + dx, y0 + dy
-        ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)
-        np.add.at(img, (yi[ok], xi[ok]), (wgt * m_hat)[ok])
-    img = gaussian_blur(img, blur_ksize, blur_sigma)
-    if noise > 0:
-        img = img + rng.normal(0.0, noise * np.abs(img).max(), size=img.shape)
-    img /= np.linalg.norm(img)
+    img = render_frame(H, W, (fx, fy, cx, cy), norm_coord, grad, idp, p_true, q_true, v_true,
+                       blur_ksize=blur_ksize, blur_sigma=blur_sigma, noise=noise, rng=rng)
 
     if start == "ctor":
         v0 = np.full(6, 0.001)
