@@ -775,10 +775,10 @@ int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau) {
     if (!tau) return fail(EDS_ERR_INVALID, "null output");
     Slot& s = h->slots[slot];
     if (method == EDS_LP_CONSTANT) return EDS_OK;
-    if (s.res_on_device && (method == EDS_LP_MAD || method == EDS_LP_STD) && eds_points_supported(h, slot, 1)) {
-        EDS_HIP_TRY(hipSetDevice(h->dev));          // residuals still in HBM: select there, 8 bytes come back
-        return eds_points_loss_param(h, slot, 1, method, tau);
-    }
+    // One slot: bring the residuals over (8 KB; the caller wants them for kf->residuals anyway, Tracker.cpp:223-230) and
+    // select on the host — 40 us against 80 us for the LDS sort of a single alignment.  Batches use
+    // eds_trk_loss_param_batch, which selects on the device (0.5 us per alignment).
+    EDS_HIP_TRY(hipSetDevice(h->dev));
     if ((rc = materialise_residuals(h, slot))) return rc;
     if ((int)s.residuals.size() != s.N || s.N < 1) return fail(EDS_ERR_STATE, "no residuals stored");
     std::vector<double>& r = s.residuals;

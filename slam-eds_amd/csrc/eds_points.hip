@@ -243,8 +243,32 @@ int eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, do
     const int ppt = (sl.N + EDS_PTS_THREADS - 1) / EDS_PTS_THREADS;
     hipLaunchKernelGGL(k_update_points, dim3(1), dim3(EDS_PTS_THREADS), 0, h->st, h->arrays(), slot, ppt, delete_out, pb.d_pose, pb.d_coord,
                        pb.d_track, pb.d_kept, pb.d_summary);
+    // one round trip: everything lands in the handle's pinned staging (36 N bytes fit its 48 Np), then a single sync
+    const size_t N0 = (size_t)sl.N;
+    char* stage = reinterpret_cast<char*>(h->h_f32);
+    double* h_sum = reinterpret_cast<double*>(stage);
+    double* h_coord = h_sum + 2;
+    double* h_track = h_coord + 2 * N0;
+    int32_t* h_kept = reinterpret_cast<int32_t*>(h_track + 2 * N0);
+    const bool fits = 16 + 36 * N0 <= h->h_f32_elems * 4;
     double summary[2] = {0, 0};
     e = hipGetLastError();
+    if (fits) {
+        if (e == hipSuccess) e = hipMemcpyAsync(h_sum, pb.d_summary, 16, hipMemcpyDeviceToHost, h->st);
+        if (e == hipSuccess && coord_xy) e = hipMemcpyAsync(h_coord, pb.d_coord, N0 * 16, hipMemcpyDeviceToHost, h->st);
+        if (e == hipSuccess && tracks_xy) e = hipMemcpyAsync(h_track, pb.d_track, N0 * 16, hipMemcpyDeviceToHost, h->st);
+        if (e == hipSuccess && kept_index) e = hipMemcpyAsync(h_kept, pb.d_kept, N0 * 4, hipMemcpyDeviceToHost, h->st);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+        summary[0] = h_sum[0]; summary[1] = h_sum[1];
+        const int n = (int)summary[0];
+        if (coord_xy && n > 0) std::memcpy(coord_xy, h_coord, (size_t)n * 16);
+        if (tracks_xy && n > 0) std::memcpy(tracks_xy, h_track, (size_t)n * 16);
+        if (kept_index && n > 0) std::memcpy(kept_index, h_kept, (size_t)n * 4);
+        if (n_kept) *n_kept = n;
+        if (mean_sq_flow) *mean_sq_flow = summary[1];
+        return EDS_OK;
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(summary, pb.d_summary, 16, hipMemcpyDeviceToHost, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
