@@ -231,6 +231,24 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj,
         }
+        if world == 1 and a.exec_ == "device" and a.sampling == "bicubic" and not a.no_ref12:
+            # the sampler north_star names (bilinear, 2x2 taps; the reference itself samples bicubically): informational
+            h.set_config(capi.default_config(device=0, sampling=capi.SAMPLE_BILINEAR, solver=cfg.solver, exec=capi.EXEC_DEVICE,
+                                             max_num_iterations=a.iters, lambda0=a.lambda0))
+            b_ms, b_dev = [], []
+            for k in range(4):
+                h.set_states(0, p0, q0, v0)
+                t1 = time.perf_counter()
+                h.optimize_batch(0, 0, B, sync=True)
+                b_ms.append(1e3 * (time.perf_counter() - t1))
+                b_dev.append(h.info(0)["device_time_us"] * 1e-3)
+            bt = h.results(0, B)
+            per_pt_b = BYTES_RESJAC["bilinear"] + BYTES_REDUCE
+            out["bilinear_sampling"] = {"iterations_per_s": B * float(np.mean(bt[:, 14])) / (float(np.median(b_ms[1:])) * 1e-3),
+                                        "kernel_ms": float(np.median(b_dev[1:])),
+                                        "roofline_frac": B * N * passes * per_pt_b / (float(np.median(b_dev[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "success_fraction": float(np.mean(bt[:, 15]))}
+            h.set_config(cfg)
         if world == 1 and a.exec_ == "device" and N <= 2048 and not a.no_ref12:
             # the reference's own problem on the same batch (12 local parameters, Ceres-LM rules; one residual block, no
             # loss): informational, outside the timed region
