@@ -201,7 +201,7 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": B * N * passes * per_pt,
                     "note": f"{per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch (J never materialised)"}
-            t = pmc_traffic(kname, a)
+            t = pmc_traffic(kname + ("<0" if a.sampling == "bicubic" else "<1"), a)      # first template argument = sampler
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
@@ -211,7 +211,7 @@ def main():
                    "frac": ach_rj / HBM_PEAK_GBS, "traffic": None, "kernel_ms": rj_ms,
                    "point_evals_per_s": B * N / (rj_ms * 1e-3),
                    "resjac_plus_reduce_ms": both_ms}
-        t = pmc_traffic("eds_resjac_kernel", a)
+        t = pmc_traffic("eds_resjac_kernel" + ("<0" if a.sampling == "bicubic" else "<1"), a)
         if t:
             roof_rj["traffic"], roof_rj["traffic_source"] = t["bytes"], t["source"]
         if roof is None:
