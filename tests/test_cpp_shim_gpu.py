@@ -62,3 +62,13 @@ def test_shim_optimize_matches_oracle(gpu, capi, synth, po, tmp_path, nb, loss):
     assert r["sq_flow"] == pytest.approx(refp["mean_sq_flow"], rel=1e-4)
     assert bool(r["need_kf"]) == pto.need_new_keyframe(refp["mean_sq_flow"], al.H, al.W, 0.03)
     assert r["first_idp"] == al.idp[refp["kept"][0]]
+
+
+def test_shim_eds_types_branch_compiles_against_mock_headers():
+    """The EDS_HIP_WITH_EDS_TYPES branch of Tracker.hpp (what an EDS build would compile: Eigen / OpenCV / Rock types and the
+    real KeyFrame) cannot be built here for lack of those libraries; tests/cpp/mock_eds declares the members it touches
+    with the reference's names and signatures so that the branch is at least compile-checked."""
+    src = os.path.join(HERE, "cpp", "shim_eds_types_check.cpp")
+    res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(HERE, "cpp", "mock_eds"), src],
+                         capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
