@@ -90,8 +90,8 @@ typedef struct eds_trk_cfg {
     double  gradient_tolerance;     /* 1e-8 (Tracker.cpp:142) */
     double  parameter_tolerance;    /* 1e-6 (Tracker.cpp:143) */
     int32_t nc;                     /* 1: PhotometricErrorNC residual (PhotometricErrorNC.hpp:124-192): r = w (m/||m|| - E/||E||_block).
-                                     * REF12 and eval(ncols = 12) only; solved by the host-driven loop; build_event_frame
-                                     * then stores the frame un-normalised, as that functor requires (EventFrame.cpp:278-281) */
+                                     * REF12 and eval(ncols = 12) only; build_event_frame then stores the frame un-normalised,
+                                     * as that functor requires (EventFrame.cpp:278-281) */
     int32_t reserved[7];
 } eds_trk_cfg;
 

@@ -144,6 +144,29 @@ void gather12(const eds_trk* h, int slot, int range_max_N, edss::Sums12* S) {
     const double* base = h->h_part + (size_t)slot * h->max_seg * EDS_RED_K;
     for (int k = 0; k < nb; ++k)
         for (int c = 0; c < cpb; ++c) edss::unpack12_add(base + (size_t)(k * cpb + c) * EDS_RED_K, S, k, c == 0);
+    // The kernels emit the velocity columns WITHOUT the local-parameterisation factor Pv = (I - v v^T/|v|^2)/|v| (the same for
+    // every point): apply it here, once and in fp64, J^T J -> P^T (J^T J) P, J^T r -> P^T (J^T r), P = blockdiag(I_6, Pv).
+    // (Done per point in fp32 it left 1e-7-level noise along v, which the weakly determined velocity block amplified.)
+    const double* Pv = h->h_pose + (size_t)slot * EDS_POSE_STRIDE + EDS_PB_PV;
+    for (int k = 0; k < nb; ++k) {
+        double T[144];
+        double* H = S->H[k];
+        for (int i = 0; i < 12; ++i)
+            for (int j = 0; j < 12; ++j) {
+                double t = H[12 * i + j];
+                if (j >= 6) { t = 0.0; for (int c = 0; c < 6; ++c) t += H[12 * i + 6 + c] * Pv[6 * c + (j - 6)]; }
+                T[12 * i + j] = t;
+            }
+        for (int i = 0; i < 12; ++i)
+            for (int j = 0; j < 12; ++j) {
+                double t = T[12 * i + j];
+                if (i >= 6) { t = 0.0; for (int c = 0; c < 6; ++c) t += Pv[6 * c + (i - 6)] * T[12 * (6 + c) + j]; }
+                H[12 * i + j] = t;
+            }
+        double g6[6];
+        for (int i = 0; i < 6; ++i) { g6[i] = 0.0; for (int c = 0; c < 6; ++c) g6[i] += Pv[6 * c + i] * S->g[k][6 + c]; }
+        for (int i = 0; i < 6; ++i) S->g[k][6 + i] = g6[i];
+    }
 }
 
 int fetch_residuals(eds_trk* h, int first, int count) {
@@ -671,6 +694,15 @@ int eds_trk_eval(eds_trk* h, int slot, const double p[3], const double q[4], con
         for (int k = 0; k < ncols; ++k) {
             EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dJ + k * plane + (size_t)slot * h->Np, (size_t)N * 4, hipMemcpyDeviceToHost));
             for (int i = 0; i < N; ++i) J[(size_t)i * ncols + k] = h->h_f32[i];
+        }
+        if (ncols == 12) {               // velocity columns: the local-parameterisation factor, in fp64 (see gather12)
+            const double* Pv = h->h_pose + (size_t)slot * EDS_POSE_STRIDE + EDS_PB_PV;
+            for (int i = 0; i < N; ++i) {
+                double* row = J + (size_t)i * 12 + 6;
+                double out[6];
+                for (int c = 0; c < 6; ++c) { out[c] = 0.0; for (int k = 0; k < 6; ++k) out[c] += row[k] * Pv[6 * k + c]; }
+                for (int c = 0; c < 6; ++c) row[c] = out[c];
+            }
         }
     }
     if (ncols == 6) {

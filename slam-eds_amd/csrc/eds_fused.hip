@@ -313,11 +313,11 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (h->cfg.solver == EDS_SOLVER_REF12) {
         // The persistent REF12 kernels beat the host-driven loop at every batch size (one 2 000-point solve: 0.29 ms vs
         // 0.42 ms; B = 1024: 8.3 M vs 0.37 M LM iterations/s).  The host loop remains for what they do not cover
-        // (more than 8 residual blocks, the NC residual).
+        // (more than 8 residual blocks).
         const char* force = getenv("EDS_REF12_EXEC");                // tuning knob: "device" | "host"
         const bool want_device = force ? (std::strcmp(force, "device") == 0) : true;
-        if (want_device && !h->cfg.nc && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
-        return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks, > 2048 points, NC residual
+        if (want_device && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
+        return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks
     }
     EdsFusedBuffers& fb = h->fused;
     if (fb.pending_count > 0) return eds_internal_fail(EDS_ERR_STATE, "previous batch not collected: call eds_trk_sync first");

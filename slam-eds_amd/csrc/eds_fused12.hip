@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
@@ -40,7 +41,7 @@ using namespace edsd;
 
 typedef double acc4d __attribute__((ext_vector_type(4)));
 
-template <int SAMPLING, int NTHR, int CAP>
+template <int SAMPLING, int NTHR, int CAP, bool NC>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
                                                               double loss_a, double ftol, double gtol, double ptol, int nb) {
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     __shared__ float s_patch[NTAP][CAP];
     __shared__ int s_cell[CAP];
     __shared__ double s_G[EDS_DEV_MAX_BLOCKS * 36];
+    __shared__ double s_nc[EDS_DEV_MAX_BLOCKS][8];    // NC residual: per block 1/||E||, then sum_j E_j J'_j / ||E||^3
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const double* __restrict__ Gg = A.G + (size_t)slot * EDS_MAX_BLOCKS * 36;
@@ -116,6 +118,14 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
         acc4d C = {0, 0, 0, 0}, C2 = {0, 0, 0, 0};
         int cb = -1;                    // residual block the tile currently belongs to (wave-uniform)
+        // One sweep over the points.  MODE 0: the plain residual (PhotometricError).  PhotometricErrorNC needs the block norm of
+        // the sampled brightness before any row can be formed, so it sweeps twice: MODE 1 samples, forms the un-weighted pose
+        // columns J' = -dE and accumulates [J' | E]^T [J' | E] (which holds sum E^2 and sum E J') while stashing E and J' in
+        // seven planes of the otherwise unused Jacobian buffer; MODE 2 re-reads the stash (no frame access) and emits the rows
+        //   w (J'/||E|| - E sum_j E_j J'_j/||E||^3),  velocity columns as for the plain residual,  r = w (m/||m|| - E/||E||).
+        auto sweep = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const size_t jplane = (size_t)A.B * A.Np;
         for (int j0 = 0; j0 < N; j0 += 2 * nthr) {
             // phase A: two points per lane: constants from HBM/L2, projection, cache probe, gathers in flight
             PointKf kf[2];
@@ -131,9 +141,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const float* __restrict__ c = A.kf + o;                 // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
                 const size_t pl = A.kf_plane;
                 kf[jj].x = c[EDS_KF_X * pl]; kf[jj].y = c[EDS_KF_Y * pl]; kf[jj].rhop = c[EDS_KF_RHO * pl] + 1e-5f;
-                kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
                 kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;
                 kgx[jj] = c[EDS_KF_GX * pl]; kgy[jj] = c[EDS_KF_GY * pl];
+                miss[jj] = false;
+                if (MODE == 2) continue;                                // rows come from the stash: no projection, no gather
+                kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
                 project_point(ps, kf[jj], pg[jj]);
                 const bool cached = i < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
@@ -147,20 +159,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][i];
                 }
             }
-            // phase B: residual + 1x12 row (closed forms of SURVEY §8a), rows through LDS into the MFMA (eds_fused12.hip)
+            // phase B: residual + 1x12 row (closed forms of SURVEY §8a), rows through LDS into the MFMA
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
                 const bool valid = i < N;
-                if (miss[jj] && i < CAP) {
-#pragma unroll
-                    for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
-                }
-                float E, Er, Ec;
-                if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
-                PointProj pp;
-                finish_point(ps, pg[jj], E, Er, Ec, pp);
                 const int i_first = j0 + jj * nthr + wave * 64;        // this wavefront's 64 consecutive points
                 const int i_last = (i_first + 63 < N) ? i_first + 63 : N - 1;
                 const int b_lo = edsc::uniform_int(block_of(i_first < N ? i_first : 0, ne, nb));
@@ -180,22 +183,55 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     for (int k = 0; k < 6; ++k) gv[k] = (float)bk[1 + k];
                 }
                 const float w = kw[jj];                              // 0 for out-of-range lanes: their rows vanish
-                float ka[6];
-                model_row(kf[jj].x, kf[jj].y, kf[jj].rhop - 1e-5f, kgx[jj], kgy[jj], ka);
-                float m = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) m += ka[k] * vf[k];
                 float x[13];
-                x[12] = w * (m * inv_n - pp.E);
-                x[0] = -w * pp.g0; x[1] = -w * pp.g1; x[2] = -w * pp.g2;
-                const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];      // R X = P - t
-                const float w2 = -2.0f * w;
-                x[3] = w2 * (ry * pp.g2 - rz * pp.g1);
-                x[4] = w2 * (rz * pp.g0 - rx * pp.g2);
-                x[5] = w2 * (rx * pp.g1 - ry * pp.g0);
+                float* __restrict__ st7 = A.J + base + (valid ? i : 0);      // NC stash: planes 0..5 J', plane 6 E
+                if (MODE != 2) {
+                    if (miss[jj] && i < CAP) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) x[6 + k] = w * (ka[k] * inv_n - m * gv[k]);             // projector applied by the solver
-                if (valid) A.mhat[base + i] = x[12];                  // candidate residual
+                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
+                    }
+                    float E, Er, Ec;
+                    if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                    else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                    PointProj pp;
+                    finish_point(ps, pg[jj], E, Er, Ec, pp);
+                    const float wp = MODE == 1 ? (valid ? 1.0f : 0.0f) : w;  // NC: pose columns un-weighted until the norm is known
+                    x[0] = -wp * pp.g0; x[1] = -wp * pp.g1; x[2] = -wp * pp.g2;
+                    const float rx = pp.Px - ps.t[0], ry = pp.Py - ps.t[1], rz = pp.Pz - ps.t[2];      // R X = P - t
+                    const float w2 = -2.0f * wp;
+                    x[3] = w2 * (ry * pp.g2 - rz * pp.g1);
+                    x[4] = w2 * (rz * pp.g0 - rx * pp.g2);
+                    x[5] = w2 * (rx * pp.g1 - ry * pp.g0);
+                    x[12] = pp.E;
+                }
+                if (MODE == 1) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) x[6 + k] = 0.0f;
+                    x[12] = valid ? x[12] : 0.0f;
+                    if (valid) {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) st7[k * jplane] = x[k];
+                        st7[6 * jplane] = x[12];
+                    }
+                } else {
+                    float ka[6];
+                    model_row(kf[jj].x, kf[jj].y, kf[jj].rhop - 1e-5f, kgx[jj], kgy[jj], ka);
+                    float m = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) m += ka[k] * vf[k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) x[6 + k] = w * (ka[k] * inv_n - m * gv[k]);         // projector applied by the solver
+                    if (MODE == 0) {
+                        x[12] = w * (m * inv_n - x[12]);
+                    } else {                                         // NC rows from the stash and the block statistics
+                        const double* nk = &s_nc[b_lo == b_hi ? b_lo : myb][0];
+                        const float inv_e = (float)nk[0], E = st7[6 * jplane];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) x[k] = w * (st7[k * jplane] * inv_e - E * (float)nk[1 + k]);
+                        x[12] = w * (m * inv_n - E * inv_e);
+                    }
+                    if (valid) A.mhat[base + i] = x[12];              // candidate residual
+                }
                 if (i_first < N) {
                     for (int b = b_lo; b <= b_hi; ++b) {
                         if (b != cb) {
@@ -220,6 +256,24 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
         }
         if (cb >= 0) flush(C + C2, cb);
+        C = acc4d{0, 0, 0, 0}; C2 = acc4d{0, 0, 0, 0}; cb = -1;
+        };
+        if (!NC) {
+            sweep(std::integral_constant<int, 0>());
+        } else {
+            sweep(std::integral_constant<int, 1>());
+            __syncthreads();
+            if (tid < nb) {                     // ||E||_block and sum_j E_j J'_j / ||E||^3 from the tile of sweep 1 (PhotometricErrorNC.hpp:151-186)
+                const double SE = 1e-3 + sums.s[tid];
+                const double inv = 1.0 / sqrt(SE);
+                s_nc[tid][0] = inv;
+                for (int c = 0; c < 6; ++c) s_nc[tid][1 + c] = sums.g[tid][c] * inv / SE;
+            }
+            __syncthreads();
+            for (int k = 1 + tid; k < (int)(sizeof(sums) / sizeof(double)); k += nthr) reinterpret_cast<double*>(&sums)[k] = 0.0;
+            __syncthreads();
+            sweep(std::integral_constant<int, 2>());
+        }
         EDS12_STAMP(0);
         __syncthreads();
         EDS12_STAMP(1);
@@ -296,13 +350,15 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     }
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
     hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH12(S, T, C)                                                                                                     \
-    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C>), dim3(count), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters,      \
+#define EDS_LAUNCH12_(S, T, C, NCM)                                                                                               \
+    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM>), dim3(count), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
                        h->cfg.parameter_tolerance, nb)
+#define EDS_LAUNCH12(S, T, C) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true); else EDS_LAUNCH12_(S, T, C, false); } while (0)
     if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1536); else EDS_LAUNCH12(1, 512, 1536); }
     else { if (bicubic) EDS_LAUNCH12(0, 256, 320); else EDS_LAUNCH12(1, 256, 320); }
 #undef EDS_LAUNCH12
+#undef EDS_LAUNCH12_
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));

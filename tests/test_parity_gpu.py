@@ -615,8 +615,9 @@ def test_nc_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
     # (a tolerance exit one iteration apart between fp32 and fp64 sums is legitimate and would make the counts differ)
     h = make_handle(capi, al, exec=ex, solver=capi.SOLVER_REF12, num_blocks=nb, nc=1, loss_type=loss, loss_param=0.2,
                     max_num_iterations=6)
-    p, q, v, info = h.optimize(0, v=al.v_true)           # exec=device routes NC solves to the host-driven loop (documented)
+    p, q, v, info = h.optimize(0, v=al.v_true)
     assert info["success"] and ref["usable"]
+    assert (info["device_time_us"] > 0) == (ex == 1)     # exec=device: the persistent kernel's two-sweep NC evaluation
     assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
     assert np.abs(v - ref["v"]).max() <= 1e-4
     assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
