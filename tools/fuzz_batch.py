@@ -1,0 +1,56 @@
+"""Randomised check of batched launches with ragged point counts: every slot of a batch must give what the same problem
+gives when solved alone (whatever kernel shape either launch picks).  One-off hunt, not a test.
+
+    python tools/fuzz_batch.py [trials] [seed]
+"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+capi = importlib.import_module("slam-eds_amd.capi"); synth = importlib.import_module("slam-eds_amd.synth")
+import pyoracle as po
+trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+H, W = 120, 160
+pool = [synth.make_alignment(int(rng.integers(1 << 30)), H=H, W=W, N=int(n), margin=2) for n in
+        list(rng.integers(1, 60, 6)) + list(rng.integers(60, 700, 14)) + list(rng.integers(700, 2300, 8))]
+bad = 0
+for t in range(trials):
+    B = int(rng.choice([2, 7, 33, 97, 130, 257, 300, 520]))
+    solver = capi.SOLVER_REF12 if rng.random() < 0.5 else (capi.SOLVER_LM6 if rng.random() < 0.8 else capi.SOLVER_GN6)
+    kw = dict(solver=solver, exec=capi.EXEC_DEVICE, sampling=int(rng.integers(0, 2)), max_num_iterations=int(rng.integers(1, 9)))
+    if solver == capi.SOLVER_REF12:
+        kw.update(num_blocks=int(rng.integers(1, 9)), loss_type=int(rng.integers(0, 3)), loss_param=float(rng.uniform(0.1, 1.0)))
+    else:
+        kw.update(huber_tau=float(rng.choice([0.0, 0.02])))
+    pick = rng.integers(0, len(pool), B)
+    Nmax = max(pool[i].N for i in pick)
+    hb = capi.Handle(capi.default_config(**kw), B, Nmax, H, W)
+    for b, i in enumerate(pick):
+        hb.set_alignment(b, pool[i])
+    first = int(rng.integers(0, max(1, B // 3))); count = int(rng.integers(1, B - first + 1))     # a sub-range of the slots
+    hb.optimize_batch(0, first, count)
+    tab = hb.results(first, count)
+    res = [hb.residuals(first + k) if tab[k, 15] == 1.0 else None for k in range(count)]
+    hb.close()
+    singles = {}
+    for k in range(count):
+        i = int(pick[first + k])
+        if i not in singles:
+            hs = capi.Handle(capi.default_config(**kw), 1, pool[i].N, H, W)
+            hs.set_alignment(0, pool[i])
+            hs.optimize_batch(0, 0, 1)
+            ts = hs.results(0, 1)[0]
+            singles[i] = (ts, hs.residuals(0) if ts[15] == 1.0 else None)
+            hs.close()
+        ts, rs = singles[i]
+        if ts[15] != tab[k, 15] or ts[14] != tab[k, 14]:
+            print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver}: status/iterations differ: batch {tab[k, 14:16]} single {ts[14:16]}"); bad += 1
+            continue
+        if ts[15] != 1.0:
+            continue
+        d = po.se3_distance(tab[k, 0:3], tab[k, 3:7], ts[0:3], ts[3:7])
+        dr = np.abs(res[k] - rs).max() / max(np.abs(rs).max(), 1e-30)
+        if (d > 1e-5 or dr > 1e-3) and pool[i].N >= 100:
+            print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver} kw={kw}: pose differs by {d:.2e}, residuals by {dr:.2e}"); bad += 1
+    print(f"trial {t}: B={B} range [{first}, {first + count}) solver={solver} ok", flush=True)
+print(f"{trials} trials, {bad} disagreements")
