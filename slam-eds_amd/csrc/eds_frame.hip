@@ -110,8 +110,9 @@ __global__ void k_store(const double* __restrict__ src, const double* __restrict
 }  // namespace
 
 void eds_frame_free(EdsFrameBuffers* fb) {
-    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex, fb->d_ey, fb->d_pol};
+    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex};     // d_ey, d_pol are slices of d_ex
     for (void* p : d) if (p) hipFree(p);
+    if (fb->h_events) hipHostFree(fb->h_events);
     *fb = EdsFrameBuffers();
 }
 
@@ -143,19 +144,32 @@ int eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, cons
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(frame accumulation)");
     }
     if (n_events > fb.cap_events) {
-        void* d[] = {fb.d_ex, fb.d_ey, fb.d_pol};
-        for (void* p : d) if (p) hipFree(p);
-        fb.cap_events = n_events + n_events / 4 + 1024;
-        if (hipMalloc((void**)&fb.d_ex, (size_t)fb.cap_events * 2) != hipSuccess || hipMalloc((void**)&fb.d_ey, (size_t)fb.cap_events * 2) != hipSuccess ||
-            hipMalloc((void**)&fb.d_pol, (size_t)fb.cap_events) != hipSuccess)
+        if (fb.d_ex) hipFree(fb.d_ex);
+        if (fb.h_events) hipHostFree(fb.h_events);
+        fb.d_ex = fb.d_ey = nullptr; fb.d_pol = nullptr; fb.h_events = nullptr;
+        fb.cap_events = (n_events + n_events / 4 + 1024 + 7) & ~7;
+        const size_t bytes = (size_t)fb.cap_events * 5;
+        if (hipMalloc((void**)&fb.d_ex, bytes) != hipSuccess || hipHostMalloc((void**)&fb.h_events, bytes, hipHostMallocDefault) != hipSuccess) {
+            fb.cap_events = 0;
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(events)");
+        }
+        fb.d_ey = fb.d_ex + fb.cap_events;
+        fb.d_pol = reinterpret_cast<uint8_t*>(fb.d_ey + fb.cap_events);
     }
     hipStream_t st = h->st;
     hipError_t e = hipSuccess;
-    if (n_events > 0) {
-        e = hipMemcpyAsync(fb.d_ex, ex, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(fb.d_ey, ey, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(fb.d_pol, pol, (size_t)n_events, hipMemcpyHostToDevice, st);
+    if (n_events > 0) {                 // pack into the pinned staging, one asynchronous copy
+        const size_t cap = (size_t)fb.cap_events;
+        std::memcpy(fb.h_events, ex, (size_t)n_events * 2);
+        std::memcpy(fb.h_events + cap * 2, ey, (size_t)n_events * 2);
+        std::memcpy(fb.h_events + cap * 4, pol, (size_t)n_events);
+        if ((size_t)n_events * 8 >= cap * 5)    // nearly full: one copy of everything; else three tight ones
+            e = hipMemcpyAsync(fb.d_ex, fb.h_events, cap * 5, hipMemcpyHostToDevice, st);
+        else {
+            e = hipMemcpyAsync(fb.d_ex, fb.h_events, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(fb.d_ey, fb.h_events + cap * 2, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(fb.d_pol, fb.h_events + cap * 4, (size_t)n_events, hipMemcpyHostToDevice, st);
+        }
     }
     if (e == hipSuccess) e = hipMemsetAsync(fb.d_img, 0, n * 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 16, st);

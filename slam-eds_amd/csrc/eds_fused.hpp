@@ -59,8 +59,9 @@ void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFus
 struct EdsFrameBuffers {
     float *d_mapx = nullptr, *d_mapy = nullptr;     // forward undistortion LUT (H x W), optional
     double *d_img = nullptr, *d_tmp = nullptr, *d_norm = nullptr;
-    uint16_t *d_ex = nullptr, *d_ey = nullptr;
+    uint16_t *d_ex = nullptr, *d_ey = nullptr;     // slices of ONE device allocation [x | y | polarity]
     uint8_t* d_pol = nullptr;
+    uint8_t* h_events = nullptr;                   // pinned staging of the same shape: one host-to-device copy per frame
     int cap_events = 0;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
