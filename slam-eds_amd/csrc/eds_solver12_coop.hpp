@@ -247,16 +247,18 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
         }
         double idr = 0.0;               // 1 / L_rr of this lane's row
         bool okl = true;
+        // right-looking: once column j is scaled, every row subtracts its share from the columns to the right.  Each entry
+        // still receives its subtractions in ascending k — the same sums as the serial left-looking code — but the updates of
+        // one step are independent of each other, so only pivot -> rsqrt -> scale is on the critical path.
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            double s = Lr[j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) s -= Lr[k] * bcast(Lr[k], j);      // L[i][k] * L[j][k]
-            const double d = bcast(s, j);
+            const double d = bcast(Lr[j], j);
             okl = okl && (d > 0.0) && (d < 1e300);
             const double inv = edsm::rsqrt_(d);
             if (row == j) { idr = inv; Lr[j] = d * inv; }
-            else Lr[j] = s * inv;                                            // meaningful for row > j
+            else Lr[j] = Lr[j] * inv;                                        // meaningful for row > j
+#pragma unroll
+            for (int c = j + 1; c < 12; ++c) Lr[c] -= Lr[j] * bcast(Lr[j], c);   // L[i][j] * L[c][j]
         }
         // L y = b  (each row subtracts in ascending k, y_k broadcast from lane k)
 #pragma unroll
