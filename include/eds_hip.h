@@ -193,7 +193,9 @@ int eds_trk_get_trace(eds_trk* h, int slot, int max_iters, double* increments, d
 /* kf->residuals after the solve (Tracker.cpp:223-230), N entries. */
 int eds_trk_get_residuals(eds_trk* h, int slot, double* r);
 /* Tracker::getLossParams (Tracker.cpp:281-317) on the stored residuals; `tau` in/out
- * (CONSTANT leaves it).  Like the reference, MAD partially reorders the stored residuals. */
+ * (CONSTANT leaves it).  Like the reference, MAD partially reorders the stored residuals.  For ONE slot the N residuals
+ * are read back (the caller needs them for kf->residuals anyway) and the O(N) selection runs where the reference runs
+ * it, on the host: 20 us against 80 us for a single-alignment sort on the GPU.  Batches: eds_trk_loss_param_batch. */
 int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau);
 
 /* Batched form: tau[count] for slots [first, first+count).  When the residuals of the last solve are still resident
