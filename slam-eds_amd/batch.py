@@ -31,8 +31,9 @@ def pack_result(p, q, v, cost, iterations, success) -> np.ndarray:
     return out
 
 
-def gather_results(local: np.ndarray, total: int, device=None) -> np.ndarray:
-    """All-gather the per-rank result rows into the global [total, 16] table (every rank gets it).
+def gather_results(local: np.ndarray, total: int, device=None, to_host: bool = True):
+    """All-gather the per-rank result rows into the global [total, 16] table (every rank gets it; with
+    ``to_host=False`` a rank only takes part in the collective and returns None — e.g. every rank but 0 in bench.py).
 
     `local` is this rank's [count, 16] block.  Without an initialised process group this is the
     identity (single process).  Shards may be ragged; rows are padded to the common shard size for
@@ -51,6 +52,8 @@ def gather_results(local: np.ndarray, total: int, device=None) -> np.ndarray:
         buf = buf.to(device)
     out = torch.empty((world * per, RESULT_WIDTH), dtype=torch.float64, device=buf.device)
     dist.all_gather_into_tensor(out, buf)
+    if not to_host:
+        return None
     table = out.cpu().numpy()
     rows = []
     for r in range(world):
