@@ -68,7 +68,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
+    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];
@@ -310,6 +310,9 @@ void eds_fused_free(EdsFusedBuffers* fb) {
 }
 
 int eds_fused_solve(eds_trk* h, int level, int first, int count) {
+    // the persistent kernels are compiled for the tiled frame only; the row-major layout exists for the layout comparison of
+    // the streaming kernels (EDS_FRAME_LAYOUT=rowmajor, tools/bench_layout.py) and is solved by the host-driven loop
+    if (!h->tiled) return eds_internal_solve_host(h, level, first, count);
     if (h->cfg.solver == EDS_SOLVER_REF12) {
         // The persistent REF12 kernels beat the host-driven loop at every batch size (one 2 000-point solve: 0.29 ms vs
         // 0.42 ms; B = 1024: 8.3 M vs 0.37 M LM iterations/s).  The host loop remains for what they do not cover

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
+    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
 
     if (wave == 0) {
         for (int k = lane; k < nb * 36; k += 64) s_G[k] = Gg[k];

@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL_R, TOL_J, TOL_H, TOL_STEP, TOL_POSE = 1e-5, 1e-4, 1e-4, 1e-4, 1e-4
+# the persistent kernels are compiled for the tiled frame; with the experimental row-major layout every solve takes the host loop
+PERSISTENT = os.environ.get("EDS_FRAME_LAYOUT") != "rowmajor"
 
 
 def rel(a, b):
@@ -507,7 +509,7 @@ def test_reference_problem_batched_on_device(gpu, capi, synth, po, B):
         assert table[b, 13] == pytest.approx(ref["final_cost"], rel=1e-4)
         info = hb.info(b)
         assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
-        assert info["device_time_us"] > 0
+        assert (info["device_time_us"] > 0) == PERSISTENT
         r = hb.residuals(b)
         er = po.Oracle(a, num_blocks=2).eval12(table[b, 0:3], table[b, 3:7], table[b, 7:13], jac=False)["r_raw"]
         assert np.abs(r - er).max() <= TOL_R * np.abs(er).max()
@@ -521,7 +523,7 @@ def test_reference_problem_more_than_2048_points_on_device(gpu, capi, synth, po)
     h = make_handle(capi, al, exec=capi.EXEC_DEVICE, solver=capi.SOLVER_REF12, num_blocks=3, loss_type=capi.LOSS_CAUCHY,
                     loss_param=0.3, max_num_iterations=8)
     p, q, v, info = h.optimize(0)
-    assert info["success"] and info["device_time_us"] > 0 and info["num_points"] == 5000
+    assert info["success"] and (info["device_time_us"] > 0) == PERSISTENT and info["num_points"] == 5000
     assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
     assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
     assert info["final_cost"] == pytest.approx(ref["final_cost"], rel=1e-4)
@@ -617,7 +619,7 @@ def test_nc_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
                     max_num_iterations=6)
     p, q, v, info = h.optimize(0, v=al.v_true)
     assert info["success"] and ref["usable"]
-    assert (info["device_time_us"] > 0) == (ex == 1)     # exec=device: the persistent kernel's two-sweep NC evaluation
+    assert (info["device_time_us"] > 0) == (ex == 1 and PERSISTENT)     # exec=device: the persistent kernel's two-sweep NC evaluation
     assert po.se3_distance(p, q, ref["p"], ref["q"]) <= TOL_POSE
     assert np.abs(v - ref["v"]).max() <= 1e-4
     assert info["num_iterations"] == ref["num_iterations"] and info["termination"] == ref["termination"]
