@@ -7,7 +7,7 @@ from hypothesis import given, settings, strategies as st
 
 finite = dict(allow_nan=False, allow_infinity=False)
 small = st.floats(min_value=-1.0, max_value=1.0, **finite)
-S = settings(max_examples=60, deadline=None)
+S = settings(max_examples=60, deadline=None, derandomize=True, database=None)     # deterministic: the same examples on every run
 
 
 @S
