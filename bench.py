@@ -110,11 +110,31 @@ def cpu_baseline(als, iters, sampling, budget_s):
             "one_core_value": one_core}
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (torch.distributed.run) before this
+    process has made any HIP / torch.cuda call — a process that has initialised the GPU must never exec or be re-used as a
+    rank — and exit with the launcher's code.  The children see WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a "
+                         f"number for a configuration that is not the one asked for")
     import torch
     import torch.distributed as dist
     # test hooks (not used by the driver): EDS_BENCH_BACKEND=gloo and EDS_BENCH_DEVICE=<ordinal> let several ranks share
@@ -123,11 +143,17 @@ def main():
     if "EDS_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["EDS_BENCH_DEVICE"])
     if world > 1:
+        if backend == "nccl" and torch.cuda.device_count() < world:      # device_count() does not initialise the GPU
+            raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                             f"(one rank per GPU: RCCL refuses two ranks on one device)")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1:
+        world = dist.get_world_size()               # n_gpus is reported from the collective, not from the environment
+        assert world == a.gpus, (world, a.gpus)
     capi = importlib.import_module("slam-eds_amd.capi")
     synth = importlib.import_module("slam-eds_amd.synth")
     batchmod = importlib.import_module("slam-eds_amd.batch")

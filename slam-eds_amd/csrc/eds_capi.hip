@@ -382,6 +382,13 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EDS_ERR_NO_DEVICE, "no HIP device visible; libeds_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(EDS_ERR_INVALID, "device ordinal out of range");
+    {   // the code object holds gfx950 kernels only (include/eds_hip.h: EDS_ERR_NO_DEVICE = "no gfx950 device visible")
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(EDS_ERR_HIP, "hipGetDeviceProperties failed");
+        if (!std::strstr(prop.gcnArchName, "gfx950"))
+            return fail(EDS_ERR_NO_DEVICE, std::string("device ") + std::to_string(cfg->device) + " is " + prop.gcnArchName +
+                                               ", not gfx950 (MI355X); libeds_hip has no other code path and no CPU fallback");
+    }
     eds_trk* h = new (std::nothrow) eds_trk();
     if (!h) return fail(EDS_ERR_INVALID, "out of memory");
     h->cfg = *cfg;
@@ -536,7 +543,10 @@ int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, con
     if ((rc = upload_points(h, slot, N, norm_xy, grad_xy, idp, w))) return rc;
     if ((rc = refresh_gram(h, slot))) return rc;
     s.has_kf = true;
+    // residuals and trace of an earlier solve belong to the previous keyframe: drop the host copy AND the "still in HBM" marks,
+    // so that get_residuals / loss_param before the next optimize report EDS_ERR_STATE instead of another keyframe's plane
     s.residuals.clear();
+    s.res_on_device = false; s.trace_on_device = false; s.ntrace = 0;
     return EDS_OK;
 }
 

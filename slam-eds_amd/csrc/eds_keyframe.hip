@@ -386,6 +386,7 @@ int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, cons
     if ((rc = eds_internal_refresh_gram(h, slot))) return rc;
     s.has_kf = true;
     s.residuals.clear();
+    s.res_on_device = false; s.trace_on_device = false; s.ntrace = 0;     // as eds_trk_set_keyframe
     kb.last_slot = slot;
     return EDS_OK;
 }

@@ -6,11 +6,33 @@
 #include <array>
 #include <cstdint>
 #include <vector>
-// ---- minimal stand-ins (same names, same data layout as the reference types they replace) ----------------
+// ---- minimal mocks (same names, same template shapes as the real types) ------------------------------------------
+namespace Eigen {
+enum { DontAlign = 0x2 };
+template <class T, int R, int C, int Options = 0>
+struct Matrix {
+    T v[R * C];
+    T& operator[](int i) { return v[i]; }
+    const T& operator[](int i) const { return v[i]; }
+    T& operator()(int i) { return v[i]; }
+    const T& operator()(int i) const { return v[i]; }
+    T* data() { return v; }
+    const T* data() const { return v; }
+    static Matrix Zero() { Matrix m; for (int i = 0; i < R * C; ++i) m.v[i] = T(0); return m; }
+};
+typedef Matrix<double, 2, 1> Vector2d;
+typedef Matrix<double, 3, 1> Vector3d;
+struct Quaterniond {                        // coeffs() order x,y,z,w like Eigen
+    double c[4];
+    static Quaterniond Identity() { return Quaterniond{{0, 0, 0, 1}}; }
+    double x() const { return c[0]; } double y() const { return c[1]; } double z() const { return c[2]; } double w() const { return c[3]; }
+    double* coeffs() { return c; } const double* coeffs() const { return c; }
+};
+}  // namespace Eigen
 namespace base {
 struct Time { int64_t microseconds = 0; };
-typedef std::array<double, 6> Vector6d;
-// Eigen::Transform<double,3,Isometry> stand-in: column-major 4x4 like Eigen's matrix()
+typedef Eigen::Matrix<double, 6, 1, Eigen::DontAlign> Vector6d;    // Rock base/Eigen.hpp: a DIFFERENT type from Eigen::Matrix<double,6,1>
+// Eigen::Transform<double,3,Isometry> mock: column-major 4x4 like Eigen's matrix()
 struct Transform3d {
     double m[16];
     static Transform3d Identity() { Transform3d t; for (int i = 0; i < 16; ++i) t.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return t; }
@@ -24,18 +46,7 @@ struct Transform3d {
     }
 };
 }  // namespace base
-namespace Eigen {
-struct Vector3d { double v[3]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; }
-                  static Vector3d Zero() { return Vector3d{{0, 0, 0}}; } double* data() { return v; } const double* data() const { return v; } };
-struct Quaterniond {                        // coeffs() order x,y,z,w like Eigen
-    double c[4];
-    static Quaterniond Identity() { return Quaterniond{{0, 0, 0, 1}}; }
-    double x() const { return c[0]; } double y() const { return c[1]; } double z() const { return c[2]; } double w() const { return c[3]; }
-    double* coeffs() { return c; } const double* coeffs() const { return c; }
-};
-}  // namespace Eigen
 namespace cv { struct Point2d { double x, y; }; }
-namespace Eigen { struct Vector2d { double v[2]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } }; }
 namespace cv {
 struct Mat {                                 // kf->img.rows / cols, kf->K_ref.at<double>(r, c)
     int rows = 0, cols = 0;

@@ -35,8 +35,41 @@ int main(int argc, char** argv) {
     base::Transform3d T = base::Transform3d::Identity();
     const bool good = tracker.optimize(0, &frame, T, eds::tracking::MAD);
     const base::Transform3d Tef = tracker.getTransform();
-    const base::Vector6d v = tracker.getVelocity();
+    const Eigen::Matrix<double, 6, 1>& v = tracker.getVelocity();
     const eds::tracking::TrackerInfo info = tracker.getInfo();
+    // the same solve again on the unchanged KeyFrame: the shim keeps the device copy (hip.reuse_uploads) — identical result required;
+    // then with the inverse depths touched (only that plane is re-uploaded) and restored
+    double rep_err = 0;
+    {
+        std::vector<double> res_first = kf->residuals;
+        tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
+        base::Transform3d T2 = base::Transform3d::Identity();
+        tracker.config.loss_params = {0.3};
+        const bool good2 = tracker.optimize(0, &frame, T2, eds::tracking::MAD);
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) rep_err = std::max(rep_err, std::fabs(T2(r, c) - T(r, c)));
+        if (!good2 || res_first.size() != kf->residuals.size()) rep_err = 1.0;
+        kf->inv_depth[0] *= 1.5;
+        tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
+        tracker.config.loss_params = {0.3};
+        base::Transform3d T3 = base::Transform3d::Identity();
+        tracker.optimize(0, &frame, T3, eds::tracking::MAD);
+        double moved3 = 0;
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) moved3 = std::max(moved3, std::fabs(T3(r, c) - T(r, c)));
+        if (moved3 == 0.0) rep_err = 2.0;                        // the changed inverse depth must have reached the device
+        kf->inv_depth[0] /= 1.5;
+        tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
+        tracker.config.loss_params = {0.3};
+        base::Transform3d T4 = base::Transform3d::Identity();
+        tracker.optimize(0, &frame, T4, eds::tracking::MAD);
+        for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) rep_err = std::max(rep_err, std::fabs(T4(r, c) - T(r, c)));
+    }
+    // getTransform(bool&) (Tracker.cpp:251-260): identity + false until three poses are in the history, then the mean-filtered pose
+    bool f1 = true, f2 = true, f3 = false;
+    const base::Transform3d F1 = tracker.getTransform(f1), F2 = tracker.getTransform(f2), F3 = tracker.getTransform(f3);
+    double filt_err = 0;                     // three identical poses: the filtered pose of a fresh accumulator is that pose
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) filt_err = std::max(filt_err, std::fabs(F3(r, c) - Tef(r, c)));
+    const int filt_flags = (f1 ? 1 : 0) | (f2 ? 2 : 0) | (f3 ? 4 : 0) | ((F1(0, 3) == 0.0 && F2(0, 3) == 0.0 && F1(0, 0) == 1.0) ? 8 : 0);
+    tracker.getVelocity()[0] += 0.0;         // by reference (Tracker.hpp:87)
     double id_err = 0;                       // T_kf_ef * T_ef_kf must be the identity (Tracker.cpp:220)
     for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { double s = 0; for (int k = 0; k < 4; ++k) s += T(r, k) * Tef(k, c); id_err = std::max(id_err, std::fabs(s - (r == c))); }
     // post-solve point maintenance through the shim (Tracker::getCoord(true) + needNewKeyframe), from a pose that pushes part
@@ -51,9 +84,9 @@ int main(int argc, char** argv) {
     double c0 = moved.empty() ? 0 : moved[0].x, c1 = moved.empty() ? 0 : moved.back().y;
     std::printf("{\"ok\": %d, \"t\": [%.17g, %.17g, %.17g], \"R\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], "
                 "\"v\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"num_points\": %u, \"tau\": %.17g, \"residuals\": %zu, \"inverse_err\": %.3g, "
-                "\"kept\": %zu, \"consistent\": %d, \"first_x\": %.17g, \"last_y\": %.17g, \"sq_flow\": %.17g, \"need_kf\": %d, \"first_idp\": %.17g}\n",
+                "\"kept\": %zu, \"consistent\": %d, \"first_x\": %.17g, \"last_y\": %.17g, \"sq_flow\": %.17g, \"need_kf\": %d, \"first_idp\": %.17g, \"rep_err\": %.3g, \"filt_err\": %.3g, \"filt_flags\": %d}\n",
                 good ? 1 : 0, Tef(0, 3), Tef(1, 3), Tef(2, 3), Tef(0, 0), Tef(0, 1), Tef(0, 2), Tef(1, 0), Tef(1, 1), Tef(1, 2), Tef(2, 0), Tef(2, 1), Tef(2, 2),
                 v[0], v[1], v[2], v[3], v[4], v[5], info.num_iterations, info.num_points, tracker.config.loss_params[0], res_before.size(), id_err,
-                n_after, consistent ? 1 : 0, c0, c1, tracker.squared_norm_flow, tracker.needNewKeyframe(0.03) ? 1 : 0, kf->inv_depth.empty() ? 0.0 : kf->inv_depth[0]);
+                n_after, consistent ? 1 : 0, c0, c1, tracker.hipSquaredNormFlow(), tracker.needNewKeyframe(0.03) ? 1 : 0, kf->inv_depth.empty() ? 0.0 : kf->inv_depth[0], rep_err, filt_err, filt_flags);
     return good ? 0 : 1;
 }

@@ -1,0 +1,143 @@
+"""GPU parity of the BATCHED workloads exactly as bench.py and BASELINE.json configs[4] run them.
+
+* configs[4]: 64 independent alignments (seeds 5000 + b, 640x480, 2 000 points), sharded 8 per rank over 8 ranks
+  (slam-eds_amd/batch.py), results gathered into the 64 x 16 table — here the 8 shards run one after the other on the
+  one GPU of the test box (RCCL needs one device per rank; the collective itself is covered by tests/test_distributed.py),
+  every row checked against the CPU oracle.
+* the kernel behind bench.py's headline number, selected by `optimize`'s OWN rule (no EDS_LM6_KERNEL override): a launch of
+  >= 1 536 alignments at 640x480 / 2 000 points, >= 32 distinct alignments against the oracle.
+
+Tolerances as in tests/test_parity_gpu.py (fp32 kernels vs the fp64 oracle): solved pose within 1e-4 (SE(3) distance), LM6
+accept pattern identical, REF12 iteration counts / termination identical, velocity within 1e-4.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL_POSE = 1e-4
+
+
+@pytest.fixture(scope="module")
+def batchmod():
+    return importlib.import_module("slam-eds_amd.batch")
+
+
+@pytest.fixture(scope="module")
+def als64(synth):
+    return [synth.make_alignment(5000 + b) for b in range(64)]            # seeds 5000 + b, 640x480, N = 2000
+
+
+def test_config4_64_alignments_8_shards_lm6(gpu, capi, synth, po, batchmod, als64):
+    assert not os.environ.get("EDS_LM6_KERNEL")
+    total, world = 64, 8
+    cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10)
+    blocks, traces = [], []
+    for rank in range(world):
+        bt = batchmod.BatchTracker(cfg, total, 2000, 480, 640, rank=rank, world_size=world)
+        assert (bt.first, bt.count) == (8 * rank, 8)
+        mine = als64[bt.first: bt.first + bt.count]
+        bt.load(mine)
+        bt.reset_states(mine)
+        bt.solve()
+        blocks.append(bt.local_results())
+        traces += [bt.handle.trace(i)["accepted"].copy() for i in range(bt.count)]
+        bt.close()
+    table = np.concatenate(blocks, axis=0)                                  # what the all-gather assembles (rank order)
+    assert table.shape == (64, 16)
+    worst = 0.0
+    for b in range(total):
+        al = als64[b]
+        ref = po.Oracle(al).pose6_lm(al.p0, al.q0, al.v0, iters=10, lambda0=cfg.lambda0)
+        d = po.se3_distance(table[b, 0:3], table[b, 3:7], ref["p"], ref["q"])
+        worst = max(worst, d)
+        assert d <= TOL_POSE, (b, d)
+        assert np.array_equal(traces[b], ref["accepted"]), b
+        assert table[b, 14] == ref["iterations"] and table[b, 15] == 1.0
+        assert np.allclose(table[b, 7:13], al.v0)                          # pose-only solver: velocity untouched
+    print(f"configs[4] LM6: worst SE(3) distance to the oracle {worst:.2e}")
+
+
+def test_config4_ref12_subset(gpu, capi, synth, po, batchmod, als64):
+    """The reference's own 12-parameter problem on a subset of configs[4] (8 alignments of the batch, both residual-block layouts)."""
+    sub = [0, 9, 18, 27, 36, 45, 54, 63]
+    for nb, loss in ((1, 0), (4, 1)):
+        cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=nb,
+                                  loss_type=loss, loss_param=0.3)
+        bt = batchmod.BatchTracker(cfg, len(sub), 2000, 480, 640)
+        mine = [als64[b] for b in sub]
+        bt.load(mine); bt.reset_states(mine); bt.solve()
+        table = bt.gather()
+        for i, b in enumerate(sub):
+            al = als64[b]
+            ref = po.Oracle(al, num_blocks=nb, loss_type=loss, loss_param=0.3, max_num_iterations=10).solve_lm(al.p0, al.q0, al.v0)
+            assert po.se3_distance(table[i, 0:3], table[i, 3:7], ref["p"], ref["q"]) <= TOL_POSE, (nb, b)
+            assert np.abs(table[i, 7:13] - ref["v"]).max() <= 1e-4
+            info = bt.handle.info(i)
+            assert info["num_iterations"] == ref["num_iterations"] and info["num_successful_steps"] == ref["num_successful_steps"]
+            assert info["termination"] == ref["termination"]
+            assert table[i, 13] == pytest.approx(ref["final_cost"], rel=1e-5)
+        bt.close()
+
+
+def test_bench_shape_kernel_selected_by_optimize(gpu, capi, synth, po, als64):
+    """1 536 alignments at the bench shape in ONE launch — the size from which optimize() switches to its large-batch kernel —
+    with no environment override; 32 distinct alignments, every distinct one checked against the oracle in two different slots."""
+    for k in ("EDS_LM6_KERNEL", "EDS_FUSED_THREADS", "EDS_FUSED_PPT"):
+        assert not os.environ.get(k), f"{k} must be unset: this test exercises optimize()'s own kernel choice"
+    B, D = 1536, 32
+    cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10)
+    h = capi.Handle(cfg, B, 2000, 480, 640)
+    fr = [np.ascontiguousarray(a.frame, dtype=np.float32) for a in als64[:D]]
+    for b in range(B):
+        a = als64[b % D]
+        h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+        h.set_event_frame(b, fr[b % D])
+    h.set_states(0, np.stack([als64[b % D].p0 for b in range(B)]), np.stack([als64[b % D].q0 for b in range(B)]),
+                 np.stack([als64[b % D].v0 for b in range(B)]))
+    h.optimize_batch(0, 0, B)
+    table = h.results(0, B)
+    assert np.all(table[:, 15] == 1.0)
+    worst = 0.0
+    for d in range(D):
+        a = als64[d]
+        # the frame was handed over as fp32 (bench.py does the same): the oracle sees the same fp32-rounded frame
+        a32 = synth.Alignment(**{**a.__dict__, "frame": fr[d].astype(np.float64)})
+        ref = po.Oracle(a32).pose6_lm(a.p0, a.q0, a.v0, iters=10, lambda0=cfg.lambda0)
+        for slot in (d, d + B - D):                                        # first and last replica of this alignment
+            dist = po.se3_distance(table[slot, 0:3], table[slot, 3:7], ref["p"], ref["q"])
+            worst = max(worst, dist)
+            assert dist <= TOL_POSE, (slot, dist)
+            assert np.array_equal(h.trace(slot)["accepted"], ref["accepted"]), slot
+            assert table[slot, 14] == ref["iterations"]
+        r = h.residuals(d)
+        e = po.Oracle(a32).pose6_eval(ref["p"], ref["q"], a.v0)
+        assert np.abs(r - e["r"]).max() <= 2e-5 * np.abs(e["r"]).max()      # residuals at the solution (Tracker.cpp:223-230)
+    # replicas of one alignment must agree bit for bit (same inputs, same kernel, no cross-slot state)
+    for slot in range(D, B):
+        assert np.array_equal(table[slot, 0:7], table[slot % D, 0:7]), slot
+    print(f"bench shape, {B} alignments in one launch: worst SE(3) distance to the oracle {worst:.2e}")
+    h.close()
+
+
+def test_new_keyframe_invalidates_device_residuals(gpu, capi, synth):
+    """after a device-mode solve, set_keyframe must not leave 'residuals still in HBM' set — get_residuals /
+    loss_param before the next optimize then report EDS_ERR_STATE instead of the previous keyframe's plane."""
+    a = synth.make_alignment(11, H=120, W=160, N=300)
+    b = synth.make_alignment(12, H=120, W=160, N=300)
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=5), 1, 300, 120, 160)
+    h.set_alignment(0, a)
+    h.optimize(0)
+    assert h.residuals(0).shape == (300,)
+    h.optimize(0)                                   # residuals of this solve stay on the device
+    h.set_keyframe(0, b.norm_coord, b.grad, b.idp, b.weights, b.fx, b.fy, b.cx, b.cy)
+    with pytest.raises(capi.EdsError) as ei:
+        h.residuals(0)
+    assert ei.value.code == capi.ERR_STATE
+    with pytest.raises(capi.EdsError):
+        h.loss_param(0, capi.LP_MAD)
+    with pytest.raises(capi.EdsError):
+        h.loss_param_batch(capi.LP_MAD, 0, 1)
+    h.close()

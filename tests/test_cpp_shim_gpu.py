@@ -62,6 +62,28 @@ def test_shim_optimize_matches_oracle(gpu, capi, synth, po, tmp_path, nb, loss):
     assert r["sq_flow"] == pytest.approx(refp["mean_sq_flow"], rel=1e-4)
     assert bool(r["need_kf"]) == pto.need_new_keyframe(refp["mean_sq_flow"], al.H, al.W, 0.03)
     assert r["first_idp"] == al.idp[refp["kept"][0]]
+    # second / fourth solve on the unchanged KeyFrame (device copy reused, then inverse depth changed and restored) reproduce the first
+    assert r["rep_err"] <= 1e-9
+    # getTransform(bool&): false + identity for the first two calls, true + the (mean-filtered) pose on the third (Tracker.cpp:251-260)
+    assert r["filt_flags"] == 4 | 8 and r["filt_err"] <= 1e-12
+
+
+def test_shim_signature_drift_breaks_the_build(tmp_path):
+    """The pointer-to-member pins of tests/cpp/shim_eds_types_check.cpp really bite: a copy of the shim whose getVelocity()
+    returns by value (the round-1 drift) must fail to compile."""
+    shim = open(os.path.join(ROOT, "slam-eds_amd", "csrc", "Tracker.hpp")).read()
+    good = "Eigen::Matrix<double, 6, 1>& getVelocity() { return vx; }"
+    assert good in shim
+    d = tmp_path / "slam-eds_amd" / "csrc"
+    d.mkdir(parents=True)
+    (d / "Tracker.hpp").write_text(shim.replace(good, "Eigen::Matrix<double, 6, 1> getVelocity() { return vx; }")
+                                   .replace('#include "../../include/eds_hip.h"', f'#include "{os.path.join(ROOT, "include", "eds_hip.h")}"'))
+    t = tmp_path / "tests" / "cpp"
+    t.mkdir(parents=True)
+    (t / "check.cpp").write_text(open(os.path.join(HERE, "cpp", "shim_eds_types_check.cpp")).read())
+    res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(HERE, "cpp", "mock_eds"), str(t / "check.cpp")],
+                         capture_output=True, text=True)
+    assert res.returncode != 0 and "getVelocity" in res.stderr
 
 
 def test_shim_eds_types_branch_compiles_against_mock_headers():
