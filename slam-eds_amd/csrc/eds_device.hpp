@@ -86,6 +86,80 @@ __device__ __forceinline__ void load_patch16(const FrameView& f, int r0, int c0,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Quad-cooperative patch gather (round 2).  A 4x4 patch read by ONE lane is 8 scattered 16-byte loads whose 64 lanes touch 64
+// different tiles per wave-instruction; the vector memory pipeline retires such an instruction at ~2.2 clocks per lane, and that
+// address rate — not bytes — bounds the pass together with the fabric's miss rate (tools/ubench_gather_quad.hip: 1.4-1.5x).
+// Here the four lanes of a quad share their four points: for each point q of the quad, lane j loads ROW j of q's patch (the
+// same two aligned 16-byte pieces per row as load_patch16).  The four lanes of one instruction then touch the rows of ONE patch
+// — one or two tiles instead of four unrelated ones — so the instruction covers ~1.75 lines per quad instead of 4.  The row's
+// cubic Hermite runs on the lane that loaded it, and a 4x4 DPP transpose hands every lane the four row results of ITS OWN
+// point: per-lane arithmetic is what it was (four row splines, then the column splines), plus ~40 cross-lane moves.
+// ---------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true)); }
+// value of lane Q (0..3) of this lane's quad
+template <int Q>
+__device__ __forceinline__ int quad_bcast_i(int v) { return dpp_i<Q * 0x55>(v); }
+template <int Q>
+__device__ __forceinline__ float quad_bcast_f(float v) { return dpp_f<Q * 0x55>(v); }
+// In-quad 4x4 transpose: on entry m[q] is what THIS lane (row `lane & 3`) computed for the quad's point q; on return m[k] is
+// what lane k computed for this lane's own point.  Two exchange rounds (partner lane ^ 1, then lane ^ 2), 12 instructions.
+__device__ __forceinline__ void quad_transpose(float (&m)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int a = 0; a < 4; a += 2) {
+        const float send = b0 ? m[a] : m[a + 1];
+        const float recv = dpp_f<0xB1>(send);                // quad_perm [1,0,3,2]
+        if (b0) m[a] = recv; else m[a + 1] = recv;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float send = b1 ? m[c] : m[c + 2];
+        const float recv = dpp_f<0x4E>(send);                // quad_perm [2,3,0,1]
+        if (b1) m[c] = recv; else m[c + 2] = recv;
+    }
+}
+// Origin of a patch packed for the in-quad broadcast: clamped like load_patch16 (rows -2..H, columns -2..W), biased by 2.
+__device__ __forceinline__ int pack_origin(const FrameView& f, int r0, int c0) {
+    return ((clampi(r0, -2, f.H) + 2) << 16) | (clampi(c0, -2, f.W) + 2);
+}
+// Row `jr` (0..3) of the patch at a packed origin: the two aligned 16-byte tile pieces that hold columns c0-1 .. c0+2.
+// `tiles` is the START of the frame's allocation (tile (0,0) of the margin), offsets are unsigned 32-bit element counts.
+__device__ __forceinline__ void load_patch_row(const float* __restrict__ tiles, int TW, int origin, int jr, float4& a, float4& b) {
+    const unsigned r = (unsigned)((origin >> 16) & 0x7fff) + (unsigned)(jr + EDS_FRAME_MARGIN - 3);   // allocation row, >= 1
+    const unsigned cc = (unsigned)(origin & 0xffff) + (unsigned)(EDS_FRAME_MARGIN - 2);              // allocation column of c0
+    // byte offsets from the start of the allocation, 32-bit: uniform base + per-lane offset (global_load ... saddr form)
+    const unsigned row_b = (r >> 2) * ((unsigned)TW * 64u) + ((r & 3u) << 4);
+    const char* base = reinterpret_cast<const char*>(tiles);
+    a = *reinterpret_cast<const float4*>(base + (row_b + (((cc - 1u) >> 2) << 6)));
+    b = *reinterpret_cast<const float4*>(base + (row_b + (((cc + 2u) >> 2) << 6)));
+}
+// a register whose content does not matter (no instruction emitted): the unselected arm of a bit_select
+__device__ __forceinline__ float4 dont_care4() {
+    float x = 0.f;
+    x = __builtin_nondeterministic_value(x);             // freeze(undef): any value, but a defined one — no instruction
+    return make_float4(x, x, x, x);
+}
+// the 4 taps starting at column c0-1 out of the two pieces (same two-stage barrel shift as load_patch16)
+// (bit-mask selects, one v_bfi_b32 each: written as ?: on the vector components the compiler turns the shift into a
+// dynamically indexed private array, i.e. scratch memory traffic inside the point loop)
+__device__ __forceinline__ float bit_select(int mask, float yes, float no) {
+    return __int_as_float((mask & __float_as_int(yes)) | (~mask & __float_as_int(no)));
+}
+__device__ __forceinline__ void shift_patch_row(const float4& a, const float4& b, int origin, float (&t)[4]) {
+    const int s = (origin & 0xffff) - 3;                       // (c0 - 1); only its two low bits matter
+    const int m2 = -((s >> 1) & 1), m1 = -(s & 1);
+    const float t0 = bit_select(m2, a.z, a.x), t1 = bit_select(m2, a.w, a.y), t2 = bit_select(m2, b.x, a.z), t3 = bit_select(m2, b.y, a.w),
+                t4 = bit_select(m2, b.z, b.x);
+    t[0] = bit_select(m1, t1, t0); t[1] = bit_select(m1, t2, t1); t[2] = bit_select(m1, t3, t2); t[3] = bit_select(m1, t4, t3);
+}
+// LDS patch cache of the quad path: [point][row][4 taps], one 16-byte unit per (point, row), units XOR-swizzled by the
+// quad index so that the 16 lanes one ds_read_b128 / ds_write_b128 services together hit 16 different bank groups.
+__device__ __forceinline__ int patch_unit(int point, int row) { return ((point << 2) + row) ^ (((point >> 2) & 3) << 2); }
+
 // Bicubic value and derivatives from a register-resident 4x4 patch (ay: row phase, ax: col phase).
 __device__ __forceinline__ void bicubic_patch(const float (&p)[16], float ay, float ax, float& E, float& Erow, float& Ecol) {
     float f[4], d[4];
@@ -305,12 +379,19 @@ __device__ __forceinline__ void accumulate_normal(float* acc, const float (&J)[N
 // One point of a pose-only pass, shared by the persistent kernels (eds_fused.hip, eds_stream6.hip): sample from the
 // register-resident taps, residual r = w (mhat - E), 1x6 SE(3) row, optional per-point Huber weight (extension, cf.
 // reference CoarseTracker.cpp:445), and the contribution to the 28 running sums.  Returns r.
+// ... from the sampled value and derivatives (shared by the lane-per-point and the quad-cooperative gathers)
+__device__ __forceinline__ float point_row6_sampled(const PoseF& ps, const PointGeom& pg, float E, float Er, float Ec, float w, float mhat,
+                                                    float tau, float* acc);
 template <int SAMPLING, int NTAP>
 __device__ __forceinline__ float point_row6(const PoseF& ps, const PointGeom& pg, float (&tap)[NTAP], float w, float mhat, float tau,
                                             float* acc) {
     float E, Er, Ec;
     if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap), pg.ay, pg.ax, E, Er, Ec);
     else bilinear_patch(reinterpret_cast<float(&)[4]>(tap), pg.ay, pg.ax, E, Er, Ec);
+    return point_row6_sampled(ps, pg, E, Er, Ec, w, mhat, tau, acc);
+}
+__device__ __forceinline__ float point_row6_sampled(const PoseF& ps, const PointGeom& pg, float E, float Er, float Ec, float w, float mhat,
+                                                    float tau, float* acc) {
     PointProj pp;
     finish_point(ps, pg, E, Er, Ec, pp);
     const float r = w * (mhat - pp.E);

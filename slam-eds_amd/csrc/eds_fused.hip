@@ -44,7 +44,10 @@ using namespace edsd;
 //
 // PPT > 0: each lane owns points tid, tid + nthr, ... (PPT of them, N <= PPT * nthr) and keeps their
 // constants in registers; PPT == 0: any N, constants re-read from HBM/L2 every pass.
-template <int SAMPLING, int PPT, int MAXT>
+// QUAD (bicubic, PPT > 0): the quad-cooperative gather of eds_device.hpp — lane j of a quad loads row j of each of the quad's
+// four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane; the cache then
+// holds [point][row] units of 16 bytes.  QUAD = 0 is the lane-per-point gather of round 1 (kept for bilinear and for A/B runs).
+template <int SAMPLING, int PPT, int MAXT, int QUAD>
 __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     constexpr int NREG = PPT > 0 ? PPT : 1;
     constexpr bool CACHE = true;
-    __shared__ float s_patch[CACHE ? NTAP : 1][CACHE ? EDS_CACHE_CAP : 1];
+    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NTAP : 1][CACHE ? EDS_CACHE_CAP : 1];
     __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
@@ -69,6 +72,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
     const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
+    const float* __restrict__ tiles = A.frame + (size_t)slot * A.Hp * A.Wp;              // start of this slot's allocation (quad gather)
+    static_assert(!QUAD || (SAMPLING == 0 && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: bicubic, register-resident points, all cached");
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];
@@ -129,6 +134,19 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #else
 #define EDS_STAMP(k) do { } while (0)
 #endif
+    // second diagnostic set (-DEDS_FUSED_STAMPS=2): the reduction split into [wave butterfly + LDS write | barrier wait | cross-wave sum]
+#if defined(EDS_FUSED_STAMPS) && EDS_FUSED_STAMPS == 2
+    unsigned long long stamp2_acc[3] = {0, 0, 0}, stamp2_t = 0;
+#define EDS_STAMP2(k)                                                            \
+    do {                                                                         \
+        const unsigned long long now_ = __builtin_readcyclecounter();            \
+        if ((k) > 1) stamp2_acc[(k)-1] += now_ - stamp2_t;                       \
+        if ((k) == 1) stamp2_acc[0] += now_ - stamp_t;                           \
+        stamp2_t = now_;                                                         \
+    } while (0)
+#else
+#define EDS_STAMP2(k) do { } while (0)
+#endif
     float rcand[NREG], racc[NREG];      // residuals of the pass in flight / of the accepted pose (PPT > 0)
 #pragma unroll
     for (int j = 0; j < NREG; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
@@ -146,7 +164,65 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             if (PPT == 0 && state == 1 && i < N) A.r[base + i] = r;      // streaming variant: residuals stored by a final pass
             return r;
         };
-        if (PPT > 0) {
+        if (QUAD) {
+            // phase A: every lane projects its own points and probes the cache; the packed origins go round the quad and every
+            // lane puts its ROW of each missing patch in flight
+            const int jr = lane & 3;
+            // this lane's four cache units per point slot: unit = 4 * point + row, XOR-swizzled by the quad index (patch_unit); the
+            // quad index of slot j is (tid >> 2) + j * nthr / 4 and nthr / 4 is a multiple of 4, so the swizzle is per lane, and the
+            // slot enters as a compile-time offset
+            float* __restrict__ cache = &s_patch[0][0] + 16 * (tid & ~3) + 4 * jr;
+            const int swz = (tid >> 2) & 3;
+            const int cq0 = 16 * (0 ^ swz), cq1 = 16 * (1 ^ swz), cq2 = 16 * (2 ^ swz), cq3 = 16 * (3 ^ swz);
+            const int cq[4] = {cq0, cq1, cq2, cq3};
+            PointGeom pg[NREG];
+            int org[NREG];
+            float4 ra[NREG][4], rb[NREG][4];
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int i = tid + j * nthr;
+                project_point(ps, kf[j], pg[j]);
+                const int key = (pg[j].r0 << 16) ^ (pg[j].c0 & 0xffff);
+                const bool miss = s_cell[i] != key;
+                if (miss) s_cell[i] = key;
+                org[j] = pack_origin(frame, pg[j].r0, pg[j].c0) | (miss ? (int)0x80000000 : 0);
+                const int o0 = quad_bcast_i<0>(org[j]), o1 = quad_bcast_i<1>(org[j]), o2 = quad_bcast_i<2>(org[j]), o3 = quad_bcast_i<3>(org[j]);
+                const int oq[4] = {o0, o1, o2, o3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ra[j][q] = dont_care4(); rb[j][q] = dont_care4();
+                    if (oq[q] < 0) load_patch_row(tiles, frame.TW, oq[q] & 0x7fffffff, jr, ra[j][q], rb[j][q]);
+                }
+            }
+            // phase B (branch-free): the cached row and the gathered row are both formed, a bit mask picks one; the row goes (back)
+            // to the cache, its spline runs here, the transposes return the four row results to the lane that owns the point
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int o0 = quad_bcast_i<0>(org[j]), o1 = quad_bcast_i<1>(org[j]), o2 = quad_bcast_i<2>(org[j]), o3 = quad_bcast_i<3>(org[j]);
+                const int oq[4] = {o0, o1, o2, o3};
+                const float x0 = quad_bcast_f<0>(pg[j].ax), x1 = quad_bcast_f<1>(pg[j].ax), x2 = quad_bcast_f<2>(pg[j].ax), x3 = quad_bcast_f<3>(pg[j].ax);
+                const float xq[4] = {x0, x1, x2, x3};
+                float4 c[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) c[q] = *reinterpret_cast<const float4*>(cache + cq[q] + 16 * j * nthr);
+                float f[4], d[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t[4];
+                    shift_patch_row(ra[j][q], rb[j][q], oq[q], t);
+                    const int m = oq[q] >> 31;                   // all ones: gathered this pass
+                    t[0] = bit_select(m, t[0], c[q].x); t[1] = bit_select(m, t[1], c[q].y); t[2] = bit_select(m, t[2], c[q].z); t[3] = bit_select(m, t[3], c[q].w);
+                    *reinterpret_cast<float4*>(cache + cq[q] + 16 * j * nthr) = make_float4(t[0], t[1], t[2], t[3]);
+                    hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
+                }
+                quad_transpose(f, lane);
+                quad_transpose(d, lane);
+                float E, Er, Ec, unused;
+                hermite(f[0], f[1], f[2], f[3], pg[j].ay, E, Er);
+                hermite(d[0], d[1], d[2], d[3], pg[j].ay, Ec, unused);
+                rcand[j] = point_row6_sampled(ps, pg[j], E, Er, Ec, kw[j], kmh[j], tau, acc);
+            }
+        } else if (PPT > 0) {
             // phase A: project every point of this lane, probe the patch cache, and put ALL the
             // missing gathers in flight before anything waits on one (memory-level parallelism:
             // a miss costs a ~2 us HBM round trip, paid once per pass instead of once per point)
@@ -207,7 +283,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP(1);
         wave_reduce_scatter<EDS_RED_K6>(acc, lane);
         if (lane < 32) s_red[wave][wave_red_index<EDS_RED_K6>(lane, 0)] = acc[0];
+        EDS_STAMP2(1);
         __syncthreads();
+        EDS_STAMP2(2);
         if (tid < EDS_RED_N6) {          // cross-wavefront sum in fp64, unpacked straight into the solver's input
             float part[EDS_FUSED_MAX_WAVES];
 #pragma unroll
@@ -233,6 +311,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         EDS_STAMP(2);
+        EDS_STAMP2(3);
         if (tid == 0) {
             sv.on_eval(s_sums);
             s_accept = sv.last_accepted;
@@ -261,6 +340,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #ifdef EDS_FUSED_STAMPS
     // diagnostic build only: cycles of lane 0 in [point loop | reduction | solver] into the pad words
     if (tid == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
+#if EDS_FUSED_STAMPS == 2
+    if (tid == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
+#endif
 #endif
 
     if (tid == 0) {
@@ -373,16 +455,19 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     } else {
     // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
     // lane variant needs to keep 4 x 16 taps + constants in registers without spilling
-#define EDS_LAUNCH_FUSED(S, P, T)                                                                                              \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+#define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb)
-#define EDS_LAUNCH_FUSED_T(S, P) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024); else EDS_LAUNCH_FUSED(S, P, 512); } while (0)
+#define EDS_LAUNCH_FUSED_T(S, P, Q) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024, Q); else EDS_LAUNCH_FUSED(S, P, 512, Q); } while (0)
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
+    bool quad = true;                                                // the quad-cooperative gather (bicubic, register-resident points)
+    if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
+    quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP;       // every point's patch has a cache line of its own
     switch (ppt) {
-        case 1: if (bicubic) EDS_LAUNCH_FUSED_T(0, 1); else EDS_LAUNCH_FUSED_T(1, 1); break;
-        case 2: if (bicubic) EDS_LAUNCH_FUSED_T(0, 2); else EDS_LAUNCH_FUSED_T(1, 2); break;
-        case 4: if (bicubic) EDS_LAUNCH_FUSED_T(0, 4); else EDS_LAUNCH_FUSED_T(1, 4); break;
-        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0); else EDS_LAUNCH_FUSED_T(1, 0); break;
+        case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_FUSED_T(1, 1, 0); break;
+        case 2: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_FUSED_T(1, 2, 0); break;
+        case 4: if (bicubic) { if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_FUSED_T(1, 4, 0); break;
+        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0, 0); else EDS_LAUNCH_FUSED_T(1, 0, 0); break;
     }
     }
 #undef EDS_LAUNCH_FUSED_T

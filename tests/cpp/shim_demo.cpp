@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
         const bool good2 = tracker.optimize(0, &frame, T2, eds::tracking::MAD);
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) rep_err = std::max(rep_err, std::fabs(T2(r, c) - T(r, c)));
         if (!good2 || res_first.size() != kf->residuals.size()) rep_err = 1.0;
+        const double idp0_saved = kf->inv_depth[0];
         kf->inv_depth[0] *= 1.5;
         tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
         tracker.config.loss_params = {0.3};
@@ -56,7 +57,7 @@ int main(int argc, char** argv) {
         double moved3 = 0;
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) moved3 = std::max(moved3, std::fabs(T3(r, c) - T(r, c)));
         if (moved3 == 0.0) rep_err = 2.0;                        // the changed inverse depth must have reached the device
-        kf->inv_depth[0] /= 1.5;
+        kf->inv_depth[0] = idp0_saved;
         tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
         tracker.config.loss_params = {0.3};
         base::Transform3d T4 = base::Transform3d::Identity();
