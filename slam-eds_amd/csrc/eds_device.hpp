@@ -218,6 +218,16 @@ __device__ __forceinline__ void load_pose(const double* pb, PoseF& ps) {
     ps.fy = uniformf((float)pb[EDS_PB_K + 1]);
 }
 
+// the same with the pass-dependent part (R - I, t) and the constant part (intrinsics) in different places
+__device__ __forceinline__ void load_pose_rt(const double* D, const double* t, const double* pb, PoseF& ps) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ps.D[i] = uniformf((float)D[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ps.t[i] = uniformf((float)t[i]);
+    ps.fx = uniformf((float)pb[EDS_PB_K]);
+    ps.fy = uniformf((float)pb[EDS_PB_K + 1]);
+}
+
 struct PointKf {                   // per-point keyframe constants (SoA in HBM, registers in the persistent kernel)
     float x, y, rhop;              // normalised coords, idp + 1e-5
     float f0x, f0y;                // fractional part of the keyframe pixel (u0, v0)

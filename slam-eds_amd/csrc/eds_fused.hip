@@ -28,6 +28,7 @@
 #include "eds_handle.hpp"
 #include "eds_math.hpp"
 #include "eds_solver.hpp"
+#include "eds_solver6_spec.hpp"
 
 using namespace edsd;
 
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
     __shared__ int s_accept;           // the pass just consumed became the accepted pose
+    __shared__ edsp::SpecState sp;     // damped solver with register-resident points: prepared candidates (eds_solver6_spec.hpp)
+    const bool spec_mode = (PPT > 0) && damped == 1 && iters > 0;   // (iters == 0: one residual pass, no solve) damped == 2: the serial solver lane of round 1 (A/B runs: EDS_LM6_SPEC=0)
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     constexpr int NREG = PPT > 0 ? PPT : 1;
     constexpr bool CACHE = true;
@@ -79,8 +82,18 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         const EdsFusedIn& I = in[slot];
         for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
         edsm::fill_pose_block(I.p, I.q, I.v, A.G + (size_t)slot * EDS_MAX_BLOCKS * 36, nb, s_pose);
-        sv.init(damped, iters, lambda0, I.p, I.q, PPT > 0 ? 1 : 0);   // PPT > 0: residuals of the accepted pose stay in registers
+        sv.init(damped != 0, iters, lambda0, I.p, I.q, PPT > 0 ? 1 : 0);   // PPT > 0: residuals of the accepted pose stay in registers
         s_state = sv.final_pass ? 1 : 0;
+        if (spec_mode) {                // candidate 0 of the first pass = the start pose
+            edsp::Spec6& c0 = sp.spec[0];
+            for (int i = 0; i < 3; ++i) { c0.p[i] = I.p[i]; c0.rt.t[i] = s_pose[EDS_PB_T + i]; }
+            for (int i = 0; i < 4; ++i) c0.q[i] = I.q[i];
+            for (int i = 0; i < 6; ++i) c0.xi[i] = 0.0;
+            for (int i = 0; i < 9; ++i) c0.rt.D[i] = s_pose[EDS_PB_D + i];
+            c0.ok = 1;
+            sp.k = 0; sp.mode = edsp::MODE_USE;
+            for (int i = 0; i < EDS_RED_N6; ++i) sp.cur[i] = 0.0;
+        }
     }
     for (int k = tid; k < EDS_FUSED_MAX_WAVES * EDS_RED_K6; k += nthr) (&s_red[0][0])[k] = 0.0f;   // rows of absent wavefronts stay 0
     __syncthreads();
@@ -154,7 +167,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP(0);
         const int state = s_state;
         PoseF ps;
-        load_pose(s_pose, ps);
+        if (spec_mode) load_pose_rt(sp.spec[sp.k].rt.D, sp.spec[sp.k].rt.t, s_pose, ps);
+        else load_pose(s_pose, ps);
         float acc[EDS_RED_K6];
 #pragma unroll
         for (int j = 0; j < EDS_RED_K6; ++j) acc[j] = 0.0f;
@@ -286,6 +300,89 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP2(1);
         __syncthreads();
         EDS_STAMP2(2);
+        if (spec_mode) {
+            // ---- damped solver with prepared candidates (eds_solver6_spec.hpp); decisions as edss::Solver6::on_eval takes them ----
+            if (wave == 0) {
+                double s = 0.0;
+                if (lane < EDS_RED_N6) {
+                    float part[EDS_FUSED_MAX_WAVES];
+#pragma unroll
+                    for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) part[wv] = s_red[wv][lane];
+#pragma unroll
+                    for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)part[wv];
+                }
+                EDS_STAMP(2);
+                EDS_STAMP2(3);
+                const int k = sp.k, max_iters = sv.max_iters;
+                int have_cur = sv.have_cur, iter = sv.iter, ntrace = sv.ntrace;
+                double lambda = sv.lambda;
+                const double cur_cost = sp.cur[EDS_RED_N6 - 1];
+                const long long sb = __double_as_longlong(s);
+                const double cost = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(sb >> 32), EDS_RED_N6 - 1) << 32) |
+                                                         (unsigned int)__builtin_amdgcn_readlane((int)(sb & 0xffffffffll), EDS_RED_N6 - 1));
+                const bool bad = lane < EDS_RED_N6 && !(fabs(s) < 1e300);
+                const bool fin = __ballot(bad) == 0ull;
+                int mode = edsp::MODE_SOLVE, accepted = 1, nk = 0;
+                bool store = false;
+                if (!have_cur) {                    // first pass: linearise at the start pose
+                    if (!fin) { mode = edsp::MODE_DONE; if (lane == 0) { sv.failed = 1; sv.done = 1; } }
+                    else { store = true; have_cur = 1; if (lane == 0) sv.initial_cost = cost; }
+                } else {
+                    const int ok = fin && (cost < cur_cost);
+                    accepted = ok;
+                    if (lane == 0 && ntrace < EDS_MAX_TRACE) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sv.tr_xi[ntrace][i] = sp.spec[k].xi[i];
+                        sv.tr_cost[ntrace] = cost; sv.tr_acc[ntrace] = ok;
+                    }
+                    if (ntrace < EDS_MAX_TRACE) ++ntrace;
+                    ++iter;
+                    if (ok) {
+                        store = true;
+                        lambda *= 0.5;
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) sv.p[i] = sp.spec[k].p[i];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sv.q[i] = sp.spec[k].q[i];
+                        }
+                    } else {
+                        lambda = edsp::next_lambda_after_reject(lambda);
+                    }
+                    if (iter >= max_iters) {        // Solver6::finish with the residuals kept by the caller: done, no extra pass
+                        mode = edsp::MODE_DONE;
+                        if (lane == 0) { sv.final_cost = ok ? cost : cur_cost; sv.done = 1; }
+                    } else if (!ok && k + 1 < EDS_NSPEC) {
+                        mode = edsp::MODE_USE; nk = k + 1;      // the candidate prepared for exactly this lambda
+                    }
+                }
+                if (store && lane < EDS_RED_N6) sp.cur[lane] = s;
+                if (lane == 0) {
+                    sv.lambda = lambda; sv.have_cur = have_cur; sv.iter = iter; sv.ntrace = ntrace; sv.last_accepted = accepted;
+                    sp.mode = mode; sp.k = nk;
+                    s_accept = accepted;
+                    if (mode == edsp::MODE_DONE) s_state = 2;
+                }
+                if (mode == edsp::MODE_SOLVE) {     // fresh linearisation (or candidates used up): lane w solves it for the lambda
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // that w rejections in a row would lead to — one
+                    __builtin_amdgcn_wave_barrier();                             // instruction stream, EDS_NSPEC lanes
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < EDS_NSPEC) edsp::propose(sp.cur, lambda, lane, sv.p, sv.q, sp.spec[lane]);
+                }
+            }
+            EDS_STAMP(3);
+            __syncthreads();
+            if (s_accept) {
+#pragma unroll
+                for (int j = 0; j < NREG; ++j) racc[j] = rcand[j];
+            }
+            if (sp.mode == edsp::MODE_DONE) break;
+            if (!sp.spec[sp.k].ok) {                // damped matrix not positive definite: Solver6 gives up here (failed only at iteration 0)
+                if (tid == 0) { sv.failed = (sv.iter == 0); sv.final_cost = sp.cur[EDS_RED_N6 - 1]; sv.done = 1; }
+                break;
+            }
+            continue;
+        }
         if (tid < EDS_RED_N6) {          // cross-wavefront sum in fp64, unpacked straight into the solver's input
             float part[EDS_FUSED_MAX_WAVES];
 #pragma unroll
@@ -345,6 +442,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #endif
 #endif
 
+    __syncthreads();                    // the solver state as its last writer left it
     if (tid == 0) {
         EdsFusedOut& O = out[slot];
         for (int i = 0; i < 3; ++i) O.p[i] = sv.p[i];
@@ -435,7 +533,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     ppt = ppt <= 1 ? 1 : (ppt <= 2 ? 2 : (ppt <= 4 ? 4 : 0));
     if (const char* ev = getenv("EDS_FUSED_PPT")) ppt = atoi(ev) > 0 && atoi(ev) * threads >= maxN ? atoi(ev) : 0;   // tuning knob
     const double tau = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
-    const int damped = h->cfg.solver == EDS_SOLVER_LM6;
+    int damped = h->cfg.solver == EDS_SOLVER_LM6;
+    if (damped) { const char* ev = getenv("EDS_LM6_SPEC"); if (ev && ev[0] == '0') damped = 2; }   // tuning knob: prepared candidates off
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
     // Streaming variants (eds_stream6.hip: constants re-read per pass, any N).
     //  * N <= 2 048: "paired" — two 256-thread workgroups per CU, reduction / solver overlapped with the other's points —
