@@ -2,6 +2,7 @@
 // drive the CPU oracle through ctypes.  TEST INFRASTRUCTURE ONLY — see the header
 // of eds_oracle.hpp (parity unpinned; never linked into the product library).
 #include "eds_oracle.hpp"
+#include "eds_cpu_fast.hpp"
 
 #include <chrono>
 
@@ -132,6 +133,23 @@ int eds_oracle_pose6_lm(const eds_oracle_problem* p, const eds_oracle_config* c,
 }
 
 // Tracker::getLossParams; `residuals` is reordered in place exactly like the reference.
+// Optimised CPU variant of pose6_lm (eds_cpu_fast.hpp): fp32 sampling, analytic rows, SoA — bench.py's second CPU baseline.
+// prepare() is the counterpart of the GPU library's set_keyframe / set_event_frame (inputs converted once, outside the timed
+// solves); the handle is freed with eds_oracle_fast_free.
+void* eds_oracle_fast_prepare(const eds_oracle_problem* p, const double* vx) {
+    Problem pb = to_problem(p);
+    eds_cpu_fast::Prepared* P = new eds_cpu_fast::Prepared();
+    eds_cpu_fast::prepare(pb, vx, P);
+    return P;
+}
+void eds_oracle_fast_free(void* h) { delete static_cast<eds_cpu_fast::Prepared*>(h); }
+int eds_oracle_fast_lm6(const void* h, double* px, double* qx, int iters, double lambda0, int32_t* accepted, double* seconds) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = eds_cpu_fast::lm6(*static_cast<const eds_cpu_fast::Prepared*>(h), px, qx, iters, lambda0, accepted);
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return n;
+}
+
 double eds_oracle_loss_param(double* residuals, int n, int method, double current) {
     std::vector<double> r(residuals, residuals + n);
     const double tau = loss_param(r, method, current);

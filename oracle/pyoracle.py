@@ -44,7 +44,7 @@ class _Summary(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with g++ (a few seconds).  Building the checker is not using it."""
-    src = [os.path.join(_HERE, f) for f in ("eds_oracle_capi.cpp", "eds_oracle.hpp")]
+    src = [os.path.join(_HERE, f) for f in ("eds_oracle_capi.cpp", "eds_oracle.hpp", "eds_cpu_fast.hpp")]
     stale = (not os.path.exists(_LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libeds_oracle.so"])
@@ -136,6 +136,29 @@ class Oracle:
                                       acc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(c0), C.byref(sec))
         return dict(p=p, q=q, iterations=n, increments=inc[:n], costs=costs[:n], accepted=acc[:n],
                     initial_cost=c0.value, seconds=sec.value)
+
+
+class FastLM6:
+    """The optimised CPU variant (oracle/eds_cpu_fast.hpp) of Oracle.pose6_lm for a fixed velocity: a baseline, not a checker.
+    Construction converts the inputs once (the counterpart of set_keyframe / set_event_frame); solve() is what gets timed."""
+
+    def __init__(self, oracle: "Oracle", v):
+        self._o = oracle
+        lib().eds_oracle_fast_prepare.restype = C.c_void_p
+        self._h = C.c_void_p(lib().eds_oracle_fast_prepare(C.byref(oracle.pb), _p(_f64(v))))
+
+    def solve(self, p, q, iters=10, lambda0=0.01):
+        p, q = _f64(p).copy(), _f64(q).copy()
+        acc = np.zeros(iters, dtype=np.int32)
+        sec = C.c_double(0.0)
+        n = lib().eds_oracle_fast_lm6(self._h, _p(p), _p(q), int(iters), C.c_double(lambda0),
+                                      acc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(sec))
+        return dict(p=p, q=q, iterations=n, accepted=acc[:n], seconds=sec.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().eds_oracle_fast_free(self._h)
+            self._h = None
 
 
 def loss_param(residuals, method, current=0.0):

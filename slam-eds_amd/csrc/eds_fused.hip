@@ -542,7 +542,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     //  * N > 2 048, where the resident kernel needs 1 024 threads at 128 registers: "wide" — one 512-thread workgroup
     //    with the whole patch cache (N = 4 000: 0.21 vs 0.30 ms for one alignment, 4.1 M vs 2.5 M it/s at 256; N = 8 000:
     //    2.1 M vs 1.7 M at 256); only a handful of very large alignments is still faster with 1 024 threads.
-    bool stream = maxN <= 2048 ? count >= 1536 : !(maxN > 4096 && count < 16);
+    // (round 2: with the quad-cooperative gather and the prepared candidates the register-resident kernel — one alignment per CU,
+    // 256 frames in flight, whole patch cache — beats the paired streaming shape at every batch size: 13.2 M vs 10.5 M it/s at 4 096)
+    bool stream = maxN <= 2048 ? false : !(maxN > 4096 && count < 16);
     bool wide = maxN > 2048;
     if (const char* ev = getenv("EDS_LM6_KERNEL")) {                 // tuning knob: "resident" | "paired" | "wide"
         stream = std::strcmp(ev, "paired") == 0 || std::strcmp(ev, "wide") == 0 || std::strcmp(ev, "stream") == 0;
@@ -559,7 +561,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
                        iters, damped, h->cfg.lambda0, tau, nb)
 #define EDS_LAUNCH_FUSED_T(S, P, Q) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024, Q); else EDS_LAUNCH_FUSED(S, P, 512, Q); } while (0)
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-    bool quad = true;                                                // the quad-cooperative gather (bicubic, register-resident points)
+    // the quad-cooperative gather (bicubic, register-resident points) costs ~130 more instructions per point and wins once the
+    // gather, not the instruction stream, bounds the pass: 152 vs 184 us at 64 alignments, 114 vs 102 us for a lone one
+    bool quad = count >= 32;
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
     quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP;       // every point's patch has a cache line of its own
     switch (ppt) {

@@ -333,3 +333,15 @@ def test_oracle_reproduces_golden(po, synth, path):
         ref = g[f"{tag}_ref12_none"]
         assert po.se3_distance(s["p"], s["q"], ref[0:3], ref[3:7]) < 1e-8
         assert s["num_iterations"] == int(ref[14]) and s["termination"] == int(ref[16])
+
+
+def test_fast_cpu_variant_matches_pose6_lm(synth, po):
+    """oracle/eds_cpu_fast.hpp (bench.py's optimised CPU baseline: fp32 sampling, analytic rows) takes the same LM6 steps as the
+    autodiff oracle: same accept pattern, solved pose within 1e-5."""
+    for seed, kw in ((41, dict(H=120, W=160, N=300)), (5000, {})):
+        al = synth.make_alignment(seed, **kw)
+        o = po.Oracle(al)
+        ref = o.pose6_lm(al.p0, al.q0, al.v0, iters=10, lambda0=0.01)
+        got = po.FastLM6(o, al.v0).solve(al.p0, al.q0, iters=10, lambda0=0.01)
+        assert got["iterations"] == ref["iterations"] and np.array_equal(got["accepted"], ref["accepted"])
+        assert po.se3_distance(got["p"], got["q"], ref["p"], ref["q"]) <= 1e-5
