@@ -48,14 +48,42 @@ using namespace edsd;
 // QUAD (bicubic, PPT > 0): the quad-cooperative gather of eds_device.hpp — lane j of a quad loads row j of each of the quad's
 // four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane; the cache then
 // holds [point][row] units of 16 bytes.  QUAD = 0 is the lane-per-point gather of round 1 (kept for bilinear and for A/B runs).
-template <int SAMPLING, int PPT, int MAXT, int QUAD>
+//
+// TEAM = K > 1: K workgroups (K CUs) share ONE alignment — the latency regime, where a launch holds fewer alignments than the chip
+// has CUs (the reference's own operating point is a single optimize per event slice, Tracker.cpp:104).  Member m takes the points
+// [m, m + 1) * PPT * nthr; after the in-workgroup reduction every member publishes its 28 fp64 partial sums as 56 eight-byte
+// {32 data bits, 32-bit tag} granules (one sc1 store each: a granule is written and read atomically, so data and "ready" flag
+// cannot be seen apart and no fence is needed — MI355X_MICROARCH.md, granule hand-off), polls the other members' granules, and sums
+// all K contributions in member order.  Every member therefore holds bit-identical totals and runs the (prepared-candidate) solver
+// redundantly: no broadcast step, one exchange per pass (~1.5 us on an idle chip against a 4-9 us pass).  Teams are formed from an
+// atomic ticket — members of a team hold consecutive tickets, so at most one team of a launch is ever incomplete and it is completed
+// by the very next workgroups to start: no co-residency assumption, no deadlock whatever the dispatch order.  Polls are bounded
+// (EDS_TEAM_TIMEOUT_TICKS of the 100 MHz clock); on a timeout the solve is reported failed-with-timeout and the host re-runs the
+// range with TEAM = 1.
+#define EDS_TEAM_MAX 4
+#define EDS_TEAM_GRANULES 64                      // per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
+#define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
+#define EDS_TEAM_SLOTS 128                        // a team launch holds at most this many alignments
+#define EDS_TEAM_MAIL_BYTES ((size_t)EDS_TEAM_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM_GRANULES * 8)
+template <int SAMPLING, int PPT, int MAXT, int QUAD, int TEAM>
 __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
-                                                          double huber_tau, int nb) {
-    const int slot = first + blockIdx.x;
+                                                          double huber_tau, int nb, unsigned long long* __restrict__ mail,
+                                                          int* __restrict__ ticket, unsigned epoch) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_ticket;
+    __shared__ unsigned s_xchg[EDS_TEAM_MAX][EDS_TEAM_GRANULES];
+    __shared__ int s_timeout;
+    int team_slot = blockIdx.x, member = 0;
+    if (TEAM > 1) {
+        if (tid == 0) { s_ticket = atomicAdd(ticket, 1); s_timeout = 0; }
+        __syncthreads();
+        team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
+    }
+    const int slot = first + team_slot;
+    unsigned pass_no = 0;                         // exchanges so far (TEAM > 1)
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];
@@ -71,9 +99,13 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
-    const int N = (int)gpb[EDS_PB_N];
-    const int ne = N / nb;
-    const size_t base = (size_t)slot * A.Np;
+    const int Nall = (int)gpb[EDS_PB_N];
+    const int ne = Nall / nb;
+    // a team member sees its own slice of the points as "the" points: local index i <-> point poff + i
+    const int poff = TEAM > 1 ? member * PPT * MAXT : 0;
+    const int N = TEAM > 1 ? (Nall - poff < 0 ? 0 : (Nall - poff > PPT * MAXT ? PPT * MAXT : Nall - poff)) : Nall;
+    const size_t base = (size_t)slot * A.Np + poff;
+    static_assert(TEAM == 1 || PPT > 0, "teams keep their points in registers");
     const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
     const float* __restrict__ tiles = A.frame + (size_t)slot * A.Hp * A.Wp;              // start of this slot's allocation (quad gather)
     static_assert(!QUAD || (SAMPLING == 0 && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: bicubic, register-resident points, all cached");
@@ -117,7 +149,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             float m = 0.0f;
 #pragma unroll
             for (int k = 0; k < 6; ++k) m += a[k] * vf[k];
-            const float mh = m * (float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * block_of(in_range ? i : 0, ne, nb)];
+            const float mh = m * (float)s_pose[EDS_PB_BLK + EDS_PB_BLK_STRIDE * block_of(in_range ? poff + i : 0, ne, nb)];
             if (PPT > 0) {
 #pragma unroll
                 for (int jj = 0; jj < NREG; ++jj) {
@@ -311,6 +343,43 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
                     for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)part[wv];
                 }
+                if (TEAM > 1) {
+                    // publish this member's partial sums: lane t < 28 writes its double as two tagged 8-byte granules (sc1 stores)
+                    const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
+                    unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * (TEAM * EDS_TEAM_GRANULES);
+                    if (lane < EDS_RED_N6) {
+                        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+                        __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xffffffffull),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    // gather all members' granules (own included: every member then adds the same numbers in the same order)
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+                    for (int m = 0; m < TEAM; ++m) {
+                        if (lane < 2 * EDS_RED_N6) {
+                            const unsigned long long* g = mb + m * EDS_TEAM_GRANULES + lane;
+                            unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            while ((unsigned)(v >> 32) != tag) {
+                                if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                                __builtin_amdgcn_s_sleep(2);
+                                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            s_xchg[m][lane] = (unsigned)v;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    s = 0.0;
+                    if (lane < EDS_RED_N6) {
+#pragma unroll
+                        for (int m = 0; m < TEAM; ++m)
+                            s += __longlong_as_double((long long)(((unsigned long long)s_xchg[m][2 * lane + 1] << 32) | s_xchg[m][2 * lane]));
+                    }
+                    ++pass_no;
+                }
                 EDS_STAMP(2);
                 EDS_STAMP2(3);
                 const int k = sp.k, max_iters = sv.max_iters;
@@ -372,6 +441,10 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             }
             EDS_STAMP(3);
             __syncthreads();
+            if (TEAM > 1 && s_timeout) {            // a team member never showed up within the bound: give up cleanly, the host re-runs without teams
+                if (tid == 0) { sv.failed = 2; sv.done = 1; }
+                break;
+            }
             if (s_accept) {
 #pragma unroll
                 for (int j = 0; j < NREG; ++j) racc[j] = rcand[j];
@@ -436,13 +509,14 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     }
 #ifdef EDS_FUSED_STAMPS
     // diagnostic build only: cycles of lane 0 in [point loop | reduction | solver] into the pad words
-    if (tid == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
+    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
 #if EDS_FUSED_STAMPS == 2
-    if (tid == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
+    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
 #endif
 #endif
 
     __syncthreads();                    // the solver state as its last writer left it
+    if (TEAM > 1 && member != 0) return;    // every member holds the same result; member 0 reports it
     if (tid == 0) {
         EdsFusedOut& O = out[slot];
         for (int i = 0; i < 3; ++i) O.p[i] = sv.p[i];
@@ -472,6 +546,11 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     if (hipHostMalloc((void**)&fb->h_out, sizeof(EdsFusedOut) * B, hipHostMallocDefault) != hipSuccess) return -1;
     if (hipMalloc((void**)&fb->d_out12, sizeof(EdsFused12Out) * B) != hipSuccess) return -1;
     if (hipHostMalloc((void**)&fb->h_out12, sizeof(EdsFused12Out) * B, hipHostMallocDefault) != hipSuccess) return -1;
+    // team launches (eds_fused6_kernel TEAM > 1): granule mailboxes of EDS_TEAM_SLOTS alignments + the ticket counter
+    if (hipMalloc((void**)&fb->d_mail, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
+    if (hipMemset(fb->d_mail, 0, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
+    if (hipMalloc((void**)&fb->d_ticket, sizeof(int)) != hipSuccess) return -1;
+    fb->epoch = 0;
     std::memset(fb->h_out12, 0, sizeof(EdsFused12Out) * B);
     std::memset(fb->h_in, 0, sizeof(EdsFusedIn) * B);
     std::memset(fb->h_out, 0, sizeof(EdsFusedOut) * B);
@@ -485,6 +564,8 @@ void eds_fused_free(EdsFusedBuffers* fb) {
     if (fb->h_in) hipHostFree(fb->h_in);
     if (fb->h_out) hipHostFree(fb->h_out);
     if (fb->d_out12) hipFree(fb->d_out12);
+    if (fb->d_mail) hipFree(fb->d_mail);
+    if (fb->d_ticket) hipFree(fb->d_ticket);
     if (fb->h_out12) hipHostFree(fb->h_out12);
     *fb = EdsFusedBuffers();
 }
@@ -550,15 +631,46 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         stream = std::strcmp(ev, "paired") == 0 || std::strcmp(ev, "wide") == 0 || std::strcmp(ev, "stream") == 0;
         wide = std::strcmp(ev, "wide") == 0;
     }
+#define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q, 1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u)
+#define EDS_LAUNCH_TEAM(S, P, Q, K)                                                                                                \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, fb.epoch)
+    // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
+    // solves with register-resident points only; 4 CUs up to 64 alignments of more than 1 024 points, 2 CUs up to 128.
+    int team = 1;
+    if (!stream && damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512 && maxN <= 2048) {
+        if (count <= 64 && maxN > 1024) team = 4;
+        else if (count <= EDS_TEAM_SLOTS) team = 2;
+    }
+    if (const char* ev = getenv("EDS_LM6_TEAM")) {                    // tuning knob: 1 | 2 | 4
+        const int v = atoi(ev);
+        const bool feasible = !stream && damped == 1 && iters > 0 && count <= EDS_TEAM_SLOTS && maxN <= 2048;
+        if (v == 1 || ((v == 2 || v == 4) && feasible)) team = v;
+    }
+    if (team > 1) {
+        if (++fb.epoch >= (1u << 24)) {              // tags are (epoch << 8 | pass): start over with clean mailboxes
+            hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
+            fb.epoch = 1;
+        }
+        hipMemsetAsync(fb.d_ticket, 0, sizeof(int), h->st);
+    }
+    fb.pending_team = team; fb.pending_level = level;
     hipEventRecord(h->ev0, h->st);
-    if (stream) {
+    if (team > 1) {
+        const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
+        const bool q = bic && count * team >= 128;   // enough gathers in flight for the quad-cooperative form to pay
+        if (team == 4) {                             // 512 points per member, one per lane
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_TEAM(1, 1, 0, 4);
+        } else {                                     // 1 024 points per member, two per lane
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 2); else EDS_LAUNCH_TEAM(0, 2, 0, 2); } else EDS_LAUNCH_TEAM(1, 2, 0, 2);
+        }
+    } else if (stream) {
         eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
     } else {
     // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
     // lane variant needs to keep 4 x 16 taps + constants in registers without spilling
-#define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb)
 #define EDS_LAUNCH_FUSED_T(S, P, Q) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024, Q); else EDS_LAUNCH_FUSED(S, P, 512, Q); } while (0)
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
     // the quad-cooperative gather (bicubic, register-resident points) costs ~130 more instructions per point and wins once the
@@ -575,6 +687,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
 #undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED
+#undef EDS_LAUNCH_TEAM
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
@@ -594,6 +707,20 @@ int eds_fused_collect(eds_trk* h) {
     const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     float dev_ms = 0.f;
     hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
+    if (fb.pending_team > 1) {                        // a team whose members did not all become resident within the bound
+        bool timed_out = false;
+        for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) timed_out |= fb.h_out[s].failed == 2;
+        if (timed_out) {                             // never again on this handle; solve the range once more, one CU per alignment
+            fb.team_disabled = true;
+            const int pf = fb.pending_first, pc = fb.pending_count;
+            fb.pending_count = 0;
+            int rc = eds_fused_solve(h, fb.pending_level, pf, pc);
+            if (rc != EDS_OK) return rc;
+            hipError_t e = hipStreamSynchronize(h->st);
+            if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+            return eds_fused_collect(h);
+        }
+    }
     for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) {
         Slot& sl = h->slots[s];
         const EdsFusedOut& O = fb.h_out[s];

@@ -35,6 +35,11 @@ struct EdsFusedBuffers {
     EdsFusedIn* h_in = nullptr;    // pinned
     EdsFusedOut* h_out = nullptr;  // pinned
     EdsFused12Out* h_out12 = nullptr;
+    unsigned long long* d_mail = nullptr;   // team launches: tagged 8-byte granules, [team slot][parity][member][64]
+    int* d_ticket = nullptr;                // team launches: workgroup arrival counter (team = ticket / K, member = ticket % K)
+    unsigned epoch = 0;                     // launch sequence number inside the granule tags
+    bool team_disabled = false;             // a team once timed out on this handle
+    int pending_team = 1, pending_level = 0;
     int B = 0;
     int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
     double launch_wall_us = 0.0;

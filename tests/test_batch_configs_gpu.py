@@ -141,3 +141,59 @@ def test_new_keyframe_invalidates_device_residuals(gpu, capi, synth):
     with pytest.raises(capi.EdsError):
         h.loss_param_batch(capi.LP_MAD, 0, 1)
     h.close()
+
+
+@pytest.mark.parametrize("team", [2, 4])
+def test_team_kernel_vs_oracle_and_single_cu(gpu, capi, synth, po, monkeypatch, team):
+    """Several CUs per alignment (eds_fused6_kernel TEAM = K: points split K-way, partial sums exchanged through tagged granules,
+    every member running the solver on identical totals) against the oracle and against the one-CU kernel, on ragged point counts
+    (members with few or no points), both samplers, with and without the per-point Huber weight."""
+    als = [synth.make_alignment(7100 + b, H=240, W=320, N=n) for b, n in enumerate((513, 700, 1024, 1025, 1999, 2048))]
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    P0, Q0, V0 = np.stack([ps] * len(als)), np.stack([qs] * len(als)), np.stack([a.v0 for a in als])
+    for sampling in (0, 1):
+        for tau in (0.0, 0.01):
+            res = {}
+            for k in (1, team):
+                monkeypatch.setenv("EDS_LM6_TEAM", str(k))
+                h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, sampling=sampling, max_num_iterations=10,
+                                                    huber_tau=tau), len(als), 2048, 240, 320)
+                for b, a in enumerate(als):
+                    h.set_alignment(b, a)
+                h.set_states(0, P0, Q0, V0)
+                h.optimize_batch(0, 0, len(als))
+                res[k] = (h.results(0, len(als)), [h.residuals(b) for b in range(len(als))], [h.trace(b) for b in range(len(als))])
+                h.close()
+            (t1, r1, tr1), (tk, rk, trk) = res[1], res[team]
+            for b, a in enumerate(als):
+                ref = po.Oracle(a, sampling=sampling).pose6_lm(ps, qs, a.v0, iters=10, lambda0=0.01, huber_tau=tau)
+                assert tk[b, 15] == 1.0 and tk[b, 14] == 10
+                assert np.array_equal(trk[b]["accepted"], ref["accepted"]) and np.array_equal(trk[b]["accepted"], tr1[b]["accepted"])
+                assert po.se3_distance(tk[b, 0:3], tk[b, 3:7], ref["p"], ref["q"]) <= TOL_POSE
+                assert po.se3_distance(tk[b, 0:3], tk[b, 3:7], t1[b, 0:3], t1[b, 3:7]) <= 1e-6
+                for k in range(len(trk[b]["increments"])):
+                    assert np.abs(trk[b]["increments"][k] - tr1[b]["increments"][k]).max() <= 1e-4 * max(np.abs(tr1[b]["increments"][k]).max(), 1e-3)
+                er = po.Oracle(a, sampling=sampling).pose6_eval(tk[b, 0:3], tk[b, 3:7], a.v0)["r"]
+                assert rk[b].shape == (a.N,) and np.abs(rk[b] - er).max() <= 1e-5 * np.abs(er).max()
+
+
+def test_team_launches_back_to_back_and_in_sub_ranges(gpu, capi, synth, po, monkeypatch):
+    """Granule tags carry the launch number: 40 team launches in a row on one handle (different sub-ranges, so a slot's mailbox
+    is re-used by other alignments) keep returning the single-CU result."""
+    monkeypatch.setenv("EDS_LM6_TEAM", "4")
+    als = [synth.make_alignment(7200 + b, H=240, W=320, N=1500 + 100 * b) for b in range(5)]
+    h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=8), len(als), 2048, 240, 320)
+    for b, a in enumerate(als):
+        h.set_alignment(b, a)
+    refs = [po.Oracle(a).pose6_lm(a.p0, a.q0, a.v0, iters=8, lambda0=0.01) for a in als]
+    rng = np.random.default_rng(3)
+    for rep in range(40):
+        first = int(rng.integers(0, len(als)))
+        count = int(rng.integers(1, len(als) - first + 1))
+        h.set_states(0, np.stack([a.p0 for a in als]), np.stack([a.q0 for a in als]), np.stack([a.v0 for a in als]))
+        h.optimize_batch(0, first, count)
+        tab = h.results(0, len(als))
+        for b in range(first, first + count):
+            assert po.se3_distance(tab[b, 0:3], tab[b, 3:7], refs[b]["p"], refs[b]["q"]) <= TOL_POSE, (rep, b)
+            assert np.array_equal(h.trace(b)["accepted"], refs[b]["accepted"])
+    h.close()
