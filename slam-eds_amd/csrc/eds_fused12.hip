@@ -53,7 +53,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     __shared__ edss::Solver12 sv;
     __shared__ edss::Sums12Dev sums;
     __shared__ edsc::Work12 work;
-    __shared__ double s_pose[EDS_POSE_STRIDE];
+    __shared__ double s_pb[EDS_NCAND][EDS_POSE_STRIDE];      // pose blocks of the prepared steps (eds_solver12_coop.hpp); s_pb[s_k] is being evaluated
+    __shared__ edsc::Cand12 s_cand[EDS_NCAND];
+    __shared__ edsc::Step12 s_step[EDS_NCAND];
+    __shared__ int s_k, s_head, s_walk;
     __shared__ float s_stage[(NTHR / 64)][64 * 17];
     __shared__ int s_state, s_accept;
     __shared__ float s_patch[NTAP][CAP];
@@ -72,8 +75,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         for (int k = lane; k < nb * 36; k += 64) s_G[k] = Gg[k];
         if (lane == 0) {
             const EdsFusedIn& I = in[slot];
-            for (int i = 0; i < 4; ++i) s_pose[EDS_PB_K + i] = gpb[EDS_PB_K + i];
+            for (int w = 0; w < EDS_NCAND; ++w)
+                for (int i = 0; i < 4; ++i) s_pb[w][EDS_PB_K + i] = gpb[EDS_PB_K + i];
             sv.init(iters, loss_type, loss_a, ftol, gtol, ptol, I.p, I.q, I.v);
+            s_k = 0; s_head = 0; s_walk = edsc::W_EVAL;
             sv.skip_final = 1;              // accepted-point residuals are kept in the residual plane as the solve goes
             sums.nb = nb;
             s_state = 0; s_accept = 0;
@@ -82,8 +87,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #endif
         }
         EDS_WSYNC();
-        edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, s_G, nb, s_pose, lane);
+        edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, s_G, nb, s_pb[0], lane);
     }
+    static_assert(NTHR / 64 >= EDS_NCAND, "one wavefront per prepared step");
     for (int i = tid; i < CAP; i += nthr) s_cell[i] = 0x7fffffff;
     for (int k = tid; k < (NTHR / 64) * 64 * 17; k += nthr) (&s_stage[0][0])[k] = 0.0f;    // columns 13..15 stay zero for good
     for (int k = tid; k < (int)(sizeof(sums) / sizeof(double)); k += nthr)
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #define EDS12_STAMP(k) do { } while (0)
 #endif
     for (;;) {
+        const double* __restrict__ s_pose = s_pb[s_k];      // the pose block under evaluation
         PoseF ps;
         load_pose(s_pose, ps);
         float vf[6];
@@ -277,15 +284,41 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         EDS12_STAMP(0);
         __syncthreads();
         EDS12_STAMP(1);
-        if (wave == 0) {                        // the LM state machine, spread over this wavefront (eds_solver12_coop.hpp)
-            edsc::coop12_on_eval(sv, sums, work, s_pose, lane);
-            const int done = edsc::uniform_int(sv.done);
+        if (wave == 0) {                        // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
+            const int mode = edsc::coop12_decide(sv, sums, work, s_pose, lane);          // linearisation if it was accepted,
             for (int k = 1 + lane; k < (int)(sizeof(sums) / sizeof(double)); k += 64) reinterpret_cast<double*>(&sums)[k] = 0.0;
-            if (!done) edsc::coop_fill_pose_block(sv.cp, sv.cq, sv.cv, s_G, nb, s_pose, lane);
+            if (lane == 0) {                    // and the bookkeeping up to the next step — a prepared one, if there is one
+                s_accept = work.accepted;
+                if (mode == edsc::M_RETURN) {
+                    s_walk = edsc::W_RETURN;
+                } else {
+                    int k = (mode == edsc::M_ADVANCE) ? s_k + 1 : EDS_NCAND;             // one notch down the radius sequence / all stale
+                    int head = 0;
+                    s_walk = edsc::coop12_walk(sv, s_cand, &k, &head);
+                    s_k = k; s_head = head;
+                }
+            }
+        }
+        __syncthreads();
+        while (s_walk == edsc::W_NEED) {        // no step prepared for this radius: EDS_NCAND wavefronts prepare the next ones side by side
+            if (wave < EDS_NCAND) {
+                edsc::coop12_propose(sv, wave, s_cand[wave], s_step[wave], lane);
+                if (edsc::uniform_int(s_cand[wave].valid))
+                    edsc::coop_fill_pose_block(s_cand[wave].cp, s_cand[wave].cq, s_cand[wave].cv, s_G, nb, s_pb[wave], lane);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int k = 0, head = s_head;
+                s_walk = edsc::coop12_walk(sv, s_cand, &k, &head);
+                s_k = k; s_head = head;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
 #ifdef EDS_FUSED_STAMPS
-            if (lane == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); work.st[6] += n_ - work.st_t; work.st_t = n_; }
+            const unsigned long long n_ = __builtin_readcyclecounter(); work.st[6] += n_ - work.st_t; work.st_t = n_;
 #endif
-            if (lane == 0) { s_state = done ? 2 : 0; s_accept = work.accepted; }
+            s_state = (s_walk == edsc::W_RETURN) ? 2 : 0;
         }
         __syncthreads();
         EDS12_STAMP(2);
@@ -355,7 +388,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
                        h->cfg.parameter_tolerance, nb)
 #define EDS_LAUNCH12(S, T, C) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true); else EDS_LAUNCH12_(S, T, C, false); } while (0)
-    if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1536); else EDS_LAUNCH12(1, 512, 1536); }
+    if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1408); else EDS_LAUNCH12(1, 512, 1408); }
     else { if (bicubic) EDS_LAUNCH12(0, 256, 320); else EDS_LAUNCH12(1, 256, 320); }
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_

@@ -53,12 +53,32 @@ __device__ __forceinline__ double bcast(double x, int src) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// edss::Solver12::on_eval + advance, cooperatively.  On return either sv.done is set, or (sv.cp, sv.cq, sv.cv) is
-// the next point to evaluate (sv.final_pass tells whether that evaluation is the residual pass at the solution).
-// `pb` is the pose block the sums were evaluated at: the persistent kernel accumulates the velocity columns WITHOUT the
-// local-parameterisation factor Pv = (I - v v^T/|v|^2)/|v| (identical for all points), so linearising applies
-// J^T J -> P^T (J^T J) P, J^T r -> P^T (J^T r) with P = blockdiag(I_6, Pv) here, once, on the 12 x 12 sums.
-__device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
+// ---- prepared steps (round 2) ----------------------------------------------------------------------------------------------
+// Ceres rejects more than half of its steps on this problem (5 successful / 6 unsuccessful of 11 on the bench workload), and after
+// an unsuccessful (or invalid) step the next one depends only on the linearisation at the accepted point and on the shrunken
+// radius — radius / decrease_factor, decrease_factor * 2, LevenbergMarquardtStrategy::StepRejected — both known before the rejected
+// step was even evaluated.  So whenever steps have to be computed, EDS_NCAND wavefronts compute them side by side for the radius
+// the solver is at and for the next EDS_NCAND - 1 radii of that sequence (each on its own SIMD: the wall time of one), including
+// the candidate point and its pose block.  An unsuccessful evaluation then only does the O(1) bookkeeping and moves on to the
+// prepared step: linearisation, factorisation and pose block are off its critical path.  Decisions, counters, radii and the order of
+// every floating-point operation are those of edss::Solver12 (which the host-driven loop and the CPU tests run).
+#define EDS_NCAND 4
+enum { W_RETURN = 0, W_EVAL = 1, W_NEED = 2 };
+
+struct Cand12 {                 // one prepared step
+    double step[12], mcc;       // scaled step, model cost change
+    double cp[3], cq[4], cv[6]; // the point it leads to
+    int valid, pad;
+};
+struct Step12 {                 // LDS scratch of one proposing wavefront
+    double y[12], t[12];
+    int ok, pad;
+};
+
+// Solver12::on_eval up to (and including) the linearisation at a newly accepted point.  Wavefront 0, all lanes.
+// Returns M_RETURN (solve ended: sv.done set), M_ADVANCE (unsuccessful step: radius already shrunk, prepared steps still valid) or
+// M_LIN_ITER0 / M_LIN_ACCEPT (fresh linearisation: prepared steps are stale).  `pb`: the pose block the sums were evaluated at.
+__device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
     using namespace edss;
     const int nb = S.nb;
 #ifdef EDS_FUSED_STAMPS
@@ -113,9 +133,9 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
     EDS_WSYNC();
     EDS_CSTAMP(0);
     const int mode = uniform_int(W.mode);
-    if (mode == M_RETURN) return;
+    if (mode == M_RETURN || mode == M_ADVANCE) return mode;
 
-    if (mode != M_ADVANCE) {            // Solver12::linearise at the (new) accepted point
+    {                                   // Solver12::linearise at the (new) accepted point
         bool bad = !(fabs(W.cost) < 1e300);
         for (int i = lane; i < 144; i += 64) {
             double a = 0.0;
@@ -137,7 +157,7 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
                 else sv.finish(TERM_FAILURE);
             }
             EDS_WSYNC();
-            return;
+            return M_RETURN;
         }
         {
             const double* Pv = pb + EDS_PB_PV;
@@ -199,10 +219,103 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
         EDS_WSYNC();
         EDS_CSTAMP(1);
     }
+    return mode;
+}
 
-    for (;;) {                          // Solver12::advance
-        if (lane == 0) {
-            int m = M_SOLVE;
+// LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system for the radius that `ahead` further shrinkages lead to, the
+// model cost change, and — for a valid step — the candidate point.  One wavefront, all lanes; reads the solver state, writes only
+// `c`, its scratch `W` and (ahead == 0, first solve after a linearisation) sv.diagonal.  Lane i (< 12) holds ROW i of the lower
+// triangle in registers; pivots and pivot-row entries travel by v_readlane, so the factorisation and both substitutions never
+// touch LDS.  Operation order per entry is that of edsm::chol_solve_packed.
+__device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand12& c, Step12& W, const int lane) {
+    double radius = sv.radius, df = sv.decrease_factor;
+    for (int i = 0; i < ahead; ++i) { radius /= df; df *= 2.0; }
+    const int row = lane < 12 ? lane : 0;
+    double Lr[12];
+    {
+        const double sr = sv.scale[row];
+#pragma unroll
+        for (int b = 0; b < 12; ++b) Lr[b] = sv.A[12 * row + b] * sr * sv.scale[b];     // only b <= row is used
+    }
+    double bi = sv.g[row] * sv.scale[row];
+    {
+        double dg = 0.0;
+#pragma unroll
+        for (int b = 0; b < 12; ++b) dg = (b == row) ? Lr[b] : dg;
+        const double dd = sv.reuse_diagonal ? sv.diagonal[row] : fmin(fmax(dg, 1e-6), 1e32);
+        EDS_WSYNC();                                                 // every proposing wavefront has read reuse_diagonal / diagonal ...
+        if (!sv.reuse_diagonal && ahead == 0 && lane < 12) sv.diagonal[lane] = dd;      // ... before the first one stores it
+        dg += dd / radius;
+#pragma unroll
+        for (int b = 0; b < 12; ++b) Lr[b] = (b == row) ? dg : Lr[b];
+    }
+    double idr = 0.0;               // 1 / L_rr of this lane's row
+    bool okl = true;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const double d = bcast(Lr[j], j);
+        okl = okl && (d > 0.0) && (d < 1e300);
+        const double inv = edsm::rsqrt_(d);
+        if (row == j) { idr = inv; Lr[j] = d * inv; }
+        else Lr[j] = Lr[j] * inv;                                        // meaningful for row > j
+#pragma unroll
+        for (int cc = j + 1; cc < 12; ++cc) Lr[cc] -= Lr[j] * bcast(Lr[j], cc);   // L[i][j] * L[c][j]
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {                                       // L y = b
+        if (row == k) bi = bi * idr;
+        const double yk = bcast(bi, k);
+        if (row > k) bi -= Lr[k] * yk;
+    }
+#pragma unroll
+    for (int i = 11; i >= 0; --i) {                                      // L^T x = y
+        double s = bcast(bi, i);
+#pragma unroll
+        for (int k = i + 1; k < 12; ++k) s -= bcast(Lr[i], k) * bcast(bi, k);          // L[k][i] lives in lane k
+        const double xi = s * bcast(idr, i);
+        if (row == i) bi = xi;
+    }
+    if (lane == 0) W.ok = okl ? 1 : 0;
+    if (lane < 12) { W.y[lane] = bi; c.step[lane] = -bi; }
+    EDS_WSYNC();
+    if (lane < 12) {
+        double t = 0.0;
+        for (int b = 0; b < 12; ++b) t += sv.A[12 * lane + b] * sv.scale[b] * c.step[b];
+        W.t[lane] = t;
+    }
+    EDS_WSYNC();
+    if (lane == 0) {
+        double chk = 0.0;
+        for (int a = 0; a < 12; ++a) chk += W.y[a];
+        bool valid = W.ok && (chk == chk) && (fabs(chk) < 1e300);
+        double mcc = 0.0;
+        if (valid) {
+            double sg = 0.0, sAs = 0.0;
+            for (int a = 0; a < 12; ++a) {
+                sg += c.step[a] * sv.g[a] * sv.scale[a];
+                sAs += c.step[a] * sv.scale[a] * W.t[a];
+            }
+            mcc = -sg - 0.5 * sAs;
+            valid = mcc > 0.0;
+        }
+        c.mcc = mcc; c.valid = valid ? 1 : 0;
+        if (valid) {
+            double delta[12];
+            for (int k = 0; k < 12; ++k) delta[k] = c.step[k] * sv.scale[k];
+            edsm::state_plus12(sv.p, sv.q, sv.v, delta, c.cp, c.cq, c.cv);
+        }
+    }
+    EDS_WSYNC();
+}
+
+// Solver12::advance on prepared steps: lane 0 of wavefront 0.  `k` = index of the prepared step that belongs to the radius the
+// solver is at (EDS_NCAND or more: none prepared), `head_done`: the per-iteration bookkeeping of advance() has already run for the
+// step about to be taken (the walk was interrupted to have steps prepared).  Returns W_RETURN (solve ended), W_EVAL (sv.cp/cq/cv
+// hold the point to evaluate; *k is the prepared step taken) or W_NEED (steps for the current radius are missing).
+__device__ inline int coop12_walk(edss::Solver12& sv, const Cand12* cand, int* k, int* head_done) {
+    using namespace edss;
+    for (;;) {
+        if (!*head_done) {
             if (sv.step_successful) {
                 ++sv.num_successful;
                 if (sv.x_cost < sv.minimum_cost || sv.iteration == 0) {
@@ -214,111 +327,29 @@ __device__ inline void coop12_on_eval(edss::Solver12& sv, const edss::Sums12Dev&
             } else {
                 ++sv.num_unsuccessful;
             }
-            if (sv.iteration >= sv.max_iters) { sv.finish(TERM_NO_CONVERGENCE); m = M_RETURN; }
-            else if (sv.step_successful && sv.grad_max_norm <= sv.gtol) { sv.finish(TERM_CONVERGENCE); m = M_RETURN; }
-            else if (sv.radius < 1e-32) { sv.finish(TERM_CONVERGENCE); m = M_RETURN; }
-            else { ++sv.iteration; sv.step_successful = 0; }
-            W.mode = m; W.ok = 1;
+            if (sv.iteration >= sv.max_iters) { sv.finish(TERM_NO_CONVERGENCE); return W_RETURN; }
+            if (sv.step_successful && sv.grad_max_norm <= sv.gtol) { sv.finish(TERM_CONVERGENCE); return W_RETURN; }
+            if (sv.radius < 1e-32) { sv.finish(TERM_CONVERGENCE); return W_RETURN; }
+            ++sv.iteration; sv.step_successful = 0;
+            *head_done = 1;
         }
-        EDS_WSYNC();
-        EDS_CSTAMP(2);
-        if (uniform_int(W.mode) == M_RETURN) return;
-        // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system.  Lane i (< 12) holds ROW i of the lower
-        // triangle in registers; pivots and pivot-row entries travel by v_readlane (wave-uniform SGPR broadcasts), so the
-        // whole factorisation and both substitutions run without touching LDS.  Operation order per entry is that of
-        // edsm::chol_solve_packed.
-        const int row = lane < 12 ? lane : 0;
-        double Lr[12];
-        {
-            const double sr = sv.scale[row];
-#pragma unroll
-            for (int b = 0; b < 12; ++b) Lr[b] = sv.A[12 * row + b] * sr * sv.scale[b];     // only b <= row is used
+        if (*k >= EDS_NCAND) return W_NEED;
+        const Cand12& c = cand[*k];
+        sv.reuse_diagonal = 1;
+        if (!c.valid) {                 // HandleInvalidStep
+            if (++sv.consecutive_invalid >= 5) { sv.finish(TERM_FAILURE); return W_RETURN; }
+            sv.radius /= sv.decrease_factor; sv.decrease_factor *= 2.0;
+            ++*k; *head_done = 0;
+            continue;                   // counts as an unsuccessful iteration
         }
-        double bi = sv.g[row] * sv.scale[row];
-        {
-            double dg = 0.0;
-#pragma unroll
-            for (int b = 0; b < 12; ++b) dg = (b == row) ? Lr[b] : dg;
-            double dd = sv.reuse_diagonal ? sv.diagonal[row] : fmin(fmax(dg, 1e-6), 1e32);
-            if (!sv.reuse_diagonal && lane < 12) sv.diagonal[lane] = dd;
-            dg += dd / sv.radius;
-#pragma unroll
-            for (int b = 0; b < 12; ++b) Lr[b] = (b == row) ? dg : Lr[b];
-        }
-        double idr = 0.0;               // 1 / L_rr of this lane's row
-        bool okl = true;
-        // right-looking: once column j is scaled, every row subtracts its share from the columns to the right.  Each entry
-        // still receives its subtractions in ascending k — the same sums as the serial left-looking code — but the updates of
-        // one step are independent of each other, so only pivot -> rsqrt -> scale is on the critical path.
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const double d = bcast(Lr[j], j);
-            okl = okl && (d > 0.0) && (d < 1e300);
-            const double inv = edsm::rsqrt_(d);
-            if (row == j) { idr = inv; Lr[j] = d * inv; }
-            else Lr[j] = Lr[j] * inv;                                        // meaningful for row > j
-#pragma unroll
-            for (int c = j + 1; c < 12; ++c) Lr[c] -= Lr[j] * bcast(Lr[j], c);   // L[i][j] * L[c][j]
-        }
-        // L y = b  (each row subtracts in ascending k, y_k broadcast from lane k)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            if (row == k) bi = bi * idr;
-            const double yk = bcast(bi, k);
-            if (row > k) bi -= Lr[k] * yk;
-        }
-        // L^T x = y: x_i = (y_i - sum_{k > i} L[k][i] x_k) / L_ii with k ascending, exactly like the serial code
-#pragma unroll
-        for (int i = 11; i >= 0; --i) {
-            double s = bcast(bi, i);
-#pragma unroll
-            for (int k = i + 1; k < 12; ++k) s -= bcast(Lr[i], k) * bcast(bi, k);          // L[k][i] lives in lane k
-            const double xi = s * bcast(idr, i);
-            if (row == i) bi = xi;
-        }
-        if (lane == 0) W.ok = okl ? 1 : 0;
-        if (lane < 12) W.y[lane] = bi;
-        EDS_WSYNC();
-        EDS_CSTAMP(3);
-        if (lane < 12) sv.step[lane] = -W.y[lane];
-        EDS_WSYNC();
-        if (lane < 12) {
-            double t = 0.0;
-            for (int b = 0; b < 12; ++b) t += sv.A[12 * lane + b] * sv.scale[b] * sv.step[b];
-            W.t[lane] = t;
-        }
-        EDS_WSYNC();
-        EDS_CSTAMP(4);
-        if (lane == 0) {
-            sv.reuse_diagonal = 1;
-            double chk = 0.0;
-            for (int a = 0; a < 12; ++a) chk += W.y[a];
-            bool valid = W.ok && (chk == chk) && (fabs(chk) < 1e300);
-            if (valid) {
-                double sg = 0.0, sAs = 0.0;
-                for (int a = 0; a < 12; ++a) {
-                    sg += sv.step[a] * sv.g[a] * sv.scale[a];
-                    sAs += sv.step[a] * sv.scale[a] * W.t[a];
-                }
-                sv.model_cost_change = -sg - 0.5 * sAs;
-                valid = sv.model_cost_change > 0.0;
-            }
-            int m;
-            if (!valid) {               // HandleInvalidStep
-                if (++sv.consecutive_invalid >= 5) { sv.finish(TERM_FAILURE); m = M_RETURN; }
-                else { sv.radius /= sv.decrease_factor; sv.decrease_factor *= 2.0; sv.reuse_diagonal = 1; m = M_LOOP; }
-            } else {
-                sv.consecutive_invalid = 0;
-                double delta[12];
-                for (int k = 0; k < 12; ++k) delta[k] = sv.step[k] * sv.scale[k];
-                edsm::state_plus12(sv.p, sv.q, sv.v, delta, sv.cp, sv.cq, sv.cv);
-                m = M_RETURN;
-            }
-            W.mode = m;
-        }
-        EDS_WSYNC();
-        EDS_CSTAMP(5);
-        if (uniform_int(W.mode) == M_RETURN) return;
+        sv.consecutive_invalid = 0;
+        for (int i = 0; i < 12; ++i) sv.step[i] = c.step[i];
+        sv.model_cost_change = c.mcc;
+        for (int i = 0; i < 3; ++i) sv.cp[i] = c.cp[i];
+        for (int i = 0; i < 4; ++i) sv.cq[i] = c.cq[i];
+        for (int i = 0; i < 6; ++i) sv.cv[i] = c.cv[i];
+        *head_done = 0;
+        return W_EVAL;
     }
 }
 
