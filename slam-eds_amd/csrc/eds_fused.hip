@@ -60,11 +60,6 @@ using namespace edsd;
 // by the very next workgroups to start: no co-residency assumption, no deadlock whatever the dispatch order.  Polls are bounded
 // (EDS_TEAM_TIMEOUT_TICKS of the 100 MHz clock); on a timeout the solve is reported failed-with-timeout and the host re-runs the
 // range with TEAM = 1.
-#define EDS_TEAM_MAX 4
-#define EDS_TEAM_GRANULES 64                      // per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
-#define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
-#define EDS_TEAM_SLOTS 128                        // a team launch holds at most this many alignments
-#define EDS_TEAM_MAIL_BYTES ((size_t)EDS_TEAM_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM_GRANULES * 8)
 template <int SAMPLING, int PPT, int MAXT, int QUAD, int TEAM>
 __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
@@ -565,6 +560,7 @@ void eds_fused_free(EdsFusedBuffers* fb) {
     if (fb->h_out) hipHostFree(fb->h_out);
     if (fb->d_out12) hipFree(fb->d_out12);
     if (fb->d_mail) hipFree(fb->d_mail);
+    if (fb->d_mail12) hipFree(fb->d_mail12);
     if (fb->d_ticket) hipFree(fb->d_ticket);
     if (fb->h_out12) hipHostFree(fb->h_out12);
     *fb = EdsFusedBuffers();

@@ -27,6 +27,17 @@ struct EdsFused12Out {         // compact result of a REF12 solve
     double pad;
 };
 
+// ---- teams: several workgroups (CUs) per alignment, partial sums exchanged as tagged 8-byte granules (eds_fused.hip) -----------
+#define EDS_TEAM_MAX 4
+#define EDS_TEAM_GRANULES 64                      // LM6, per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
+#define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
+#define EDS_TEAM_SLOTS 128                        // an LM6 team launch holds at most this many alignments
+#define EDS_TEAM_MAIL_BYTES ((size_t)EDS_TEAM_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM_GRANULES * 8)
+#define EDS_TEAM12_VALUES 157                     // REF12, per residual block: ||r||^2, J^T J (144), J^T r (12)
+#define EDS_TEAM12_GRANULES 2560                  // per member and parity: 2 x 157 x 8 blocks = 2 512, padded
+#define EDS_TEAM12_SLOTS 64
+#define EDS_TEAM12_MAIL_BYTES ((size_t)EDS_TEAM12_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM12_GRANULES * 8)
+
 struct EdsFusedBuffers {
     EdsFusedIn* d_in = nullptr;
     EdsFusedOut* d_out = nullptr;
@@ -36,6 +47,7 @@ struct EdsFusedBuffers {
     EdsFusedOut* h_out = nullptr;  // pinned
     EdsFused12Out* h_out12 = nullptr;
     unsigned long long* d_mail = nullptr;   // team launches: tagged 8-byte granules, [team slot][parity][member][64]
+    unsigned long long* d_mail12 = nullptr; // the same for REF12 (allocated at the first REF12 team launch)
     int* d_ticket = nullptr;                // team launches: workgroup arrival counter (team = ticket / K, member = ticket % K)
     unsigned epoch = 0;                     // launch sequence number inside the granule tags
     bool team_disabled = false;             // a team once timed out on this handle

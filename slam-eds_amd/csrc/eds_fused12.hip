@@ -24,6 +24,7 @@
 // is accepted, so no residual pass is needed at the end.  Any number of points.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -41,13 +42,26 @@ using namespace edsd;
 
 typedef double acc4d __attribute__((ext_vector_type(4)));
 
-template <int SAMPLING, int NTHR, int CAP, bool NC>
+// TEAM = K > 1 (latency regime, see eds_fused.hip): K workgroups share one alignment; member m evaluates a contiguous slice of the
+// points, the members exchange their per-block sums (157 doubles per residual block) as tagged granules after every evaluation,
+// add them in member order, and all run the LM state machine on the identical totals.
+template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
-                                                              double loss_a, double ftol, double gtol, double ptol, int nb) {
-    const int slot = first + blockIdx.x;
+                                                              double loss_a, double ftol, double gtol, double ptol, int nb,
+                                                              unsigned long long* __restrict__ mail, int* __restrict__ ticket, unsigned epoch) {
     const int tid = threadIdx.x;
     constexpr int nthr = NTHR;
+    static_assert(TEAM == 1 || !NC, "the NC residual needs a second exchange (block norm of the sampled brightness): no teams");
+    __shared__ int s_ticket, s_timeout;
+    int team_slot = blockIdx.x, member = 0;
+    if (TEAM > 1) {
+        if (tid == 0) { s_ticket = atomicAdd(ticket, 1); s_timeout = 0; }
+        __syncthreads();
+        team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
+    }
+    const int slot = first + team_slot;
+    unsigned pass_no = 0;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     __shared__ edss::Solver12 sv;
@@ -69,6 +83,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
+    // this workgroup's slice of the points [lo, hi): everything for TEAM == 1; whole wavefront tiles otherwise
+    const int chunk = TEAM > 1 ? (((N + TEAM - 1) / TEAM + 63) & ~63) : N;
+    const int lo = TEAM > 1 ? (member * chunk < N ? member * chunk : N) : 0;
+    const int hi = TEAM > 1 ? (lo + chunk < N ? lo + chunk : N) : N;
     const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
 
     if (wave == 0) {
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         auto sweep = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             const size_t jplane = (size_t)A.B * A.Np;
-        for (int j0 = 0; j0 < N; j0 += 2 * nthr) {
+        for (int j0 = lo; j0 < hi; j0 += 2 * nthr) {
             // phase A: two points per lane: constants from HBM/L2, projection, cache probe, gathers in flight
             PointKf kf[2];
             float kw[2], kgx[2], kgy[2];
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
-                const bool valid = i < N;
+                const bool valid = i < hi;
                 const size_t o = base + (valid ? i : 0);
                 const float* __restrict__ c = A.kf + o;                 // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
                 const size_t pl = A.kf_plane;
@@ -154,26 +172,27 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 if (MODE == 2) continue;                                // rows come from the stash: no projection, no gather
                 kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
                 project_point(ps, kf[jj], pg[jj]);
-                const bool cached = i < CAP;
+                const int li = i - lo;                                  // cache index: local to this workgroup's slice
+                const bool cached = li < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
-                miss[jj] = !(cached && s_cell[i] == key);
+                miss[jj] = !(cached && s_cell[li] == key);
                 if (miss[jj]) {
                     if (SAMPLING == 0) load_patch16(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[16]>(tap[jj]));
                     else load_patch4(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[4]>(tap[jj]));
-                    if (cached) s_cell[i] = key;
+                    if (cached) s_cell[li] = key;
                 } else {
 #pragma unroll
-                    for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][i];
+                    for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][li];
                 }
             }
             // phase B: residual + 1x12 row (closed forms of SURVEY §8a), rows through LDS into the MFMA
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
-                const bool valid = i < N;
+                const bool valid = i < hi;
                 const int i_first = j0 + jj * nthr + wave * 64;        // this wavefront's 64 consecutive points
-                const int i_last = (i_first + 63 < N) ? i_first + 63 : N - 1;
-                const int b_lo = edsc::uniform_int(block_of(i_first < N ? i_first : 0, ne, nb));
+                const int i_last = (i_first + 63 < hi) ? i_first + 63 : hi - 1;
+                const int b_lo = edsc::uniform_int(block_of(i_first < hi ? i_first : 0, ne, nb));
                 const int b_hi = edsc::uniform_int(block_of(i_last > 0 ? i_last : 0, ne, nb));
                 int myb = b_lo;
                 float inv_n, gv[6];
@@ -193,9 +212,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 float x[13];
                 float* __restrict__ st7 = A.J + base + (valid ? i : 0);      // NC stash: planes 0..5 J', plane 6 E
                 if (MODE != 2) {
-                    if (miss[jj] && i < CAP) {
+                    if (miss[jj] && i - lo < CAP) {
 #pragma unroll
-                        for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[jj][t];
+                        for (int t = 0; t < NTAP; ++t) s_patch[t][i - lo] = tap[jj][t];
                     }
                     float E, Er, Ec;
                     if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     }
                     if (valid) A.mhat[base + i] = x[12];              // candidate residual
                 }
-                if (i_first < N) {
+                if (i_first < hi) {
                     for (int b = b_lo; b <= b_hi; ++b) {
                         if (b != cb) {
                             if (cb >= 0) flush(C + C2, cb);
@@ -283,6 +302,50 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         }
         EDS12_STAMP(0);
         __syncthreads();
+        if (TEAM > 1) {
+            // every thread publishes "its" entries of this member's sums, then collects the same entries of all members and leaves
+            // their total (added in member order: identical on every member) in place
+            const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
+            unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * ((size_t)TEAM * EDS_TEAM12_GRANULES);
+            const int nval = nb * EDS_TEAM12_VALUES;
+            auto entry = [&](int e) -> double* {
+                const int b = e / EDS_TEAM12_VALUES, r = e - b * EDS_TEAM12_VALUES;
+                return r == 0 ? &sums.s[b] : (r <= 144 ? &sums.H[b][r - 1] : &sums.g[b][r - 145]);
+            };
+            for (int e = tid; e < nval; e += nthr) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(*entry(e));
+                unsigned long long* g = mb + (size_t)member * EDS_TEAM12_GRANULES + 2 * e;
+                __hip_atomic_store(g, ((unsigned long long)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(g + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            for (int e = tid; e < nval; e += nthr) {
+                double tot = 0.0;
+#pragma unroll
+                for (int m = 0; m < TEAM; ++m) {
+                    unsigned half[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const unsigned long long* g = mb + (size_t)m * EDS_TEAM12_GRANULES + 2 * e + hh;
+                        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((unsigned)(v >> 32) != tag) {
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        half[hh] = (unsigned)v;
+                    }
+                    tot += __longlong_as_double((long long)(((unsigned long long)half[1] << 32) | half[0]));
+                }
+                *entry(e) = tot;
+            }
+            ++pass_no;
+            __syncthreads();
+            if (s_timeout) {                    // a member never showed up: report it, the host solves the range again without teams
+                if (tid == 0) { sv.termination = edss::TERM_FAILURE; sv.num_unsuccessful = -2; }
+                break;
+            }
+        }
         EDS12_STAMP(1);
         if (wave == 0) {                        // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
             const int mode = edsc::coop12_decide(sv, sums, work, s_pose, lane);          // linearisation if it was accepted,
@@ -326,7 +389,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         ++st_n;
 #endif
         if (s_accept) {                         // the candidate became the accepted point: its residuals are the ones to keep
-            for (int i = tid; i < N; i += nthr) A.r[base + i] = A.mhat[base + i];      // each thread copies what it wrote itself
+            for (int i = lo + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];    // each thread copies what it wrote itself
         }
         if (s_state == 2) break;
     }
@@ -339,6 +402,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }
 #endif
+    if (TEAM > 1 && member != 0) return;        // every member holds the same result; member 0 reports it
     if (tid == 0) {
         EdsFused12Out& O = out[slot];
         const bool ok = sv.termination != edss::TERM_FAILURE;
@@ -347,7 +411,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         for (int i = 0; i < 6; ++i) O.v[i] = ok ? sv.best_v[i] : sv.v[i];
         O.initial_cost = sv.initial_cost; O.final_cost = sv.minimum_cost;
         O.termination = sv.termination; O.num_successful = sv.num_successful; O.num_unsuccessful = sv.num_unsuccessful;
-        O.failed = ok ? 0 : 1;
+        O.failed = ok ? 0 : (TEAM > 1 && sv.num_unsuccessful == -2 ? 2 : 1);     // 2: team timeout
     }
 }
 
@@ -382,13 +446,39 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         else if (std::strcmp(e, "paired") == 0) wide = false;
     }
     const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
+    // Teams (eds_fused.hip): K CUs per alignment while the launch leaves most of the chip idle — the plain residual only
+    int maxN = 0;
+    for (int s = first; s < first + count; ++s) maxN = std::max(maxN, h->slots[s].N);
+    int team = 1;
+    if (wide && !h->cfg.nc && !fb.team_disabled && maxN > 512 && count <= EDS_TEAM12_SLOTS) team = (count <= 64 && maxN > 1024) ? 4 : 2;
+    if (const char* ev = getenv("EDS_REF12_TEAM")) {                  // tuning knob: 1 | 2 | 4
+        const int v = atoi(ev);
+        if (v == 1 || ((v == 2 || v == 4) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS)) team = v;
+    }
+    if (team > 1) {
+        if (!fb.d_mail12) {
+            if (hipMalloc((void**)&fb.d_mail12, EDS_TEAM12_MAIL_BYTES) != hipSuccess) team = 1;
+            else hipMemsetAsync(fb.d_mail12, 0, EDS_TEAM12_MAIL_BYTES, h->st);
+        }
+    }
+    if (team > 1) {
+        if (++fb.epoch >= (1u << 24)) {
+            hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
+            hipMemsetAsync(fb.d_mail12, 0, EDS_TEAM12_MAIL_BYTES, h->st);
+            fb.epoch = 1;
+        }
+        hipMemsetAsync(fb.d_ticket, 0, sizeof(int), h->st);
+    }
+    fb.pending_team = team; fb.pending_level = level;
     hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH12_(S, T, C, NCM)                                                                                               \
-    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM>), dim3(count), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
+#define EDS_LAUNCH12_(S, T, C, NCM, K)                                                                                                \
+    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K>), dim3(count * K), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
-                       h->cfg.parameter_tolerance, nb)
-#define EDS_LAUNCH12(S, T, C) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true); else EDS_LAUNCH12_(S, T, C, false); } while (0)
-    if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1408); else EDS_LAUNCH12(1, 512, 1408); }
+                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, fb.epoch)
+#define EDS_LAUNCH12(S, T, C) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1); else EDS_LAUNCH12_(S, T, C, false, 1); } while (0)
+    if (team == 4) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 4); else EDS_LAUNCH12_(1, 512, 1408, false, 4); }
+    else if (team == 2) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 2); else EDS_LAUNCH12_(1, 512, 1408, false, 2); }
+    else if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1408); else EDS_LAUNCH12(1, 512, 1408); }
     else { if (bicubic) EDS_LAUNCH12(0, 256, 320); else EDS_LAUNCH12(1, 256, 320); }
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_
@@ -406,6 +496,20 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
 
 int eds_fused12_collect(eds_trk* h) {
     EdsFusedBuffers& fb = h->fused;
+    if (fb.pending_team > 1) {                        // a team whose members did not all become resident within the bound
+        bool timed_out = false;
+        for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) timed_out |= fb.h_out12[s].failed == 2;
+        if (timed_out) {
+            fb.team_disabled = true;
+            const int pf = fb.pending_first, pc = fb.pending_count;
+            fb.pending_count = 0;
+            int rc = eds_fused12_solve(h, fb.pending_level, pf, pc);
+            if (rc != EDS_OK) return rc;
+            hipError_t e = hipStreamSynchronize(h->st);
+            if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+            return eds_fused12_collect(h);
+        }
+    }
     const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     float dev_ms = 0.f;
     hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);

@@ -197,3 +197,32 @@ def test_team_launches_back_to_back_and_in_sub_ranges(gpu, capi, synth, po, monk
             assert po.se3_distance(tab[b, 0:3], tab[b, 3:7], refs[b]["p"], refs[b]["q"]) <= TOL_POSE, (rep, b)
             assert np.array_equal(h.trace(b)["accepted"], refs[b]["accepted"])
     h.close()
+
+
+@pytest.mark.parametrize("team", [2, 4])
+def test_ref12_team_kernel_vs_oracle(gpu, capi, synth, po, monkeypatch, team):
+    """The reference problem with K CUs per alignment (eds_fused12_kernel TEAM = K: contiguous point slices, the per-block sums
+    exchanged through tagged granules, every member running the LM state machine on identical totals) against the oracle's
+    Ceres-LM restatement: same iteration / successful-step counts and termination, pose and velocity within tolerance."""
+    monkeypatch.setenv("EDS_REF12_TEAM", str(team))
+    als = [synth.make_alignment(7300 + b, H=240, W=320, N=n, start="ctor") for b, n in enumerate((600, 1024, 1500, 2000))]
+    for nb, loss, sampling in ((1, 0, 0), (4, 1, 0), (3, 2, 1)):
+        cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=nb, loss_type=loss,
+                                  loss_param=0.3, sampling=sampling)
+        h = capi.Handle(cfg, len(als), 2048, 240, 320)
+        for b, a in enumerate(als):
+            h.set_alignment(b, a)
+        h.optimize_batch(0, 0, len(als))
+        tab = h.results(0, len(als))
+        for b, a in enumerate(als):
+            ref = po.Oracle(a, num_blocks=nb, loss_type=loss, loss_param=0.3, max_num_iterations=10, sampling=sampling).solve_lm(a.p0, a.q0, a.v0)
+            info = h.info(b)
+            assert info["num_iterations"] == ref["num_iterations"] and info["num_successful_steps"] == ref["num_successful_steps"], (nb, b)
+            assert info["termination"] == ref["termination"]
+            assert po.se3_distance(tab[b, 0:3], tab[b, 3:7], ref["p"], ref["q"]) <= TOL_POSE
+            assert np.abs(tab[b, 7:13] - ref["v"]).max() <= 1e-4
+            assert tab[b, 13] == pytest.approx(ref["final_cost"], rel=1e-5)
+            r = h.residuals(b)
+            e = po.Oracle(a, num_blocks=nb, sampling=sampling).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
+            assert np.abs(r - e).max() <= 2e-5 * np.abs(e).max()
+        h.close()
