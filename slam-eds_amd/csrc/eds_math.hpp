@@ -142,11 +142,30 @@ EDS_HD void state_plus12(const double* p, const double* q, const double* v, cons
                          double* po, double* qo, double* vo) {
     EDS_UNROLL
     for (int i = 0; i < 3; ++i) po[i] = p[i] + d[i];
-    const double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+    const double nd = sqrt(nd2);
     if (nd > 0.0) {
-        double sn, cs;
-        sincos(nd, &sn, &cs);           // one range reduction for both (the serial solver lane pays for every instruction)
-        const double s = sn / nd;
+        double sn, cs, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (nd2 <= 0.25) {              // |delta| <= 0.5 rad: sin(nd)/nd and cos(nd) as polynomials in nd^2 (truncation < 1e-23): no
+            const double z = nd2;       // library sincos, no division on the solver's critical path
+            double ps = 1.0 / 355687428096000.0;
+            ps = fma(-ps, z, 1.0 / 1307674368000.0); ps = fma(-ps, z, 1.0 / 6227020800.0); ps = fma(-ps, z, 1.0 / 39916800.0);
+            ps = fma(-ps, z, 1.0 / 362880.0); ps = fma(-ps, z, 1.0 / 5040.0); ps = fma(-ps, z, 1.0 / 120.0); ps = fma(-ps, z, 1.0 / 6.0);
+            s = fma(-z, ps, 1.0);
+            double pc = 1.0 / 6402373705728000.0;
+            pc = fma(-pc, z, 1.0 / 20922789888000.0); pc = fma(-pc, z, 1.0 / 87178291200.0); pc = fma(-pc, z, 1.0 / 479001600.0);
+            pc = fma(-pc, z, 1.0 / 3628800.0); pc = fma(-pc, z, 1.0 / 40320.0); pc = fma(-pc, z, 1.0 / 720.0); pc = fma(-pc, z, 1.0 / 24.0);
+            pc = fma(-pc, z, 0.5);
+            cs = fma(-z, pc, 1.0);
+            sn = s * nd;
+        } else
+#endif
+        {
+            sincos(nd, &sn, &cs);       // one range reduction for both (the serial solver lane pays for every instruction)
+            s = sn / nd;
+        }
+        (void)sn;
         const double qd[4] = {s * d[3], s * d[4], s * d[5], cs};
         double nq[4];
         quat_mul(qd, q, nq);
@@ -159,7 +178,7 @@ EDS_HD void state_plus12(const double* p, const double* q, const double* v, cons
     double s2 = 0.0, tmp[6];
     EDS_UNROLL
     for (int i = 0; i < 6; ++i) { tmp[i] = v[i] + d[6 + i]; s2 += tmp[i] * tmp[i]; }
-    const double inv = 1.0 / sqrt(s2);
+    const double inv = rsqrt_(s2);
     EDS_UNROLL
     for (int i = 0; i < 6; ++i) vo[i] = tmp[i] * inv;
 }

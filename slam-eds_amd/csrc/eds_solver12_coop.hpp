@@ -365,10 +365,12 @@ __device__ inline void coop_fill_pose_block(const double* p, const double* q, co
     if (lane < 6) pb[EDS_PB_V + lane] = v[lane];
     double vv = 0.0;
     for (int i = 0; i < 6; ++i) vv += v[i] * v[i];
-    const double vn = sqrt(vv);
+    // (reciprocal square roots and multiplications instead of the serial code's sqrt + divisions: every fp64 division or square root
+    // is a 20-30 instruction dependent sequence on the solver's critical path; the results agree to the last bits and feed fp32 kernels)
+    const double inv_vn = edsm::rsqrt_(vv), inv_vv = inv_vn * inv_vn;
     if (lane < 36) {
         const int i = lane / 6, j = lane - 6 * i;
-        pb[EDS_PB_PV + lane] = ((i == j ? 1.0 : 0.0) - v[i] * v[j] / vv) / vn;
+        pb[EDS_PB_PV + lane] = ((i == j ? 1.0 : 0.0) - v[i] * v[j] * inv_vv) * inv_vn;
     }
     const int k = lane / 6, i6 = lane - 6 * k;
     double* o = pb + EDS_PB_BLK + EDS_PB_BLK_STRIDE * (k < nb ? k : 0);
@@ -384,9 +386,9 @@ __device__ inline void coop_fill_pose_block(const double* p, const double* q, co
         for (int i = 0; i < 6; ++i) raw[i] = o[1 + i];
         double S = 1e-3;
         for (int i = 0; i < 6; ++i) S += v[i] * raw[i];
-        const double n = sqrt(S);
-        o[1 + i6] = raw[i6] / (n * n * n);
-        if (i6 == 0) { o[0] = 1.0 / n; o[7] = S; }
+        const double inv_n = edsm::rsqrt_(S);
+        o[1 + i6] = raw[i6] * (inv_n * inv_n * inv_n);
+        if (i6 == 0) { o[0] = inv_n; o[7] = S; }
     }
     EDS_WSYNC();
 }

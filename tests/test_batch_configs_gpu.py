@@ -206,7 +206,9 @@ def test_ref12_team_kernel_vs_oracle(gpu, capi, synth, po, monkeypatch, team):
     Ceres-LM restatement: same iteration / successful-step counts and termination, pose and velocity within tolerance."""
     monkeypatch.setenv("EDS_REF12_TEAM", str(team))
     als = [synth.make_alignment(7300 + b, H=240, W=320, N=n, start="ctor") for b, n in enumerate((600, 1024, 1500, 2000))]
-    for nb, loss, sampling in ((1, 0, 0), (4, 1, 0), (3, 2, 1)):
+    # (bicubic only: from the identity start the projections sit on pixel centres, where the bilinear gradient is discontinuous and fp32 /
+    # fp64 trajectories part ways — tests/test_parity_gpu.py covers bilinear from a generic start)
+    for nb, loss, sampling in ((1, 0, 0), (4, 1, 0), (3, 2, 0)):
         cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=nb, loss_type=loss,
                                   loss_param=0.3, sampling=sampling)
         h = capi.Handle(cfg, len(als), 2048, 240, 320)
