@@ -45,7 +45,9 @@ typedef double acc4d __attribute__((ext_vector_type(4)));
 // TEAM = K > 1 (latency regime, see eds_fused.hip): K workgroups share one alignment; member m evaluates a contiguous slice of the
 // points, the members exchange their per-block sums (157 doubles per residual block) as tagged granules after every evaluation,
 // add them in member order, and all run the LM state machine on the identical totals.
-template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM>
+// QUAD (bicubic): the quad-cooperative gather of eds_device.hpp / eds_fused.hip — lane j of a quad loads row j of each of the quad's
+// four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane.
+template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
                                                               double loss_a, double ftol, double gtol, double ptol, int nb,
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     __shared__ int s_k, s_head, s_walk;
     __shared__ float s_stage[(NTHR / 64)][64 * 17];
     __shared__ int s_state, s_accept;
-    __shared__ float s_patch[NTAP][CAP];
+    __shared__ __attribute__((aligned(16))) float s_patch[NTAP][CAP];
+    static_assert(!QUAD || (SAMPLING == 0 && CAP % 4 == 0), "quad gather: bicubic, whole quads cached");
     __shared__ int s_cell[CAP];
     __shared__ double s_G[EDS_DEV_MAX_BLOCKS * 36];
     __shared__ double s_nc[EDS_DEV_MAX_BLOCKS][8];    // NC residual: per block 1/||E||, then sum_j E_j J'_j / ||E||^3
@@ -158,6 +161,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             PointGeom pg[2];
             float tap[2][NTAP];
             bool miss[2];
+            int org[2];                                                 // QUAD: packed patch origin | miss flag, per point
+            float4 ra[2][4], rb[2][4];                                  // QUAD: this lane's row of the quad's four patches
+            const int jr = lane & 3;
+            const float* __restrict__ tiles = A.frame + (size_t)slot * A.Hp * A.Wp;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
@@ -176,6 +183,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const bool cached = li < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
                 miss[jj] = !(cached && s_cell[li] == key);
+                if (QUAD) {
+                    if (miss[jj] && cached) s_cell[li] = key;
+                    org[jj] = pack_origin(frame, pg[jj].r0, pg[jj].c0) | (miss[jj] ? (int)0x80000000 : 0);
+                    continue;
+                }
                 if (miss[jj]) {
                     if (SAMPLING == 0) load_patch16(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[16]>(tap[jj]));
                     else load_patch4(frame, pg[jj].r0, pg[jj].c0, reinterpret_cast<float(&)[4]>(tap[jj]));
@@ -183,6 +195,18 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 } else {
 #pragma unroll
                     for (int t = 0; t < NTAP; ++t) tap[jj][t] = s_patch[t][li];
+                }
+            }
+            if (QUAD && MODE != 2) {                                    // the packed origins go round the quad; every lane puts its ROW of
+#pragma unroll                                                          // each missing patch in flight
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int o0 = quad_bcast_i<0>(org[jj]), o1 = quad_bcast_i<1>(org[jj]), o2 = quad_bcast_i<2>(org[jj]), o3 = quad_bcast_i<3>(org[jj]);
+                    const int oq[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ra[jj][q] = dont_care4(); rb[jj][q] = dont_care4();
+                        if (oq[q] < 0) load_patch_row(tiles, frame.TW, oq[q] & 0x7fffffff, jr, ra[jj][q], rb[jj][q]);
+                    }
                 }
             }
             // phase B: residual + 1x12 row (closed forms of SURVEY §8a), rows through LDS into the MFMA
@@ -212,13 +236,43 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 float x[13];
                 float* __restrict__ st7 = A.J + base + (valid ? i : 0);      // NC stash: planes 0..5 J', plane 6 E
                 if (MODE != 2) {
+                    float E, Er, Ec;
+                    if (QUAD) {
+                        // branch-free: the cached row and the gathered row are both formed, a bit mask picks one; the row goes (back) to
+                        // the cache ([point][row] units of 16 bytes, XOR-swizzled by the quad index: patch_unit), its spline runs here,
+                        // the transposes return the four row results to the lane that owns the point
+                        const int qli = (i & ~3) - lo;                   // first point of this quad, local index (quads are cached whole)
+                        const bool qcached = qli < CAP;
+                        float* __restrict__ cache = &s_patch[0][0];
+                        const int o0 = quad_bcast_i<0>(org[jj]), o1 = quad_bcast_i<1>(org[jj]), o2 = quad_bcast_i<2>(org[jj]), o3 = quad_bcast_i<3>(org[jj]);
+                        const int oq[4] = {o0, o1, o2, o3};
+                        const float x0 = quad_bcast_f<0>(pg[jj].ax), x1 = quad_bcast_f<1>(pg[jj].ax), x2 = quad_bcast_f<2>(pg[jj].ax), x3 = quad_bcast_f<3>(pg[jj].ax);
+                        const float xq[4] = {x0, x1, x2, x3};
+                        float f[4], d[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float* unit = cache + 4 * patch_unit(qcached ? qli + q : q, jr);
+                            const float4 c = *reinterpret_cast<const float4*>(unit);
+                            float t[4];
+                            shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
+                            const int m = oq[q] >> 31;               // all ones: gathered this pass
+                            t[0] = bit_select(m, t[0], c.x); t[1] = bit_select(m, t[1], c.y); t[2] = bit_select(m, t[2], c.z); t[3] = bit_select(m, t[3], c.w);
+                            if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
+                            hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
+                        }
+                        quad_transpose(f, lane);
+                        quad_transpose(d, lane);
+                        float unused;
+                        hermite(f[0], f[1], f[2], f[3], pg[jj].ay, E, Er);
+                        hermite(d[0], d[1], d[2], d[3], pg[jj].ay, Ec, unused);
+                    } else {
                     if (miss[jj] && i - lo < CAP) {
 #pragma unroll
                         for (int t = 0; t < NTAP; ++t) s_patch[t][i - lo] = tap[jj][t];
                     }
-                    float E, Er, Ec;
                     if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
                     else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
+                    }
                     PointProj pp;
                     finish_point(ps, pg[jj], E, Er, Ec, pp);
                     const float wp = MODE == 1 ? (valid ? 1.0f : 0.0f) : w;  // NC: pose columns un-weighted until the norm is known
@@ -471,15 +525,18 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     }
     fb.pending_team = team; fb.pending_level = level;
     hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH12_(S, T, C, NCM, K)                                                                                                \
-    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K>), dim3(count * K), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
+#define EDS_LAUNCH12_(S, T, C, NCM, K, Q)                                                                                             \
+    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
                        h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, fb.epoch)
-#define EDS_LAUNCH12(S, T, C) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1); else EDS_LAUNCH12_(S, T, C, false, 1); } while (0)
-    if (team == 4) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 4); else EDS_LAUNCH12_(1, 512, 1408, false, 4); }
-    else if (team == 2) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 2); else EDS_LAUNCH12_(1, 512, 1408, false, 2); }
-    else if (wide) { if (bicubic) EDS_LAUNCH12(0, 512, 1408); else EDS_LAUNCH12(1, 512, 1408); }
-    else { if (bicubic) EDS_LAUNCH12(0, 256, 320); else EDS_LAUNCH12(1, 256, 320); }
+#define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)
+    // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
+    bool quad = bicubic && count >= 1024;          // measured: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below
+    if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
+    if (team == 4) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
+    else if (team == 2) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 2, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 2, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 2, 0); }
+    else if (wide) { if (bicubic) { if (quad) EDS_LAUNCH12(0, 512, 1408, 1); else EDS_LAUNCH12(0, 512, 1408, 0); } else EDS_LAUNCH12(1, 512, 1408, 0); }
+    else { if (bicubic) { if (quad) EDS_LAUNCH12(0, 256, 320, 1); else EDS_LAUNCH12(0, 256, 320, 0); } else EDS_LAUNCH12(1, 256, 320, 0); }
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_
     hipEventRecord(h->ev1, h->st);
