@@ -242,6 +242,34 @@ int eds_trk_build_keyframe(eds_trk* h, int slot, int img_type, const void* img, 
 int eds_trk_get_keyframe_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp,
                                 double* weights);
 
+/* ---- coarse-to-fine tracking on an image pyramid (BASELINE.json configs[3]) ------------------------------- */
+/* An extension patterned on the DSO-derived coarse tracker the reference carries: levels by 2x2 box averaging (reference
+ * src/tracking/HessianBlocks.cpp:173-176), level intrinsics fx_l = fx_{l-1} / 2, cx_l = (cx_0 + 0.5) / 2^l - 0.5
+ * (src/tracking/CoarseTracker.cpp:103-111), coarsest level first with the pose carried down (CoarseTracker.cpp:545-664).  One
+ * handle holds `levels` frame sizes H >> l x W >> l and one point set per level (max_points[l] entries at most); the event frame
+ * is handed over (or built from events) once, at level 0, and the coarser frames are made on the device. */
+typedef struct eds_pyr eds_pyr;
+int  eds_pyr_create(const eds_trk_cfg* cfg, int levels, const int* max_points, int H, int W, eds_pyr** out);
+void eds_pyr_destroy(eds_pyr* p);
+int  eds_pyr_set_config(eds_pyr* p, const eds_trk_cfg* cfg);
+/* K[4] = fx, fy, cx, cy of `level` from the level-0 intrinsics (CoarseTracker.cpp:103-111) */
+int  eds_pyr_level_intrinsics(int level, double fx0, double fy0, double cx0, double cy0, double K[4]);
+/* the points tracked at `level` (arrays as eds_trk_set_keyframe; normalised coordinates do not depend on the level);
+ * intrinsics are those of LEVEL 0 */
+int  eds_pyr_set_keyframe(eds_pyr* p, int level, int N, const double* norm_xy, const double* grad_xy, const double* idp,
+                          const double* w, double fx0, double fy0, double cx0, double cy0);
+/* level-0 frame (H x W row-major doubles, as eds_trk_set_event_frame) or events (as eds_trk_build_event_frame, level 0 of
+ * EventFrame::create); levels 1 .. L-1 follow on the device */
+int  eds_pyr_set_event_frame(eds_pyr* p, const double* frame);
+int  eds_pyr_build_event_frame(eds_pyr* p, int n_events, const uint16_t* x, const uint16_t* y, const uint8_t* polarity,
+                               double blur_sigma, int use_exp_weights, double* norm_out);
+int  eds_pyr_level_size(const eds_pyr* p, int level, int* H, int* W);
+int  eds_pyr_get_level_frame(eds_pyr* p, int level, double* frame);     /* (H >> level) x (W >> level) doubles */
+/* One call: levels L-1 .. 0, `max_num_iterations[level]` iterations each, (p, q, v) in/out and carried from level to level;
+ * infos (optional) receives one eds_trk_info per level.  Returns the status of the finest level. */
+int  eds_pyr_optimize(eds_pyr* p, double pose_p[3], double q_xyzw[4], double v[6], eds_trk_info* infos);
+int  eds_pyr_get_residuals(eds_pyr* p, int level, double* r);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
 int eds_trk_timer_start(eds_trk* h);

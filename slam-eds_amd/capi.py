@@ -40,6 +40,9 @@ EXPORTS = (
     "eds_trk_loss_param_batch", "eds_trk_update_points",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
+    "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
+    "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
+    "eds_pyr_get_residuals",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -141,6 +144,19 @@ def lib():
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.eds_pyr_create.argtypes = [C.POINTER(Cfg), C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.eds_pyr_destroy.argtypes = [C.c_void_p]
+        L.eds_pyr_destroy.restype = None
+        L.eds_pyr_set_config.argtypes = [C.c_void_p, C.POINTER(Cfg)]
+        L.eds_pyr_level_intrinsics.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _dp]
+        L.eds_pyr_set_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.eds_pyr_set_event_frame.argtypes = [C.c_void_p, _dp]
+        L.eds_pyr_build_event_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16), C.POINTER(C.c_uint8),
+                                                C.c_double, C.c_int, _dp]
+        L.eds_pyr_level_size.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
+        L.eds_pyr_get_level_frame.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.eds_pyr_optimize.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(Info)]
+        L.eds_pyr_get_residuals.argtypes = [C.c_void_p, C.c_int, _dp]
         if L.eds_trk_cfg_size() != C.sizeof(Cfg) or L.eds_trk_info_size() != C.sizeof(Info):
             raise EdsError(ERR_INVALID, "ctypes struct layout disagrees with include/eds_hip.h")
         _lib = L
@@ -405,6 +421,80 @@ class Handle:
         ms = C.c_float(0.0)
         _check(lib().eds_trk_bench_eval(self._h, first, count, ncols, int(with_reduction), reps, C.byref(ms)))
         return ms.value
+
+
+class Pyramid:
+    """RAII wrapper of ``eds_pyr*``: coarse-to-fine tracking of one alignment on an image pyramid (BASELINE.json configs[3])."""
+
+    def __init__(self, cfg: Cfg, max_points, H: int, W: int):
+        self.levels = len(max_points)
+        self.H, self.W = int(H), int(W)
+        mp = np.ascontiguousarray(max_points, dtype=np.int32)
+        self._h = C.c_void_p()
+        self._N = [0] * self.levels
+        _check(lib().eds_pyr_create(C.byref(cfg), self.levels, mp.ctypes.data_as(_ip), self.H, self.W, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().eds_pyr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_config(self, cfg: Cfg):
+        _check(lib().eds_pyr_set_config(self._h, C.byref(cfg)))
+
+    @staticmethod
+    def level_intrinsics(level, fx, fy, cx, cy):
+        K = np.zeros(4)
+        _check(lib().eds_pyr_level_intrinsics(int(level), fx, fy, cx, cy, _p(K)))
+        return K
+
+    def set_keyframe(self, level, norm_coord, grad, idp, weights, fx, fy, cx, cy):
+        nc, g, d, w = _f64(norm_coord), _f64(grad), _f64(idp), _f64(weights)
+        self._N[level] = int(d.shape[0])
+        _check(lib().eds_pyr_set_keyframe(self._h, int(level), self._N[level], _p(nc), _p(g), _p(d), _p(w), fx, fy, cx, cy))
+
+    def set_event_frame(self, frame):
+        f = _f64(frame)
+        assert f.size == self.H * self.W
+        _check(lib().eds_pyr_set_event_frame(self._h, _p(f)))
+
+    def build_event_frame(self, x, y, polarity, blur_sigma=0.5, use_exp_weights=True):
+        x = np.ascontiguousarray(x, dtype=np.uint16); y = np.ascontiguousarray(y, dtype=np.uint16)
+        pol = np.ascontiguousarray(polarity, dtype=np.uint8)
+        norm = C.c_double(0.0)
+        _check(lib().eds_pyr_build_event_frame(self._h, int(x.shape[0]), x.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               y.ctypes.data_as(C.POINTER(C.c_uint16)), pol.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               float(blur_sigma), int(bool(use_exp_weights)), C.cast(C.byref(norm), _dp)))
+        return norm.value
+
+    def level_size(self, level):
+        h, w = C.c_int32(0), C.c_int32(0)
+        _check(lib().eds_pyr_level_size(self._h, int(level), C.byref(h), C.byref(w)))
+        return h.value, w.value
+
+    def level_frame(self, level):
+        h, w = self.level_size(level)
+        out = np.zeros((h, w))
+        _check(lib().eds_pyr_get_level_frame(self._h, int(level), _p(out)))
+        return out
+
+    def optimize(self, p, q, v):
+        """One call, coarsest level first.  Returns (p, q, v, [info per level, finest first])."""
+        p, q, v = _f64(p).copy(), _f64(q).copy(), _f64(v).copy()
+        infos = (Info * self.levels)()
+        _check(lib().eds_pyr_optimize(self._h, _p(p), _p(q), _p(v), infos))
+        return p, q, v, [infos[l].as_dict() for l in range(self.levels)]
+
+    def residuals(self, level):
+        r = np.zeros(self._N[level])
+        _check(lib().eds_pyr_get_residuals(self._h, int(level), _p(r)))
+        return r
 
 
 def device_count() -> int:
