@@ -154,6 +154,17 @@ int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy);
  * the frame was divided by (EventFrame::norm[level]). */
 int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y,
                               const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norm_out);
+/* EventFrame::create as a whole (EventFrame.cpp:302-389): ALL `num_levels` frames of one event slice from a single vote, into slots
+ * first_slot .. first_slot + num_levels - 1 (level i in slot first_slot + i; EventFrame::event_frame[i], norms[i] = EventFrame::norm[i]).
+ * sensor_H x sensor_W is the size the events and the undistortion LUT live in; when it differs from the handle's H x W (out_scale != 1)
+ * the brightness image is resized the way the reference's call does it (EventFrame.cpp:342-346: `cv::resize(img, img, out_size,
+ * cv::INTER_CUBIC)` passes INTER_CUBIC in the `fx` position, so OpenCV interpolates with its default INTER_LINEAR, and with its 2x2
+ * block average when both scales are exactly 2).  sensor_H, sensor_W <= 0: the handle's size. */
+int eds_trk_build_event_frames(eds_trk* h, int first_slot, int num_levels, int n_events, const uint16_t* x, const uint16_t* y,
+                               const uint8_t* polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights,
+                               double* norms);
+/* The forward LUT at the sensor's size when that is not the handle's (out_scale != 1). */
+int eds_trk_set_undistort_map_sized(eds_trk* h, const float* mapx, const float* mapy, int sensor_H, int sensor_W);
 /* Reads slot `slot`'s frame back as H*W row-major doubles (whatever set_event_frame* / build_event_frame stored). */
 int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame);
 

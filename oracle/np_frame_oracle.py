@@ -79,3 +79,57 @@ def event_frame(x, y, polarity, H, W, mapx=None, mapy=None, level=0, sigma=0.5, 
         img = morph_level(img, level)
     norm = np.linalg.norm(img)                                                    # :359-364 cv::norm
     return img / norm, norm
+
+
+def resize_cv_default(img, H, W):
+    """What ``cv::resize(img, img, cv::Size(W, H), cv::INTER_CUBIC)`` does AS THE REFERENCE WRITES IT (EventFrame.cpp:345,
+    KeyFrame.cpp:355): the fourth positional parameter of cv::resize is ``fx``, so the interpolation stays at its default
+    INTER_LINEAR — and OpenCV's resize() replaces INTER_LINEAR by the 2x2 block average of its INTER_AREA fast path when both
+    scales are exactly 2.  Published OpenCV behaviour (modules/imgproc/src/resize.cpp), restated for CV_64F images: source
+    coordinate ``fx = float((dx + 0.5) * scale - 0.5)``, ``sx = floor(fx)``, fraction and both weights in fp32, taps clamped to
+    the image; horizontal pass, then vertical pass, in fp64.  OpenCV is absent from this image: unpinned."""
+    img = np.asarray(img, dtype=np.float64)
+    sH, sW = img.shape
+    if sH == 2 * H and sW == 2 * W:
+        a, b = img[0::2, 0::2], img[0::2, 1::2]
+        c, d = img[1::2, 0::2], img[1::2, 1::2]
+        return ((((0.0 + a) + b) + c) + d) * 0.25
+
+    def coords(n_dst, n_src):
+        scale = n_src / n_dst
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        f[lo] = 0.0; s[lo] = 0
+        hi = s >= n_src - 1
+        f[hi] = 0.0; s[hi] = n_src - 1
+        return s, np.minimum(s + 1, n_src - 1), (np.float32(1.0) - f).astype(np.float64), f.astype(np.float64)
+
+    x0, x1, a0, a1 = coords(W, sW)
+    y0, y1, b0, b1 = coords(H, sH)
+    h0 = img[y0][:, x0] * a0[None, :] + img[y0][:, x1] * a1[None, :]
+    h1 = img[y1][:, x0] * a0[None, :] + img[y1][:, x1] * a1[None, :]
+    return h0 * b0[:, None] + h1 * b1[:, None]
+
+
+def event_frames(x, y, polarity, sensor_H, sensor_W, H, W, num_levels, mapx=None, mapy=None, sigma=0.5, use_exp_weights=True):
+    """EventFrame::create as a whole (EventFrame.cpp:302-389): the `num_levels` normalised frames of one event slice and their
+    norms; events and LUT at the sensor's size, frames at H x W (resized when out_scale != 1, :342-346)."""
+    x = np.asarray(x, dtype=np.int64)
+    y = np.asarray(y, dtype=np.int64)
+    if mapx is not None:
+        ux = np.asarray(mapx, dtype=np.float32)[y, x].astype(np.float64)
+        uy = np.asarray(mapy, dtype=np.float32)[y, x].astype(np.float64)
+    else:
+        ux, uy = x.astype(np.float64), y.astype(np.float64)
+    pol = np.where(np.asarray(polarity) != 0, 1.0, -1.0)
+    img = draw_values_points(ux, uy, pol, sensor_H, sensor_W, sigma, use_exp_weights)     # :339
+    if (sensor_H, sensor_W) != (H, W):
+        img = resize_cv_default(img, H, W)                                                # :342-346
+    frames, norms = [], []
+    for i in range(num_levels):                                                           # :348-357
+        lv = img if i == 0 else morph_level(img, i)
+        n = np.linalg.norm(lv)
+        frames.append(lv / n); norms.append(n)
+    return frames, norms

@@ -33,7 +33,8 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
-    "eds_trk_set_undistort_map", "eds_trk_build_event_frame", "eds_trk_get_event_frame",
+    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames",
+    "eds_trk_get_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
@@ -123,6 +124,9 @@ def lib():
         L.eds_trk_build_event_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                 C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_get_event_frame.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.eds_trk_set_undistort_map_sized.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_int]
+        L.eds_trk_build_event_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                                 C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_set_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_results.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -271,6 +275,24 @@ class Handle:
                                                int(level), float(blur_sigma), int(bool(use_exp_weights)),
                                                C.cast(C.byref(norm), _dp)))
         return norm.value
+
+    def build_event_frames(self, first_slot, num_levels, x, y, polarity, sensor_size=None, blur_sigma=0.5, use_exp_weights=True):
+        """All `num_levels` frames of one event slice from a single vote (EventFrame::create), level i into slot first_slot + i;
+        sensor_size = (H, W) of the events / LUT when it differs from the handle's frame size (out_scale != 1).  Returns the norms."""
+        x = np.ascontiguousarray(x, dtype=np.uint16); y = np.ascontiguousarray(y, dtype=np.uint16)
+        pol = np.ascontiguousarray(polarity, dtype=np.uint8)
+        sH, sW = (0, 0) if sensor_size is None else sensor_size
+        norms = np.zeros(num_levels)
+        _check(lib().eds_trk_build_event_frames(self._h, int(first_slot), int(num_levels), int(x.shape[0]),
+                                                x.ctypes.data_as(C.POINTER(C.c_uint16)), y.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                pol.ctypes.data_as(C.POINTER(C.c_uint8)), int(sH), int(sW), float(blur_sigma),
+                                                int(bool(use_exp_weights)), _p(norms)))
+        return norms
+
+    def set_undistort_map_sized(self, mapx, mapy, sensor_size):
+        mx = np.ascontiguousarray(mapx, dtype=np.float32); my = np.ascontiguousarray(mapy, dtype=np.float32)
+        assert mx.shape == tuple(sensor_size) and my.shape == tuple(sensor_size)
+        _check(lib().eds_trk_set_undistort_map_sized(self._h, mx.ctypes.data_as(_fp), my.ctypes.data_as(_fp), int(sensor_size[0]), int(sensor_size[1])))
 
     def get_event_frame(self, slot):
         fr = np.zeros((self.H, self.W))

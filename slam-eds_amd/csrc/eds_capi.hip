@@ -593,7 +593,15 @@ int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy) 
     if (!h) return fail(EDS_ERR_INVALID, "null handle");
     if ((mapx == nullptr) != (mapy == nullptr)) return fail(EDS_ERR_INVALID, "mapx and mapy must both be given or both be NULL");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    return eds_frame_set_map(h, mapx, mapy);
+    return eds_frame_set_map(h, mapx, mapy, h->H, h->W);
+}
+
+int eds_trk_set_undistort_map_sized(eds_trk* h, const float* mapx, const float* mapy, int sensor_H, int sensor_W) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if ((mapx == nullptr) != (mapy == nullptr)) return fail(EDS_ERR_INVALID, "mapx and mapy must both be given or both be NULL");
+    if (mapx && (sensor_H < 1 || sensor_W < 1)) return fail(EDS_ERR_INVALID, "bad sensor size");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_frame_set_map(h, mapx, mapy, sensor_H, sensor_W);
 }
 
 int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y, const uint8_t* polarity,
@@ -603,7 +611,20 @@ int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t
     if (n_events < 0 || level < 0 || level > 16) return fail(EDS_ERR_INVALID, "bad event count or level");
     if (n_events > 0 && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    return eds_frame_build(h, slot, n_events, x, y, polarity, level, blur_sigma, use_exp_weights, norm_out);
+    return eds_frame_build_levels(h, slot, level, 1, n_events, x, y, polarity, h->H, h->W, blur_sigma, use_exp_weights, norm_out);
+}
+
+int eds_trk_build_event_frames(eds_trk* h, int first_slot, int num_levels, int n_events, const uint16_t* x, const uint16_t* y,
+                               const uint8_t* polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights, double* norms) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (num_levels < 1 || num_levels > EDS_MAX_LEVELS) return fail(EDS_ERR_INVALID, "num_levels out of range");
+    if (first_slot < 0 || first_slot + num_levels > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds (one slot per level)");
+    if (n_events < 0) return fail(EDS_ERR_INVALID, "bad event count");
+    if (n_events > 0 && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
+    if (sensor_H <= 0 || sensor_W <= 0) { sensor_H = h->H; sensor_W = h->W; }
+    if (sensor_H < 2 || sensor_W < 2) return fail(EDS_ERR_INVALID, "bad sensor size");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_frame_build_levels(h, first_slot, 0, num_levels, n_events, x, y, polarity, sensor_H, sensor_W, blur_sigma, use_exp_weights, norms);
 }
 
 int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {

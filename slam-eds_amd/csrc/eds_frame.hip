@@ -11,6 +11,7 @@
 //   5. divide by the Frobenius norm (EventFrame.cpp:359-383) and store as fp32 in the handle's frame layout
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -57,91 +58,142 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
     return i;
 }
-// separable 3-tap Gaussian, row filter then column filter like cv::sepFilter2D
-__global__ void k_blur_rows(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= W) return;
-    const double* row = src + (size_t)r * W;
-    dst[(size_t)r * W + c] = k0 * row[reflect101(c - 1, W)] + k1 * row[c] + k0 * row[reflect101(c + 1, W)];
+// 3x3 Gaussian in ONE pass with the arithmetic of cv::sepFilter2D's two (row filter, then column filter): the three row-filtered
+// values a pixel's column filter needs are formed on the fly, each exactly as the row pass would round it
+__device__ __forceinline__ double blur_row_at(const double* __restrict__ row, int c, int W, double k0, double k1) {
+    return k0 * row[reflect101(c - 1, W)] + k1 * row[c] + k0 * row[reflect101(c + 1, W)];
 }
-__global__ void k_blur_cols(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1) {
+__global__ void k_blur3(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= W) return;
-    dst[(size_t)r * W + c] = k0 * src[(size_t)reflect101(r - 1, H) * W + c] + k1 * src[(size_t)r * W + c] +
-                             k0 * src[(size_t)reflect101(r + 1, H) * W + c];
+    const double a = blur_row_at(src + (size_t)reflect101(r - 1, H) * W, c, W, k0, k1);
+    const double b = blur_row_at(src + (size_t)r * W, c, W, k0, k1);
+    const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
+    dst[(size_t)r * W + c] = k0 * a + k1 * b + k0 * d;
 }
-// dilate + erode with a (2 rad + 1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue)
-__global__ void k_morph(const double* __restrict__ src, double* __restrict__ dst, int H, int W, int rad) {
+// cv::resize(src, dst, out_size, cv::INTER_CUBIC) as the reference WRITES it (EventFrame.cpp:345, KeyFrame.cpp:355): the fourth
+// positional parameter of cv::resize is `fx`, not the interpolation, so the call runs with the default INTER_LINEAR — and OpenCV
+// turns INTER_LINEAR into the 2x2 block average (INTER_AREA fast path) when both scales are exactly 2.  Published OpenCV behaviour
+// (imgproc/resize.cpp), restated: source coordinate fx = float((dx + 0.5) * scale - 0.5), sx = floor(fx), fractional part and
+// the two weights in fp32, clamped to the first / last pixel; horizontal pass then vertical pass, in fp64 for CV_64F images.
+__device__ __forceinline__ void resize_coord(int d, double scale, int n_src, int* s0, int* s1, double* w0, double* w1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.0f; s = 0; }
+    if (s >= n_src - 1) { f = 0.0f; s = n_src - 1; }
+    *s0 = s; *s1 = s + 1 < n_src ? s + 1 : n_src - 1;
+    *w0 = (double)(1.0f - f); *w1 = (double)f;
+}
+__global__ void k_resize(const double* __restrict__ src, int sH, int sW, double* __restrict__ dst, int H, int W) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= W) return;
-    double mx = -1.7976931348623157e308, mn = 1.7976931348623157e308;
-    for (int dr = -rad; dr <= rad; ++dr) {
-        const int rr = r + dr;
-        if (rr < 0 || rr >= H) continue;
-        for (int dc = -rad; dc <= rad; ++dc) {
-            const int cc = c + dc;
-            if (cc < 0 || cc >= W) continue;
-            const double v = src[(size_t)rr * W + cc];
-            mx = v > mx ? v : mx;
-            mn = v < mn ? v : mn;
-        }
+    if (sH == 2 * H && sW == 2 * W) {                // INTER_AREA fast path: sum of the block in raster order, times 1/4
+        const double* p = src + (size_t)(2 * r) * sW + 2 * c;
+        dst[(size_t)r * W + c] = (((0.0 + p[0]) + p[1]) + p[sW] + p[sW + 1]) * 0.25;
+        return;
     }
-    dst[(size_t)r * W + c] = mx + mn;
+    int x0, x1, y0, y1;
+    double a0, a1, b0, b1;
+    resize_coord(c, (double)sW / (double)W, sW, &x0, &x1, &a0, &a1);
+    resize_coord(r, (double)sH / (double)H, sH, &y0, &y1, &b0, &b1);
+    const double h0 = src[(size_t)y0 * sW + x0] * a0 + src[(size_t)y0 * sW + x1] * a1;
+    const double h1 = src[(size_t)y1 * sW + x0] * a0 + src[(size_t)y1 * sW + x1] * a1;
+    dst[(size_t)r * W + c] = h0 * b0 + h1 * b1;
 }
-__global__ void k_sumsq(const double* __restrict__ src, size_t n, double* __restrict__ out) {
-    double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += src[i] * src[i];
+// Levels of EventFrame::create from ONE brightness image (EventFrame.cpp:348-357): level 0 is the image, level i >= 1 its
+// dilation + erosion with a (2i+1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue).  blockIdx.z
+// selects the level (level0 + z); each level's image goes to its own plane and its sum of squares is accumulated on the way.
+__global__ void k_levels(const double* __restrict__ src, double* __restrict__ planes, double* __restrict__ sumsq, int H, int W, int level0) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, rad = level0 + (int)blockIdx.z;
+    double v = 0.0;
+    if (c < W) {
+        if (rad == 0) {
+            v = src[(size_t)r * W + c];
+        } else {
+            double mx = -1.7976931348623157e308, mn = 1.7976931348623157e308;
+            for (int dr = -rad; dr <= rad; ++dr) {
+                const int rr = r + dr;
+                if (rr < 0 || rr >= H) continue;
+                for (int dc = -rad; dc <= rad; ++dc) {
+                    const int cc = c + dc;
+                    if (cc < 0 || cc >= W) continue;
+                    const double t = src[(size_t)rr * W + cc];
+                    mx = t > mx ? t : mx;
+                    mn = t < mn ? t : mn;
+                }
+            }
+            v = mx + mn;
+        }
+        planes[(size_t)blockIdx.z * H * W + (size_t)r * W + c] = v;
+    }
+    double s = v * v;
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     __shared__ double sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) atomicAdd(&sumsq[blockIdx.z], sh[0] + sh[1] + sh[2] + sh[3]);
 }
-// frame / ||frame||_F -> fp32 in the handle's layout (padding and margin filled with the nearest border pixel)
-__global__ void k_store(const double* __restrict__ src, const double* __restrict__ sumsq, float* __restrict__ dst, int H, int W,
-                        int Hp, int Wp, int tiled, int normalise) {
+// level / ||level||_F -> fp32 in the handle's layout, one slot per level (padding and margin filled with the nearest border pixel)
+__global__ void k_store_levels(const double* __restrict__ planes, const double* __restrict__ sumsq, float* __restrict__ frames, int first_slot,
+                               int H, int W, int Hp, int Wp, int tiled, int normalise) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
     if (c >= Wp - EDS_FRAME_MARGIN) return;
-    const double inv = normalise ? 1.0 / sqrt(*sumsq) : 1.0;     // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
-    const double v = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
-    dst[eds_frame_index(r, c, Wp, tiled)] = (float)v;
+    const double inv = normalise ? 1.0 / sqrt(sumsq[blockIdx.z]) : 1.0;     // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
+    const double v = planes[(size_t)blockIdx.z * H * W + (size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
+    frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
 }
 
 }  // namespace
 
 void eds_frame_free(EdsFrameBuffers* fb) {
-    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex};     // d_ey, d_pol are slices of d_ex
+    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex, fb->d_planes};     // d_ey, d_pol are slices of d_ex
     for (void* p : d) if (p) hipFree(p);
     if (fb->h_events) hipHostFree(fb->h_events);
     *fb = EdsFrameBuffers();
 }
 
-int eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy) {
+int eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW) {
     EdsFrameBuffers& fb = h->frame_build;
-    const size_t n = (size_t)h->H * h->W;
     if (!mapx || !mapy) {               // identity LUT
         if (fb.d_mapx) { hipFree(fb.d_mapx); hipFree(fb.d_mapy); fb.d_mapx = fb.d_mapy = nullptr; }
+        fb.map_H = fb.map_W = 0;
         return EDS_OK;
     }
+    const size_t n = (size_t)mH * mW;
+    if (fb.d_mapx && (fb.map_H != mH || fb.map_W != mW)) { hipFree(fb.d_mapx); hipFree(fb.d_mapy); fb.d_mapx = fb.d_mapy = nullptr; }
     if (!fb.d_mapx) {
         if (hipMalloc((void**)&fb.d_mapx, n * 4) != hipSuccess || hipMalloc((void**)&fb.d_mapy, n * 4) != hipSuccess)
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(undistortion map)");
     }
+    fb.map_H = mH; fb.map_W = mW;
     if (hipMemcpy(fb.d_mapx, mapx, n * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(fb.d_mapy, mapy, n * 4, hipMemcpyHostToDevice) != hipSuccess)
         return eds_internal_fail(EDS_ERR_HIP, "hipMemcpy(undistortion map)");
     return EDS_OK;
 }
 
-int eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol, int level,
-                    double blur_sigma, int use_exp_weights, double* norm_out) {
+// Levels level0 .. level0 + nlevels - 1 of EventFrame::create into slots first_slot .. first_slot + nlevels - 1 from ONE vote:
+// events -> brightness image at the sensor's size (sH x sW) -> 3x3 Gaussian -> resize to the handle's H x W when they differ
+// (out_scale != 1) -> every level + its Frobenius norm in one launch -> normalise + store every level in one launch.
+int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
+                           const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out) {
     EdsFrameBuffers& fb = h->frame_build;
     const int H = h->H, W = h->W;
-    const size_t n = (size_t)H * W;
-    if (!fb.d_img) {
-        if (hipMalloc((void**)&fb.d_img, n * 8) != hipSuccess || hipMalloc((void**)&fb.d_tmp, n * 8) != hipSuccess ||
-            hipMalloc((void**)&fb.d_norm, 16) != hipSuccess)
+    const size_t n = (size_t)H * W, ns = (size_t)sH * sW;
+    if (fb.d_mapx && (fb.map_H != sH || fb.map_W != sW)) return eds_internal_fail(EDS_ERR_INVALID, "undistortion map and sensor size differ");
+    if (fb.img_elems < std::max(n, ns)) {
+        if (fb.d_img) { hipFree(fb.d_img); hipFree(fb.d_tmp); fb.d_img = fb.d_tmp = nullptr; }
+        fb.img_elems = std::max(n, ns);
+        if (hipMalloc((void**)&fb.d_img, fb.img_elems * 8) != hipSuccess || hipMalloc((void**)&fb.d_tmp, fb.img_elems * 8) != hipSuccess)
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(frame accumulation)");
+    }
+    if (!fb.d_norm && hipMalloc((void**)&fb.d_norm, 8 * EDS_MAX_LEVELS) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(norms)");
+    if (fb.plane_levels < nlevels) {
+        if (fb.d_planes) hipFree(fb.d_planes);
+        fb.d_planes = nullptr; fb.plane_levels = 0;
+        if (hipMalloc((void**)&fb.d_planes, n * 8 * nlevels) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(level planes)");
+        fb.plane_levels = nlevels;
     }
     if (n_events > fb.cap_events) {
         if (fb.d_ex) hipFree(fb.d_ex);
@@ -171,35 +223,36 @@ int eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, cons
             if (e == hipSuccess) e = hipMemcpyAsync(fb.d_pol, fb.h_events + cap * 4, (size_t)n_events, hipMemcpyHostToDevice, st);
         }
     }
-    if (e == hipSuccess) e = hipMemsetAsync(fb.d_img, 0, n * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 16, st);
+    if (e == hipSuccess) e = hipMemsetAsync(fb.d_img, 0, ns * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 8 * EDS_MAX_LEVELS, st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     if (n_events > 0)
         hipLaunchKernelGGL(k_vote, dim3((n_events + 255) / 256), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, fb.d_mapx, fb.d_mapy,
-                           n_events, H, W, use_exp_weights, fb.d_img);
-    const dim3 g2((W + 255) / 256, H), b2(256);
+                           n_events, sH, sW, use_exp_weights, fb.d_img);
+    const dim3 b2(256);
     double* cur = fb.d_img;
     double* other = fb.d_tmp;
     if (blur_sigma > 0.0) {             // cv::getGaussianKernel(3, sigma): exp(-x^2 / (2 sigma^2)), normalised
         const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), s = 1.0 + 2.0 * t;
-        hipLaunchKernelGGL(k_blur_rows, g2, b2, 0, st, cur, other, H, W, t / s, 1.0 / s);
-        hipLaunchKernelGGL(k_blur_cols, g2, b2, 0, st, other, cur, H, W, t / s, 1.0 / s);
+        hipLaunchKernelGGL(k_blur3, dim3((sW + 255) / 256, sH), b2, 0, st, cur, other, sH, sW, t / s, 1.0 / s);
+        std::swap(cur, other);
     }
-    if (level > 0) {
-        hipLaunchKernelGGL(k_morph, g2, b2, 0, st, cur, other, H, W, level);
-        double* t = cur; cur = other; other = t;
+    if (sH != H || sW != W) {           // out_scale != 1 (EventFrame.cpp:342-346)
+        hipLaunchKernelGGL(k_resize, dim3((W + 255) / 256, H), b2, 0, st, cur, sH, sW, other, H, W);
+        std::swap(cur, other);
     }
-    hipLaunchKernelGGL(k_sumsq, dim3(256), dim3(256), 0, st, cur, n, fb.d_norm);
-    const dim3 g3((h->Wp + 255) / 256, h->Hp);
-    hipLaunchKernelGGL(k_store, g3, b2, 0, st, cur, fb.d_norm, h->dframe + (size_t)slot * h->Hp * h->Wp, H, W, h->Hp, h->Wp, h->tiled,
-                       h->cfg.nc ? 0 : 1);
+    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, fb.d_norm, H, W, level0);
+    hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, nlevels), b2, 0, st, fb.d_planes, fb.d_norm, h->dframe, first_slot, H, W,
+                       h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    double ss = 0.0;
-    e = hipMemcpyAsync(&ss, fb.d_norm, 8, hipMemcpyDeviceToHost, st);
+    double ss[EDS_MAX_LEVELS];
+    e = hipMemcpyAsync(ss, fb.d_norm, 8 * nlevels, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    if (norm_out) *norm_out = std::sqrt(ss);
-    h->slots[slot].has_frame = true;
+    for (int i = 0; i < nlevels; ++i) {
+        if (norms_out) norms_out[i] = std::sqrt(ss[i]);
+        h->slots[first_slot + i].has_frame = true;
+    }
     return EDS_OK;
 }

@@ -74,17 +74,21 @@ void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFus
 
 // ---- event-frame construction on device (eds_frame.hip) ---------------------------------------------------
 struct EdsFrameBuffers {
-    float *d_mapx = nullptr, *d_mapy = nullptr;     // forward undistortion LUT (H x W), optional
+    float *d_mapx = nullptr, *d_mapy = nullptr;     // forward undistortion LUT (sensor size map_H x map_W), optional
+    int map_H = 0, map_W = 0;
     double *d_img = nullptr, *d_tmp = nullptr, *d_norm = nullptr;
+    size_t img_elems = 0;                           // capacity of d_img / d_tmp (max of sensor and frame size)
+    double* d_planes = nullptr;                     // the levels of one event frame, [plane_levels][H][W]
+    int plane_levels = 0;
     uint16_t *d_ex = nullptr, *d_ey = nullptr;     // slices of ONE device allocation [x | y | polarity]
     uint8_t* d_pol = nullptr;
     uint8_t* h_events = nullptr;                   // pinned staging of the same shape: one host-to-device copy per frame
     int cap_events = 0;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
-int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy);
-int  eds_frame_build(eds_trk* h, int slot, int n_events, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol, int level,
-                     double blur_sigma, int use_exp_weights, double* norm_out);
+int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
+int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
+                            const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out);
 
 // ---- loss scale and point maintenance on device (eds_points.hip) --------------------------------------------
 struct EdsPointBuffers {

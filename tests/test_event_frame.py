@@ -123,3 +123,49 @@ def test_build_event_frame_unnormalised_for_nc(gpu, capi):
     assert norm == pytest.approx(ref_norm, rel=1e-12)
     assert np.abs(got - ref * ref_norm).max() <= 1e-7 * np.abs(ref * ref_norm).max()
     h.close()
+
+
+def test_oracle_resize_as_the_reference_calls_it():
+    """cv::resize(img, img, out_size, cv::INTER_CUBIC) puts INTER_CUBIC in the `fx` slot: the interpolation is INTER_LINEAR
+    (pixel-centre aligned, taps clamped), and the 2x2 block mean when both scales are exactly 2."""
+    import np_frame_oracle as fo
+    rng = np.random.default_rng(0)
+    img = rng.standard_normal((12, 16))
+    half = fo.resize_cv_default(img, 6, 8)
+    assert np.allclose(half, img.reshape(6, 2, 8, 2).mean(axis=(1, 3)), rtol=0, atol=1e-15)
+    same = fo.resize_cv_default(img, 12, 16)
+    assert np.array_equal(same, img)                                    # scale 1: fx = dx exactly, weights (1, 0)
+    ramp = np.add.outer(np.arange(9.0) * 2.0, np.arange(12.0) * 3.0)   # a plane is reproduced away from the clamped border
+    r = fo.resize_cv_default(ramp, 6, 8)
+    yy = (np.arange(6) + 0.5) * 1.5 - 0.5; xx = (np.arange(8) + 0.5) * 1.5 - 0.5
+    inner = np.add.outer(yy * 2.0, xx * 3.0)
+    assert np.allclose(r[1:-1, 1:-1], inner[1:-1, 1:-1], rtol=0, atol=1e-5)      # fp32 coordinates: 1e-6-level weights
+    up = fo.resize_cv_default(img, 24, 32)
+    assert up.shape == (24, 32) and up[0, 0] == img[0, 0] and up[-1, -1] == img[-1, -1]     # clamped corners
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sensor,frame,levels", [((120, 160), (120, 160), 3), ((240, 320), (120, 160), 3), ((180, 240), (120, 160), 2),
+                                                 ((100, 150), (120, 160), 1), ((480, 640), (480, 640), 4)],
+                         ids=["same", "half", "x1.5", "up", "vga4"])
+def test_build_all_levels_from_one_vote(gpu, capi, sensor, frame, levels):
+    """eds_trk_build_event_frames: every level of EventFrame::create from ONE vote, out_scale != 1 included, against the oracle."""
+    import np_frame_oracle as fo
+    (sH, sW), (H, W) = sensor, frame
+    x, y, pol, mapx, mapy = make_events(sH + levels, 20000, sH, sW, distort=True)
+    h = capi.Handle(capi.default_config(), levels + 1, 64, H, W)
+    h.set_undistort_map_sized(mapx, mapy, (sH, sW))
+    norms = h.build_event_frames(1, levels, x, y, pol, sensor_size=(sH, sW))
+    ref_frames, ref_norms = fo.event_frames(x, y, pol, sH, sW, H, W, levels, mapx, mapy)
+    for i in range(levels):
+        assert norms[i] == pytest.approx(ref_norms[i], rel=1e-11)
+        got = h.get_event_frame(1 + i)
+        assert np.abs(got - ref_frames[i]).max() <= 1e-6 * np.abs(ref_frames[i]).max()     # stored as fp32
+    if sensor == frame:                                                  # the single-level entry point gives the same frames
+        for i in range(levels):
+            n1 = h.build_event_frame(0, x, y, pol, level=i)
+            assert n1 == pytest.approx(norms[i], rel=1e-12)
+            assert np.array_equal(h.get_event_frame(0), h.get_event_frame(1 + i))
+    with pytest.raises(capi.EdsError):
+        h.build_event_frames(1, levels + 1, x, y, pol, sensor_size=(sH, sW))               # one slot per level
+    h.close()
