@@ -248,6 +248,15 @@ void eds_kf_select_default(eds_kf_select* sel);
 int eds_trk_build_keyframe(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
                            const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy,
                            int* n_points);
+/* The same from the image as the camera driver hands it over: img_H x img_W pixels with `channels` interleaved channels (1 grey,
+ * 3 RGB; EDS_IMG_U8 / EDS_IMG_F32 — OpenCV's cvtColor takes no CV_64F colour image).  A size other than the handle's H x W is the
+ * reference's out_scale != 1: the image is resized first (KeyFrame.cpp:352-357; the call `cv::resize(img, img, out_size,
+ * cv::INTER_CUBIC)` passes INTER_CUBIC as `fx`, so OpenCV interpolates with INTER_LINEAR, and with the 2x2 block mean when both scales
+ * are exactly 2), then converted to grey (cv::cvtColor COLOR_RGB2GRAY, :361), each with OpenCV's arithmetic for the element type.
+ * fx, fy, cx, cy are the intrinsics of the RESIZED image (kf->K_ref). */
+int eds_trk_build_keyframe_image(eds_trk* h, int slot, int img_type, const void* img, int img_H, int img_W, int channels,
+                                 const eds_kf_select* sel, int n_depth, const double* depth_xy, const double* depth_idp,
+                                 double fx, double fy, double cx, double cy, int* n_points);
 /* The index-aligned vectors KeyFrame keeps (coord, norm_coord, grad, inv_depth, weights; KeyFrame.hpp:80-96) of the
  * keyframe eds_trk_build_keyframe built last; any pointer may be NULL. */
 int eds_trk_get_keyframe_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp,

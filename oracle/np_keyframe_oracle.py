@@ -19,6 +19,73 @@ LOG_EPS = float(np.float32(0.2))       # `static constexpr float log_eps = 0.2` 
 MAX, MEDIAN = 0, 1                     # eds::tracking::CANDIDATE_POINT_METHOD
 
 
+def _resize_coords(n_dst, n_src):
+    """OpenCV resize (INTER_LINEAR) source taps and fp32 fraction per destination index (imgproc/resize.cpp)."""
+    scale = n_src / n_dst
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    lo = s < 0
+    f[lo] = 0.0; s[lo] = 0
+    hi = s >= n_src - 1
+    f[hi] = 0.0; s[hi] = n_src - 1
+    return s, np.minimum(s + 1, n_src - 1), f
+
+
+def resize_cv_default(img, H, W):
+    """``cv::resize(img, img, cv::Size(W, H), cv::INTER_CUBIC)`` as KeyFrame::create calls it (KeyFrame.cpp:355): INTER_CUBIC sits in
+    the `fx` parameter, the interpolation is the default INTER_LINEAR — the 2x2 block mean when both scales are exactly 2 — with
+    OpenCV's arithmetic for the element type: uint8 in fixed point (11-bit weights; vertical pass
+    ``((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2 >> 2``), float32 in fp32, float64 in fp64.  Channels are independent.
+    Restated from OpenCV's published source; OpenCV is absent here (unpinned)."""
+    img = np.asarray(img)
+    if img.ndim == 3:
+        return np.stack([resize_cv_default(img[:, :, k], H, W) for k in range(img.shape[2])], axis=2)
+    sH, sW = img.shape
+    if (sH, sW) == (H, W):
+        return img.copy()
+    if sH == 2 * H and sW == 2 * W:
+        a, b, c, d = img[0::2, 0::2], img[0::2, 1::2], img[1::2, 0::2], img[1::2, 1::2]
+        if img.dtype == np.uint8:
+            return ((a.astype(np.int32) + b + c + d + 2) >> 2).astype(np.uint8)
+        z = img.dtype.type(0)
+        return ((((z + a) + b) + c) + d) * img.dtype.type(0.25)
+    x0, x1, fx = _resize_coords(W, sW)
+    y0, y1, fy = _resize_coords(H, sH)
+    one = np.float32(1.0)
+    if img.dtype == np.uint8:
+        rs = lambda v: np.clip(np.rint(v), -32768, 32767).astype(np.int64)     # saturate_cast<short>: round half to even
+        a0, a1 = rs((one - fx) * np.float32(2048.0)), rs(fx * np.float32(2048.0))
+        b0, b1 = rs((one - fy) * np.float32(2048.0)), rs(fy * np.float32(2048.0))
+        s = img.astype(np.int64)
+        S0 = s[y0][:, x0] * a0[None, :] + s[y0][:, x1] * a1[None, :]
+        S1 = s[y1][:, x0] * a0[None, :] + s[y1][:, x1] * a1[None, :]
+        return ((((b0[:, None] * (S0 >> 4)) >> 16) + ((b1[:, None] * (S1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+    T = img.dtype.type
+    a0, a1, b0, b1 = (one - fx).astype(T), fx.astype(T), (one - fy).astype(T), fy.astype(T)
+    S0 = img[y0][:, x0] * a0[None, :] + img[y0][:, x1] * a1[None, :]
+    S1 = img[y1][:, x0] * a0[None, :] + img[y1][:, x1] * a1[None, :]
+    return S0 * b0[:, None] + S1 * b1[:, None]
+
+
+def rgb_to_gray(img):
+    """cv::cvtColor(img, img, cv::COLOR_RGB2GRAY) (KeyFrame.cpp:361): uint8 (R 4899 + G 9617 + B 1868 + 2^13) >> 14; float32
+    R 0.299f + G 0.587f + B 0.114f evaluated left to right in fp32.  (No CV_64F colour images in OpenCV.)"""
+    img = np.asarray(img)
+    if img.ndim == 2:
+        return img
+    R, G, B = img[:, :, 0], img[:, :, 1], img[:, :, 2]
+    if img.dtype == np.uint8:
+        return ((R.astype(np.int32) * 4899 + G.astype(np.int32) * 9617 + B.astype(np.int32) * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    assert img.dtype == np.float32
+    return (R * np.float32(0.299) + G * np.float32(0.587)) + B * np.float32(0.114)
+
+
+def prepare_image(img, H, W):
+    """The image KeyFrame::create works on: resized to H x W when out_scale != 1, grey (KeyFrame.cpp:352-362)."""
+    return rgb_to_gray(resize_cv_default(img, H, W))
+
+
 def normalise_log(img):
     """KeyFrame.cpp:363-374: convertTo(CV_64F), (img - min)/(max - min), log(img + log_eps)."""
     img = np.asarray(img, dtype=np.float64)

@@ -39,7 +39,7 @@ EXPORTS = (
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
     "eds_trk_loss_param_batch", "eds_trk_update_points",
-    "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_get_keyframe_points",
+    "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
@@ -145,6 +145,8 @@ def lib():
         L.eds_trk_build_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(KfSelect), C.c_int, _dp, _dp,
                                              C.c_double, C.c_double, C.c_double, C.c_double, _ip]
         L.eds_trk_get_keyframe_points.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp]
+        L.eds_trk_build_keyframe_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(KfSelect),
+                                                   C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double, _ip]
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
@@ -403,8 +405,10 @@ class Handle:
                        min_depth=1.0, max_depth=3.0, weight_threshold=0.7):
         """KeyFrame::create's tracker-facing part on the device; returns dict(coord, norm_coord, grad, idp, weights)."""
         img = np.ascontiguousarray(img)
-        if img.shape != (self.H, self.W):
-            raise EdsError(ERR_INVALID, f"image must be {self.H} x {self.W}")
+        if img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] not in (1, 3)):
+            raise EdsError(ERR_INVALID, "image must be H x W (grey) or H x W x 3 (RGB)")
+        channels = 1 if img.ndim == 2 else int(img.shape[2])
+        img_H, img_W = int(img.shape[0]), int(img.shape[1])      # != (self.H, self.W): out_scale != 1, resized on the device
         if img.dtype == np.uint8:
             ty = IMG_U8
         elif img.dtype == np.float32:
@@ -420,9 +424,14 @@ class Handle:
         didp = _f64(depth_idp) if nd else None
         n = C.c_int32(0)
         fx, fy, cx, cy = [float(k) for k in K]
-        _check(lib().eds_trk_build_keyframe(self._h, slot, ty, img.ctypes.data_as(C.c_void_p), C.byref(sel), nd,
-                                            _p(dxy) if nd else None, _p(didp) if nd else None, fx, fy, cx, cy,
-                                            C.cast(C.byref(n), _ip)))
+        if channels == 1 and (img_H, img_W) == (self.H, self.W):
+            _check(lib().eds_trk_build_keyframe(self._h, slot, ty, img.ctypes.data_as(C.c_void_p), C.byref(sel), nd,
+                                                _p(dxy) if nd else None, _p(didp) if nd else None, fx, fy, cx, cy,
+                                                C.cast(C.byref(n), _ip)))
+        else:
+            _check(lib().eds_trk_build_keyframe_image(self._h, slot, ty, img.ctypes.data_as(C.c_void_p), img_H, img_W, channels,
+                                                      C.byref(sel), nd, _p(dxy) if nd else None, _p(didp) if nd else None,
+                                                      fx, fy, cx, cy, C.cast(C.byref(n), _ip)))
         N = n.value
         self._N[slot] = N
         out = dict(coord=np.zeros((N, 2)), norm_coord=np.zeros((N, 2)), grad=np.zeros((N, 2)), idp=np.zeros(N), weights=np.zeros(N))

@@ -973,7 +973,18 @@ int eds_trk_build_keyframe(eds_trk* h, int slot, int img_type, const void* img, 
     if (!img || !sel) return fail(EDS_ERR_INVALID, "null image or selection parameters");
     if (n_depth < 0) return fail(EDS_ERR_INVALID, "negative depth-map size");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    return eds_keyframe_build(h, slot, img_type, img, sel, n_depth, depth_xy, depth_idp, fx, fy, cx, cy, n_points);
+    return eds_keyframe_build(h, slot, img_type, img, h->H, h->W, 1, sel, n_depth, depth_xy, depth_idp, fx, fy, cx, cy, n_points);
+}
+
+int eds_trk_build_keyframe_image(eds_trk* h, int slot, int img_type, const void* img, int img_H, int img_W, int channels,
+                                 const eds_kf_select* sel, int n_depth, const double* depth_xy, const double* depth_idp, double fx, double fy,
+                                 double cx, double cy, int* n_points) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!img || !sel) return fail(EDS_ERR_INVALID, "null image or selection parameters");
+    if (n_depth < 0) return fail(EDS_ERR_INVALID, "negative depth-map size");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_keyframe_build(h, slot, img_type, img, img_H, img_W, channels, sel, n_depth, depth_xy, depth_idp, fx, fy, cx, cy, n_points);
 }
 
 int eds_trk_get_keyframe_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp, double* weights) {

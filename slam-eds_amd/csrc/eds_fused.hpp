@@ -104,7 +104,8 @@ int  eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, d
 // ---- keyframe point set-up on device (eds_keyframe.hip) ------------------------------------------------------
 struct eds_kf_select;
 struct EdsKeyframeBuffers {
-    void* d_raw = nullptr;                                                   // the image as handed over (u8 / f32 / f64)
+    void* d_raw = nullptr;                                                   // the H x W grey image the pipeline starts from (u8 / f32 / f64)
+    void* d_src = nullptr; size_t src_bytes = 0;                             // the image as handed over when it is resized / colour
     double *d_log = nullptr, *d_gx = nullptr, *d_gy = nullptr, *d_mag = nullptr, *d_partial = nullptr;
     int *d_cand = nullptr, *d_cnt = nullptr, *d_off = nullptr, *d_summary = nullptr;
     double *d_coord = nullptr, *d_grad = nullptr, *d_idp = nullptr, *d_w = nullptr;   // candidates, then the cleaned points (in place)
@@ -113,7 +114,7 @@ struct EdsKeyframeBuffers {
     double K[4] = {0, 0, 0, 0};
 };
 void eds_keyframe_free(EdsKeyframeBuffers* kb);
-int  eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
+int  eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, int img_H, int img_W, int channels, const eds_kf_select* sel, int n_depth,
                         const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points);
 int  eds_keyframe_get_points(eds_trk* h, int slot, double* coord_xy, double* norm_xy, double* grad_xy, double* idp, double* weights);
 

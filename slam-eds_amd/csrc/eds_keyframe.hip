@@ -34,6 +34,89 @@ __device__ __forceinline__ double load_px(const void* img, int type, size_t i) {
     return static_cast<const double*>(img)[i];
 }
 
+// ---- image preparation: what KeyFrame::create does to the image before anything else (KeyFrame.cpp:352-362) ----------------------
+// (1) `cv::resize(img, img, out_size, cv::INTER_CUBIC)` when out_scale != 1 — INTER_CUBIC lands in the `fx` parameter, so the
+//     interpolation is OpenCV's default INTER_LINEAR, replaced by the 2x2 block mean when both scales are exactly 2;
+// (2) `cv::cvtColor(img, img, cv::COLOR_RGB2GRAY)` for a colour image.
+// Both restated per element type from OpenCV's published implementation (imgproc/resize.cpp, color_rgb.simd.hpp): uint8 runs in
+// fixed point (11-bit interpolation weights, 14-bit luma coefficients 4899 / 9617 / 1868), float in fp32, double in fp64.
+__device__ __forceinline__ void kf_resize_coord(int d, double scale, int n_src, int* s0, int* s1, float* f) {
+    float fr = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(fr);
+    fr -= (float)s;
+    if (s < 0) { fr = 0.0f; s = 0; }
+    if (s >= n_src - 1) { fr = 0.0f; s = n_src - 1; }
+    *s0 = s; *s1 = s + 1 < n_src ? s + 1 : n_src - 1; *f = fr;
+}
+__device__ __forceinline__ int kf_round_short(float v) {               // saturate_cast<short>(float): round half to even, saturate
+    const float r = rintf(v);
+    return r > 32767.0f ? 32767 : (r < -32768.0f ? -32768 : (int)r);
+}
+// one channel `ch` of pixel (r, c) of the H x W image resized from src (sH x sW, `cn` interleaved channels)
+template <class T>
+__device__ __forceinline__ T kf_resized(const T* __restrict__ src, int sH, int sW, int cn, int ch, int H, int W, int r, int c);
+template <>
+__device__ __forceinline__ uint8_t kf_resized<uint8_t>(const uint8_t* __restrict__ src, int sH, int sW, int cn, int ch, int H, int W, int r, int c) {
+    if (sH == H && sW == W) return src[((size_t)r * sW + c) * cn + ch];
+    if (sH == 2 * H && sW == 2 * W) {
+        const uint8_t* p = src + ((size_t)(2 * r) * sW + 2 * c) * cn + ch;
+        return (uint8_t)((p[0] + p[cn] + p[(size_t)sW * cn] + p[(size_t)sW * cn + cn] + 2) >> 2);
+    }
+    int x0, x1, y0, y1; float fx, fy;
+    kf_resize_coord(c, (double)sW / (double)W, sW, &x0, &x1, &fx);
+    kf_resize_coord(r, (double)sH / (double)H, sH, &y0, &y1, &fy);
+    const int a0 = kf_round_short((1.0f - fx) * 2048.0f), a1 = kf_round_short(fx * 2048.0f);
+    const int b0 = kf_round_short((1.0f - fy) * 2048.0f), b1 = kf_round_short(fy * 2048.0f);
+    const int S0 = src[((size_t)y0 * sW + x0) * cn + ch] * a0 + src[((size_t)y0 * sW + x1) * cn + ch] * a1;
+    const int S1 = src[((size_t)y1 * sW + x0) * cn + ch] * a0 + src[((size_t)y1 * sW + x1) * cn + ch] * a1;
+    return (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+}
+template <>
+__device__ __forceinline__ float kf_resized<float>(const float* __restrict__ src, int sH, int sW, int cn, int ch, int H, int W, int r, int c) {
+    if (sH == H && sW == W) return src[((size_t)r * sW + c) * cn + ch];
+    if (sH == 2 * H && sW == 2 * W) {
+        const float* p = src + ((size_t)(2 * r) * sW + 2 * c) * cn + ch;
+        return ((((0.0f + p[0]) + p[cn]) + p[(size_t)sW * cn]) + p[(size_t)sW * cn + cn]) * 0.25f;
+    }
+    int x0, x1, y0, y1; float fx, fy;
+    kf_resize_coord(c, (double)sW / (double)W, sW, &x0, &x1, &fx);
+    kf_resize_coord(r, (double)sH / (double)H, sH, &y0, &y1, &fy);
+    const float a0 = 1.0f - fx, a1 = fx, b0 = 1.0f - fy, b1 = fy;
+    const float S0 = src[((size_t)y0 * sW + x0) * cn + ch] * a0 + src[((size_t)y0 * sW + x1) * cn + ch] * a1;
+    const float S1 = src[((size_t)y1 * sW + x0) * cn + ch] * a0 + src[((size_t)y1 * sW + x1) * cn + ch] * a1;
+    return S0 * b0 + S1 * b1;
+}
+template <>
+__device__ __forceinline__ double kf_resized<double>(const double* __restrict__ src, int sH, int sW, int cn, int ch, int H, int W, int r, int c) {
+    if (sH == H && sW == W) return src[((size_t)r * sW + c) * cn + ch];
+    if (sH == 2 * H && sW == 2 * W) {
+        const double* p = src + ((size_t)(2 * r) * sW + 2 * c) * cn + ch;
+        return ((((0.0 + p[0]) + p[cn]) + p[(size_t)sW * cn]) + p[(size_t)sW * cn + cn]) * 0.25;
+    }
+    int x0, x1, y0, y1; float fx, fy;
+    kf_resize_coord(c, (double)sW / (double)W, sW, &x0, &x1, &fx);
+    kf_resize_coord(r, (double)sH / (double)H, sH, &y0, &y1, &fy);
+    const double a0 = (double)(1.0f - fx), a1 = (double)fx, b0 = (double)(1.0f - fy), b1 = (double)fy;
+    const double S0 = src[((size_t)y0 * sW + x0) * cn + ch] * a0 + src[((size_t)y0 * sW + x1) * cn + ch] * a1;
+    const double S1 = src[((size_t)y1 * sW + x0) * cn + ch] * a0 + src[((size_t)y1 * sW + x1) * cn + ch] * a1;
+    return S0 * b0 + S1 * b1;
+}
+template <class T>
+__global__ __launch_bounds__(KF_T) void k_prepare(const T* __restrict__ src, int sH, int sW, int cn, T* __restrict__ dst, int H, int W) {
+    const int c = blockIdx.x * KF_T + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    T v;
+    if (cn == 1) {
+        v = kf_resized<T>(src, sH, sW, 1, 0, H, W, r, c);
+    } else {                            // COLOR_RGB2GRAY on the resized pixel
+        const T R = kf_resized<T>(src, sH, sW, cn, 0, H, W, r, c), G = kf_resized<T>(src, sH, sW, cn, 1, H, W, r, c),
+                B = kf_resized<T>(src, sH, sW, cn, 2, H, W, r, c);
+        if (sizeof(T) == 1) v = (T)(((int)R * 4899 + (int)G * 9617 + (int)B * 1868 + (1 << 13)) >> 14);
+        else v = (T)((float)R * 0.299f + (float)G * 0.587f + (float)B * 0.114f);
+    }
+    dst[(size_t)r * W + c] = v;
+}
+
 // block-level min / max; result valid on thread 0
 __device__ __forceinline__ void block_minmax(double& mn, double& mx) {
     __shared__ double s_mn[KF_T], s_mx[KF_T];
@@ -294,6 +377,7 @@ __global__ __launch_bounds__(KF_T) void k_fill_slot(EdsArrays A, int slot, int N
 }  // namespace
 
 void eds_keyframe_free(EdsKeyframeBuffers* kb) {
+    if (kb->d_src) hipFree(kb->d_src);
     void* d[] = {kb->d_raw, kb->d_log, kb->d_gx, kb->d_gy, kb->d_mag, kb->d_partial, kb->d_cand, kb->d_cnt, kb->d_off,
                  kb->d_coord, kb->d_grad, kb->d_idp, kb->d_w, kb->d_dxy, kb->d_didp, kb->d_summary};
     for (void* p : d) if (p) hipFree(p);
@@ -318,10 +402,15 @@ static int ensure(eds_trk* h) {
     return EDS_OK;
 }
 
-int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, const eds_kf_select* sel, int n_depth,
-                       const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points) {
+int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, int img_H, int img_W, int channels, const eds_kf_select* sel,
+                       int n_depth, const double* depth_xy, const double* depth_idp, double fx, double fy, double cx, double cy, int* n_points) {
     const int H = h->H, W = h->W;
     const size_t n = (size_t)H * W;
+    if (img_H <= 0 || img_W <= 0) { img_H = H; img_W = W; }
+    if (channels != 1 && channels != 3) return eds_internal_fail(EDS_ERR_INVALID, "an image has 1 (grey) or 3 (RGB, interleaved) channels");
+    if (channels == 3 && img_type == 2) return eds_internal_fail(EDS_ERR_INVALID, "cv::cvtColor takes 8-bit or float colour images, not CV_64F");
+    if (img_H < 2 || img_W < 2) return eds_internal_fail(EDS_ERR_INVALID, "bad image size");
+    const bool prepare = channels != 1 || img_H != H || img_W != W;
     const int cell = sel->cell;
     if (cell < 2 || cell > KF_MAX_CELL || cell > H || cell > W) return eds_internal_fail(EDS_ERR_INVALID, "cell size must be in [2, 32] and fit the image");
     if (sel->method != EDS_KF_MAX && sel->method != EDS_KF_MEDIAN) return eds_internal_fail(EDS_ERR_INVALID, "unknown point selection method");
@@ -341,7 +430,23 @@ int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, cons
     }
     hipStream_t st = h->st;
     const size_t px = img_type == 0 ? 1 : (img_type == 1 ? 4 : 8);
-    hipError_t e = hipMemcpyAsync(kb.d_raw, img, n * px, hipMemcpyHostToDevice, st);
+    hipError_t e = hipSuccess;
+    if (!prepare) {
+        e = hipMemcpyAsync(kb.d_raw, img, n * px, hipMemcpyHostToDevice, st);
+    } else {                            // resize and / or grey conversion on the device (KeyFrame.cpp:352-362), into the usual buffer
+        const size_t src_bytes = (size_t)img_H * img_W * channels * px;
+        if (src_bytes > kb.src_bytes) {
+            if (kb.d_src) hipFree(kb.d_src);
+            kb.d_src = nullptr; kb.src_bytes = 0;
+            if (hipMalloc(&kb.d_src, src_bytes) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(source image)");
+            kb.src_bytes = src_bytes;
+        }
+        e = hipMemcpyAsync(kb.d_src, img, src_bytes, hipMemcpyHostToDevice, st);
+        const dim3 g((W + KF_T - 1) / KF_T, H), b(KF_T);
+        if (img_type == 0) hipLaunchKernelGGL(k_prepare<uint8_t>, g, b, 0, st, (const uint8_t*)kb.d_src, img_H, img_W, channels, (uint8_t*)kb.d_raw, H, W);
+        else if (img_type == 1) hipLaunchKernelGGL(k_prepare<float>, g, b, 0, st, (const float*)kb.d_src, img_H, img_W, channels, (float*)kb.d_raw, H, W);
+        else hipLaunchKernelGGL(k_prepare<double>, g, b, 0, st, (const double*)kb.d_src, img_H, img_W, channels, (double*)kb.d_raw, H, W);
+    }
     if (e == hipSuccess && n_depth > 0) e = hipMemcpyAsync(kb.d_dxy, depth_xy, (size_t)n_depth * 16, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && n_depth > 0) e = hipMemcpyAsync(kb.d_didp, depth_idp, (size_t)n_depth * 8, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));

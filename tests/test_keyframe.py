@@ -171,3 +171,60 @@ def test_keyframe_mirror_create(gpu, capi):
     kf0 = trk.KeyFrame.create(img, K, xy, di, trk.SELECT_MAX, percent_points=0.0)      # no target: MEDIAN
     ref0 = ko.keyframe(img, (125.0, 125.0, 79.5, 59.5), ko.MEDIAN, 0, depth_xy=xy, depth_idp=di)
     assert np.array_equal(kf0.coord, ref0["coord"])
+
+
+# ---- image preparation: out_scale != 1 and colour input (KeyFrame.cpp:352-362) ---------------------------------------------
+def test_oracle_image_preparation_known_answers():
+    import np_keyframe_oracle as ko
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, (12, 16), dtype=np.uint8)
+    half = ko.resize_cv_default(u8, 6, 8)                        # exact factor 2: rounded block mean
+    blk = u8.reshape(6, 2, 8, 2).astype(np.int32).sum(axis=(1, 3))
+    assert half.dtype == np.uint8 and np.array_equal(half, (blk + 2) >> 2)
+    assert np.array_equal(ko.resize_cv_default(u8, 12, 16), u8)
+    const = np.full((9, 13), 77, np.uint8)
+    assert np.all(ko.resize_cv_default(const, 6, 7) == 77)       # fixed-point weights sum to 2048: constants survive
+    f32 = rng.standard_normal((9, 12)).astype(np.float32)
+    r = ko.resize_cv_default(f32, 6, 8)
+    assert r.dtype == np.float32 and r.shape == (6, 8) and r[0, 0] != f32[0, 0]
+    rgb = np.zeros((2, 2, 3), np.uint8); rgb[..., 0] = 255
+    assert np.all(ko.rgb_to_gray(rgb) == (255 * 4899 + (1 << 13)) >> 14)      # 76
+    white = np.full((2, 2, 3), 255, np.uint8)
+    assert np.all(ko.rgb_to_gray(white) == 255)                  # 4899 + 9617 + 1868 = 2^14
+    g = ko.rgb_to_gray(np.ones((2, 2, 3), np.float32))
+    assert g.dtype == np.float32 and np.allclose(g, 1.0, atol=1e-6)
+    assert ko.prepare_image(rng.integers(0, 256, (20, 30, 3), dtype=np.uint8), 10, 15).shape == (10, 15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32, np.float64], ids=["u8", "f32", "f64"])
+@pytest.mark.parametrize("src,channels", [((240, 320), 1), ((240, 320), 3), ((180, 240), 3), ((120, 160), 3), ((100, 130), 1)],
+                         ids=["half-grey", "half-rgb", "x1.5-rgb", "same-rgb", "up-grey"])
+def test_build_keyframe_from_camera_image(gpu, capi, dtype, src, channels):
+    """eds_trk_build_keyframe_image: resize (out_scale != 1) and RGB -> grey on the device, then the usual set-up; against the
+    numpy restatement of OpenCV's per-type arithmetic."""
+    import np_keyframe_oracle as ko
+    if dtype == np.float64 and channels == 3:
+        h = capi.Handle(capi.default_config(), 1, 1000, 120, 160)
+        with pytest.raises(capi.EdsError):                       # cv::cvtColor has no CV_64F colour path
+            h.build_keyframe(0, np.zeros(src + (3,), np.float64), (100.0, 100.0, 80.0, 60.0))
+        h.close()
+        return
+    H, W = 120, 160
+    sH, sW = src
+    base = make_image(23, sH, sW, np.float64)
+    if channels == 3:
+        rng = np.random.default_rng(2)
+        img = np.stack([base, np.roll(base, 3, 1) * 0.8 + 0.1, np.clip(base + 0.1 * rng.standard_normal(base.shape), 0, 1)], axis=2)
+    else:
+        img = base
+    img = np.round(img * 255).astype(np.uint8) if dtype == np.uint8 else img.astype(dtype)
+    K = (0.78 * W, 0.78 * W, (W - 1) / 2, (H - 1) / 2)
+    xy, di = make_depth_map(24, H, W, 800)
+    grey = ko.prepare_image(img, H, W)
+    assert grey.shape == (H, W) and grey.dtype == img.dtype
+    ref = ko.keyframe(grey, K, 0, 1500, depth_xy=xy, depth_idp=di)
+    h = capi.Handle(capi.default_config(), 1, H * W, H, W)
+    out = h.build_keyframe(0, img, K, method=0, num_points=1500, depth_xy=xy, depth_idp=di)
+    _compare(out, ref)
+    h.close()
