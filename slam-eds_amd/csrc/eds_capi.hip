@@ -308,7 +308,7 @@ void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     void* dptrs[] = {h->dkf, h->dpose, h->dG, h->dpart, h->dncstat,
-                     h->dmhat, h->dframe, h->dr, h->dJ};
+                     h->dmhat, h->dframe, h->dr, h->dJ, h->dstage};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
     eds_frame_free(&h->frame_build);
@@ -324,17 +324,25 @@ void free_all(eds_trk* h) {
 
 }  // namespace
 
-// Row-major H x W host frame (double or float) -> the handle's HBM layout in pinned staging: fp32, padded to multiples
-// of 4 plus a margin, everything outside the image filled with the nearest border pixel (= Grid2D's clamp), in 4x4
-// tiles of one 64-byte sector each or row-major (eds_layout.hpp eds_frame_index).
+// Row-major H x W host frame (double or float) -> the slot's frame in HBM.  The host only narrows to fp32 (a loop the compiler
+// vectorises; no index arithmetic) into pinned staging, in EDS_UPLOAD_CHUNKS pieces: the DMA of piece i runs while piece i + 1 is
+// being narrowed.  Tiling, padding and the replicated margin (= Grid2D's clamp) happen on the device (k_store_rowmajor).
+// (Round 1 built the tiled, margin-padded image element by element on one host thread: 300 us for 640x480, more than the solve.)
+#define EDS_UPLOAD_CHUNKS 4
 template <class T>
-static void stage_frame(eds_trk* h, const T* frame) {
-    const int H = h->H, W = h->W, Hp = h->Hp, Wp = h->Wp, M = EDS_FRAME_MARGIN;
-    float* dst = h->h_f32;
-    for (int r = -M; r < Hp - M; ++r) {
-        const T* src = frame + (size_t)std::min(std::max(r, 0), H - 1) * W;
-        for (int c = -M; c < Wp - M; ++c) dst[eds_frame_index(r, c, Wp, h->tiled)] = (float)src[std::min(std::max(c, 0), W - 1)];
+static int upload_frame(eds_trk* h, int slot, const T* frame) {
+    const size_t n = (size_t)h->H * h->W;
+    float* stage = h->h_f32;                                     // h_f32_elems >= Hp * Wp >= H * W
+    for (int k = 0; k < EDS_UPLOAD_CHUNKS; ++k) {
+        const size_t b = n * k / EDS_UPLOAD_CHUNKS, e = n * (k + 1) / EDS_UPLOAD_CHUNKS;
+        for (size_t i = b; i < e; ++i) stage[i] = (float)frame[i];
+        EDS_HIP_TRY(hipMemcpyAsync(h->dstage + b, stage + b, (e - b) * 4, hipMemcpyHostToDevice, h->st));
     }
+    eds_frame_store_rowmajor(h, slot, h->dstage);
+    EDS_HIP_TRY(hipGetLastError());
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));                    // the staging buffer is reused by the next call
+    h->slots[slot].has_frame = true;
+    return EDS_OK;
 }
 
 int eds_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
@@ -427,6 +435,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->dcell0 = reinterpret_cast<int*>(h->dkf + EDS_KF_CELL0 * BN);
     EDS_ALLOC(h->dmhat, BN * 4); EDS_ALLOC(h->dr, BN * 4); EDS_ALLOC(h->dJ, BN * 4 * 12);
     EDS_ALLOC(h->dframe, (size_t)batch * h->Hp * h->Wp * 4);
+    EDS_ALLOC(h->dstage, (size_t)H * W * 4);
     EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_ALLOC(h->dG, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
     EDS_ALLOC(h->dpart, (size_t)batch * h->max_seg * EDS_RED_K * 8);
@@ -568,12 +577,7 @@ int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame) {
     if (rc) return rc;
     if (!frame) return fail(EDS_ERR_INVALID, "null frame");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    stage_frame(h, frame);
-    const size_t n = (size_t)h->Hp * h->Wp;
-    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
-    EDS_HIP_TRY(hipStreamSynchronize(h->st));
-    h->slots[slot].has_frame = true;
-    return EDS_OK;
+    return upload_frame(h, slot, frame);
 }
 
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
@@ -581,12 +585,7 @@ int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
     if (rc) return rc;
     if (!frame) return fail(EDS_ERR_INVALID, "null frame");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    stage_frame(h, frame);
-    const size_t n = (size_t)h->Hp * h->Wp;
-    EDS_HIP_TRY(hipMemcpyAsync(h->dframe + (size_t)slot * n, h->h_f32, n * 4, hipMemcpyHostToDevice, h->st));
-    EDS_HIP_TRY(hipStreamSynchronize(h->st));
-    h->slots[slot].has_frame = true;
-    return EDS_OK;
+    return upload_frame(h, slot, frame);
 }
 
 int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy) {

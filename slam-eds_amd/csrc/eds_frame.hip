@@ -144,7 +144,19 @@ __global__ void k_store_levels(const double* __restrict__ planes, const double* 
     frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
 }
 
+// row-major H x W fp32 image -> the handle's frame layout (tiles, padding and margin filled with the nearest border pixel)
+__global__ void k_store_rowmajor(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Hp, int Wp, int tiled) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+    if (c >= Wp - EDS_FRAME_MARGIN) return;
+    dst[eds_frame_index(r, c, Wp, tiled)] = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
+}
+
 }  // namespace
+
+void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src) {
+    hipLaunchKernelGGL(k_store_rowmajor, dim3((h->Wp + 255) / 256, h->Hp), dim3(256), 0, h->st, d_src, h->dframe + (size_t)slot * h->Hp * h->Wp,
+                       h->H, h->W, h->Hp, h->Wp, h->tiled);
+}
 
 void eds_frame_free(EdsFrameBuffers* fb) {
     void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex, fb->d_planes};     // d_ey, d_pol are slices of d_ex

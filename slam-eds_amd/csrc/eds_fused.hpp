@@ -86,6 +86,7 @@ struct EdsFrameBuffers {
     int cap_events = 0;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
+void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src);     // row-major fp32 H x W in HBM -> the slot's tiled frame
 int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
 int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
                             const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out);

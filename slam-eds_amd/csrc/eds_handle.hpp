@@ -38,6 +38,7 @@ struct eds_trk {
     float *df0x = nullptr, *df0y = nullptr;
     int* dcell0 = nullptr;
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
+    float* dstage = nullptr;            // one row-major H x W fp32 frame: landing area of set_event_frame's chunked upload
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
     EdsPointBuffers point_ops;

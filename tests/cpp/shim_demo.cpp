@@ -1,5 +1,6 @@
 // Drives the C++ shim (slam-eds_amd/csrc/Tracker.hpp) the way the external EDS component drives
 // eds::tracking::Tracker: read one alignment from a flat binary file, call optimize(), print the result.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -39,13 +40,16 @@ int main(int argc, char** argv) {
     const eds::tracking::TrackerInfo info = tracker.getInfo();
     // the same solve again on the unchanged KeyFrame: the shim keeps the device copy (hip.reuse_uploads) — identical result required;
     // then with the inverse depths touched (only that plane is re-uploaded) and restored
-    double rep_err = 0;
+    double rep_err = 0, live_call_us = 0, live_kernel_us = 0;
     {
         std::vector<double> res_first = kf->residuals;
         tracker.reset(kf, Eigen::Vector3d::Zero(), Eigen::Quaterniond::Identity(), velo);
         base::Transform3d T2 = base::Transform3d::Identity();
         tracker.config.loss_params = {0.3};
+        const auto t_a = std::chrono::steady_clock::now();
         const bool good2 = tracker.optimize(0, &frame, T2, eds::tracking::MAD);
+        live_call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_a).count();
+        live_kernel_us = tracker.getInfo().meas_time_us;
         for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) rep_err = std::max(rep_err, std::fabs(T2(r, c) - T(r, c)));
         if (!good2 || res_first.size() != kf->residuals.size()) rep_err = 1.0;
         const double idp0_saved = kf->inv_depth[0];
@@ -85,9 +89,9 @@ int main(int argc, char** argv) {
     double c0 = moved.empty() ? 0 : moved[0].x, c1 = moved.empty() ? 0 : moved.back().y;
     std::printf("{\"ok\": %d, \"t\": [%.17g, %.17g, %.17g], \"R\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g, %.17g], "
                 "\"v\": [%.17g, %.17g, %.17g, %.17g, %.17g, %.17g], \"iterations\": %d, \"num_points\": %u, \"tau\": %.17g, \"residuals\": %zu, \"inverse_err\": %.3g, "
-                "\"kept\": %zu, \"consistent\": %d, \"first_x\": %.17g, \"last_y\": %.17g, \"sq_flow\": %.17g, \"need_kf\": %d, \"first_idp\": %.17g, \"rep_err\": %.3g, \"filt_err\": %.3g, \"filt_flags\": %d}\n",
+                "\"kept\": %zu, \"consistent\": %d, \"first_x\": %.17g, \"last_y\": %.17g, \"sq_flow\": %.17g, \"need_kf\": %d, \"first_idp\": %.17g, \"rep_err\": %.3g, \"filt_err\": %.3g, \"filt_flags\": %d, \"live_call_us\": %.1f, \"live_solve_us\": %.1f}\n",
                 good ? 1 : 0, Tef(0, 3), Tef(1, 3), Tef(2, 3), Tef(0, 0), Tef(0, 1), Tef(0, 2), Tef(1, 0), Tef(1, 1), Tef(1, 2), Tef(2, 0), Tef(2, 1), Tef(2, 2),
                 v[0], v[1], v[2], v[3], v[4], v[5], info.num_iterations, info.num_points, tracker.config.loss_params[0], res_before.size(), id_err,
-                n_after, consistent ? 1 : 0, c0, c1, tracker.hipSquaredNormFlow(), tracker.needNewKeyframe(0.03) ? 1 : 0, kf->inv_depth.empty() ? 0.0 : kf->inv_depth[0], rep_err, filt_err, filt_flags);
+                n_after, consistent ? 1 : 0, c0, c1, tracker.hipSquaredNormFlow(), tracker.needNewKeyframe(0.03) ? 1 : 0, kf->inv_depth.empty() ? 0.0 : kf->inv_depth[0], rep_err, filt_err, filt_flags, live_call_us, live_kernel_us);
     return good ? 0 : 1;
 }
