@@ -377,7 +377,18 @@ def main():
                     "note": f"achieved/frac: SURVEY 8d credit, {per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch "
                             f"(a fused kernel is credited the J bytes it never moves); *_must_move: {mm} B per point-evaluation "
                             f"(point constants + taps only)"}
-            t = pmc_traffic(kname + ("<0" if a.sampling == "bicubic" else "<1"), a)      # first template argument = sampler
+            # the instantiation eds_fused_solve launches for this shape: <sampler, points per lane, threads, quad gather, team>
+            if kname == "eds_fused6_kernel":
+                thr = 512 if N <= 2048 else 1024
+                while thr > 64 and thr // 2 >= N:
+                    thr //= 2
+                ppt = -(-N // thr); ppt = 1 if ppt <= 1 else (2 if ppt <= 2 else (4 if ppt <= 4 else 0))
+                smp = 0 if a.sampling == "bicubic" else 1
+                inst = f"<{smp}, {ppt}, {thr}, {1 if (smp == 0 and B >= 32 and ppt > 0) else 0}, 1>"
+            else:
+                inst = "<0" if a.sampling == "bicubic" else "<1"
+            roof["kernel"] = kname + (inst if inst.endswith(">") else "")
+            t = pmc_traffic(kname + inst, a)
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
@@ -454,7 +465,10 @@ def main():
                                                      "traffic": None, "kernel_ms": rk_ms,
                                                      "note": f"{r_cred} B credited / {r_mm} B must-move per point-evaluation x {B}x{N} points x "
                                                              f"{r_evals:.2f} evaluations per solve"}}
-            t = pmc_traffic("eds_fused12_kernel" + ("<0" if a.sampling == "bicubic" else "<1"), a)
+            smp = 0 if a.sampling == "bicubic" else 1
+            inst12 = (f"<{smp}, 512, 1408, false, 1, 0>" if B <= 256 else f"<{smp}, 256, 320, false, 1, {1 if (smp == 0 and B >= 1024) else 0}>")
+            out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = "eds_fused12_kernel" + inst12
+            t = pmc_traffic("eds_fused12_kernel" + inst12, a)
             if t:
                 out["reference_problem"]["roofline"]["traffic"] = t["bytes"]
                 out["reference_problem"]["roofline"]["traffic_source"] = t["source"]

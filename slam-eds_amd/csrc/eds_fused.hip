@@ -65,7 +65,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
                                                           double huber_tau, int nb, unsigned long long* __restrict__ mail,
-                                                          int* __restrict__ ticket, unsigned epoch) {
+                                                          int* __restrict__ ticket, unsigned ticket_base, unsigned epoch) {
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ int s_ticket;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ int s_timeout;
     int team_slot = blockIdx.x, member = 0;
     if (TEAM > 1) {
-        if (tid == 0) { s_ticket = atomicAdd(ticket, 1); s_timeout = 0; }
+        if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
         team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
     }
@@ -534,17 +534,21 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 // ---------------------------------------------------------------------------------------
 int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     fb->B = B;
-    if (hipMalloc((void**)&fb->d_in, sizeof(EdsFusedIn) * B) != hipSuccess) return -1;
-    if (hipMalloc((void**)&fb->d_out, sizeof(EdsFusedOut) * B) != hipSuccess) return -1;
+    // start states and compact results live in pinned host memory that the kernels read / write directly (a solve moves ~100 bytes
+    // each way per alignment): no copy calls on the latency path of a single optimize — each HIP call costs 3-5 us of host time
     if (hipMalloc(&fb->d_sv, sizeof(edss::Solver6) * (size_t)B) != hipSuccess) return -1;
-    if (hipHostMalloc((void**)&fb->h_in, sizeof(EdsFusedIn) * B, hipHostMallocDefault) != hipSuccess) return -1;
-    if (hipHostMalloc((void**)&fb->h_out, sizeof(EdsFusedOut) * B, hipHostMallocDefault) != hipSuccess) return -1;
-    if (hipMalloc((void**)&fb->d_out12, sizeof(EdsFused12Out) * B) != hipSuccess) return -1;
-    if (hipHostMalloc((void**)&fb->h_out12, sizeof(EdsFused12Out) * B, hipHostMallocDefault) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&fb->h_in, sizeof(EdsFusedIn) * B, hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&fb->h_out, sizeof(EdsFusedOut) * B, hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&fb->h_out12, sizeof(EdsFused12Out) * B, hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostGetDevicePointer((void**)&fb->d_in, fb->h_in, 0) != hipSuccess) return -1;
+    if (hipHostGetDevicePointer((void**)&fb->d_out, fb->h_out, 0) != hipSuccess) return -1;
+    if (hipHostGetDevicePointer((void**)&fb->d_out12, fb->h_out12, 0) != hipSuccess) return -1;
     // team launches (eds_fused6_kernel TEAM > 1): granule mailboxes of EDS_TEAM_SLOTS alignments + the ticket counter
     if (hipMalloc((void**)&fb->d_mail, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
     if (hipMemset(fb->d_mail, 0, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
     if (hipMalloc((void**)&fb->d_ticket, sizeof(int)) != hipSuccess) return -1;
+    if (hipMemset(fb->d_ticket, 0, sizeof(int)) != hipSuccess) return -1;
+    fb->ticket_base = 0;
     fb->epoch = 0;
     std::memset(fb->h_out12, 0, sizeof(EdsFused12Out) * B);
     std::memset(fb->h_in, 0, sizeof(EdsFusedIn) * B);
@@ -553,12 +557,9 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
 }
 
 void eds_fused_free(EdsFusedBuffers* fb) {
-    if (fb->d_in) hipFree(fb->d_in);
-    if (fb->d_out) hipFree(fb->d_out);
     if (fb->d_sv) hipFree(fb->d_sv);
     if (fb->h_in) hipHostFree(fb->h_in);
     if (fb->h_out) hipHostFree(fb->h_out);
-    if (fb->d_out12) hipFree(fb->d_out12);
     if (fb->d_mail) hipFree(fb->d_mail);
     if (fb->d_mail12) hipFree(fb->d_mail12);
     if (fb->d_ticket) hipFree(fb->d_ticket);
@@ -593,8 +594,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         EdsFusedIn& I = fb.h_in[s];
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
-    hipError_t e = hipMemcpyAsync(fb.d_in + first, fb.h_in + first, sizeof(EdsFusedIn) * count, hipMemcpyHostToDevice, h->st);
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    hipError_t e = hipSuccess;
     const EdsArrays A = h->arrays();
     // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
     // the points-per-lane variant is picked from the largest N of the range
@@ -629,10 +629,10 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
 #define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q, 1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u)
+                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u, 0u)
 #define EDS_LAUNCH_TEAM(S, P, Q, K)                                                                                                \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, fb.epoch)
+                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch)
     // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
     // solves with register-resident points only; 4 CUs up to 64 alignments of more than 1 024 points, 2 CUs up to 128.
     int team = 1;
@@ -650,9 +650,10 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
             hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
             fb.epoch = 1;
         }
-        hipMemsetAsync(fb.d_ticket, 0, sizeof(int), h->st);
     }
     fb.pending_team = team; fb.pending_level = level;
+    const unsigned ticket_base = fb.ticket_base;
+    if (team > 1) fb.ticket_base += (unsigned)(count * team);
     hipEventRecord(h->ev0, h->st);
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
@@ -686,8 +687,6 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH_TEAM
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    e = hipMemcpyAsync(fb.h_out + first, fb.d_out + first, sizeof(EdsFusedOut) * count, hipMemcpyDeviceToHost, h->st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;
     fb.pending_count = count;

@@ -39,7 +39,7 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 #define EDS_TEAM12_MAIL_BYTES ((size_t)EDS_TEAM12_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM12_GRANULES * 8)
 
 struct EdsFusedBuffers {
-    EdsFusedIn* d_in = nullptr;
+    EdsFusedIn* d_in = nullptr;             // device-side addresses of the pinned h_in / h_out / h_out12 below
     EdsFusedOut* d_out = nullptr;
     EdsFused12Out* d_out12 = nullptr;
     void* d_sv = nullptr;          // edss::Solver6 per slot (full state incl. trace)
@@ -50,6 +50,7 @@ struct EdsFusedBuffers {
     unsigned long long* d_mail12 = nullptr; // the same for REF12 (allocated at the first REF12 team launch)
     int* d_ticket = nullptr;                // team launches: workgroup arrival counter (team = ticket / K, member = ticket % K)
     unsigned epoch = 0;                     // launch sequence number inside the granule tags
+    unsigned ticket_base = 0;               // tickets handed out by earlier team launches (the device counter is never reset)
     bool team_disabled = false;             // a team once timed out on this handle
     int pending_team = 1, pending_level = 0;
     int B = 0;

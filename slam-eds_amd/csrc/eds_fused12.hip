@@ -51,14 +51,14 @@ template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
                                                               double loss_a, double ftol, double gtol, double ptol, int nb,
-                                                              unsigned long long* __restrict__ mail, int* __restrict__ ticket, unsigned epoch) {
+                                                              unsigned long long* __restrict__ mail, int* __restrict__ ticket, unsigned ticket_base, unsigned epoch) {
     const int tid = threadIdx.x;
     constexpr int nthr = NTHR;
     static_assert(TEAM == 1 || !NC, "the NC residual needs a second exchange (block norm of the sampled brightness): no teams");
     __shared__ int s_ticket, s_timeout;
     int team_slot = blockIdx.x, member = 0;
     if (TEAM > 1) {
-        if (tid == 0) { s_ticket = atomicAdd(ticket, 1); s_timeout = 0; }
+        if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
         team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
     }
@@ -487,8 +487,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         EdsFusedIn& I = fb.h_in[s];
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
-    hipError_t e = hipMemcpyAsync(fb.d_in + first, fb.h_in + first, sizeof(EdsFusedIn) * count, hipMemcpyHostToDevice, h->st);
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    hipError_t e = hipSuccess;           // (start states and results: pinned host memory the kernel accesses directly, eds_fused_alloc)
     const EdsArrays A = h->arrays();
     // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads,
     // 96 KB patch cache — the lower latency (0.28 ms for one 2 000-point alignment, 7.0 M LM iterations/s at 256).
@@ -521,14 +520,15 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
             hipMemsetAsync(fb.d_mail12, 0, EDS_TEAM12_MAIL_BYTES, h->st);
             fb.epoch = 1;
         }
-        hipMemsetAsync(fb.d_ticket, 0, sizeof(int), h->st);
     }
     fb.pending_team = team; fb.pending_level = level;
+    const unsigned ticket_base = fb.ticket_base;
+    if (team > 1) fb.ticket_base += (unsigned)(count * team);
     hipEventRecord(h->ev0, h->st);
 #define EDS_LAUNCH12_(S, T, C, NCM, K, Q)                                                                                             \
     hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
-                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, fb.epoch)
+                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch)
 #define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
     bool quad = bicubic && count >= 1024;          // measured: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below
@@ -541,8 +541,6 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH12_
     hipEventRecord(h->ev1, h->st);
     e = hipGetLastError();
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    e = hipMemcpyAsync(fb.h_out12 + first, fb.d_out12 + first, sizeof(EdsFused12Out) * count, hipMemcpyDeviceToHost, h->st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;
     fb.pending_count = count;

@@ -5,12 +5,14 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_${1:-r01}
+OUT=gpurun_out/prof_${1:-r02}
 rm -rf "$OUT"; mkdir -p "$OUT"
 ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu}"
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_write.json" 2> "$OUT/write.err"
+# L2 behaviour of the gather: requests, hits, misses and what goes on to the fabric (4 TCC slots = one pass)
+rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -d "$OUT/pmc_l2" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_l2.json" 2> "$OUT/l2.err"
 find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"

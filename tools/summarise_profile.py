@@ -14,7 +14,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -42,6 +42,13 @@ for which in ("fetch", "write"):
         for r in csv.DictReader(open(f)):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
+l2 = collections.defaultdict(lambda: collections.defaultdict(list))
+try:
+    for r in csv.DictReader(open(newest(os.path.join(src, "pmc_l2", "*", "*_counter_collection.csv")))):
+        l2[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+except ValueError:
+    pass
+
 bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().splitlines()[-1])
 cfg = bench["config"]
 out = {"tag": tag, "bench_config": cfg, "bench_value": bench["value"], "kernels": {}}
@@ -61,9 +68,21 @@ for k, r in stats.items():
     wkb = sum(w) / len(w) if w else None
     raw = (fkb + wkb) * 1024 if (fkb is not None and wkb is not None) else None
     out["kernels"][k] = {"calls": int(r["Calls"]), "avg_us": avg_us, "fetch_kb": fkb, "write_kb": wkb, "raw_hbm_bytes": raw}
+    if k in l2:
+        m = {c: sum(v) / len(v) for c, v in l2[k].items()}
+        if m.get("TCC_REQ_sum"):
+            m["hit_fraction"] = m.get("TCC_HIT_sum", 0.0) / m["TCC_REQ_sum"]
+        out["kernels"][k]["l2"] = m
     lines.append(f"| {k} | {r['Calls']} | {avg_us:.1f} | {fkb if fkb is None else round(fkb, 1)} | "
                  f"{wkb if wkb is None else round(wkb, 1)} | {raw if raw is None else int(raw)} | "
                  f"{'' if raw is None else round(raw / avg_us / 1e3, 1)} |")
+lines += ["", "L2 (separate `--pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum` pass; per launch, chip-wide sums):", "",
+          "| kernel | TCC_REQ | TCC_HIT | TCC_MISS | TCC_EA0_RDREQ | hit fraction |", "|---|---|---|---|---|---|"]
+for k, v in out["kernels"].items():
+    if "l2" in v:
+        m = v["l2"]
+        lines.append(f"| {k} | {m.get('TCC_REQ_sum', 0):.4g} | {m.get('TCC_HIT_sum', 0):.4g} | {m.get('TCC_MISS_sum', 0):.4g} | "
+                     f"{m.get('TCC_EA0_RDREQ_sum', 0):.4g} | {m.get('hit_fraction', float('nan')):.3f} |")
 lines += ["",
           "FETCH_SIZE / WRITE_SIZE were collected in two separate `--pmc` passes (they do not fit one pass on gfx950).",
           "Raw = (FETCH_SIZE + WRITE_SIZE) x 1024.  Calibration on known byte counts (MI355X_MICROARCH.md asks for it):",
@@ -74,8 +93,9 @@ lines += ["",
           "  except that two sectors of one 128-B line fetched together are tallied once;",
           "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
           "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound.",
-          "`eds_stream6_kernel` and `eds_fused12_kernel` (bench.py's headline and its informational REF12 measurement) write the",
-          "candidate residuals of every pass (8 KB per alignment and pass) plus the accepted copies: that is their WRITE_SIZE."]
+          "`eds_fused12_kernel` (bench.py's REF12 measurement) writes the candidate residuals of every evaluation (8 KB per alignment and",
+          "evaluation) plus the accepted copies: that is its WRITE_SIZE; `eds_fused6_kernel` (the headline) keeps them in registers and writes",
+          "the residuals once."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
 print("\n".join(lines))
