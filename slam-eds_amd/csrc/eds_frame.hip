@@ -101,6 +101,7 @@ __global__ void k_resize(const double* __restrict__ src, int sH, int sW, double*
     const double h1 = src[(size_t)y1 * sW + x0] * a0 + src[(size_t)y1 * sW + x1] * a1;
     dst[(size_t)r * W + c] = h0 * b0 + h1 * b1;
 }
+#define EDS_SUMSQ_WAYS 64
 // Levels of EventFrame::create from ONE brightness image (EventFrame.cpp:348-357): level 0 is the image, level i >= 1 its
 // dilation + erosion with a (2i+1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue).  blockIdx.z
 // selects the level (level0 + z); each level's image goes to its own plane and its sum of squares is accumulated on the way.
@@ -132,14 +133,19 @@ __global__ void k_levels(const double* __restrict__ src, double* __restrict__ pl
     __shared__ double sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sumsq[blockIdx.z], sh[0] + sh[1] + sh[2] + sh[3]);
+    // one atomic per workgroup, spread over EDS_SUMSQ_WAYS accumulators per level: 1 440 workgroups adding to ONE fp64 address
+    // serialise (17 us for a VGA level, measured); k_store_levels adds the accumulators up
+    if (threadIdx.x == 0) atomicAdd(&sumsq[blockIdx.z * EDS_SUMSQ_WAYS + ((blockIdx.y * gridDim.x + blockIdx.x) & (EDS_SUMSQ_WAYS - 1))],
+                                    sh[0] + sh[1] + sh[2] + sh[3]);
 }
 // level / ||level||_F -> fp32 in the handle's layout, one slot per level (padding and margin filled with the nearest border pixel)
 __global__ void k_store_levels(const double* __restrict__ planes, const double* __restrict__ sumsq, float* __restrict__ frames, int first_slot,
                                int H, int W, int Hp, int Wp, int tiled, int normalise) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
     if (c >= Wp - EDS_FRAME_MARGIN) return;
-    const double inv = normalise ? 1.0 / sqrt(sumsq[blockIdx.z]) : 1.0;     // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
+    double ss = 0.0;
+    for (int k = 0; k < EDS_SUMSQ_WAYS; ++k) ss += sumsq[blockIdx.z * EDS_SUMSQ_WAYS + k];      // wave-uniform, L2-resident
+    const double inv = normalise ? 1.0 / sqrt(ss) : 1.0;         // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
     const double v = planes[(size_t)blockIdx.z * H * W + (size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
     frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
 }
@@ -200,7 +206,7 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
         if (hipMalloc((void**)&fb.d_img, fb.img_elems * 8) != hipSuccess || hipMalloc((void**)&fb.d_tmp, fb.img_elems * 8) != hipSuccess)
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(frame accumulation)");
     }
-    if (!fb.d_norm && hipMalloc((void**)&fb.d_norm, 8 * EDS_MAX_LEVELS) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(norms)");
+    if (!fb.d_norm && hipMalloc((void**)&fb.d_norm, 8 * EDS_MAX_LEVELS * EDS_SUMSQ_WAYS) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(norms)");
     if (fb.plane_levels < nlevels) {
         if (fb.d_planes) hipFree(fb.d_planes);
         fb.d_planes = nullptr; fb.plane_levels = 0;
@@ -236,7 +242,7 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
         }
     }
     if (e == hipSuccess) e = hipMemsetAsync(fb.d_img, 0, ns * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 8 * EDS_MAX_LEVELS, st);
+    if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 8 * EDS_MAX_LEVELS * EDS_SUMSQ_WAYS, st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     if (n_events > 0)
         hipLaunchKernelGGL(k_vote, dim3((n_events + 255) / 256), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, fb.d_mapx, fb.d_mapy,
@@ -258,12 +264,14 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
                        h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    double ss[EDS_MAX_LEVELS];
-    e = hipMemcpyAsync(ss, fb.d_norm, 8 * nlevels, hipMemcpyDeviceToHost, st);
+    double ss[EDS_MAX_LEVELS * EDS_SUMSQ_WAYS];
+    e = hipMemcpyAsync(ss, fb.d_norm, 8 * nlevels * EDS_SUMSQ_WAYS, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     for (int i = 0; i < nlevels; ++i) {
-        if (norms_out) norms_out[i] = std::sqrt(ss[i]);
+        double t = 0.0;
+        for (int k = 0; k < EDS_SUMSQ_WAYS; ++k) t += ss[i * EDS_SUMSQ_WAYS + k];      // the order k_store_levels adds them in
+        if (norms_out) norms_out[i] = std::sqrt(t);
         h->slots[first_slot + i].has_frame = true;
     }
     return EDS_OK;
