@@ -403,7 +403,6 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         EDS12_STAMP(1);
         if (wave == 0) {                        // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
             const int mode = edsc::coop12_decide(sv, sums, work, s_pose, lane);          // linearisation if it was accepted,
-            for (int k = 1 + lane; k < (int)(sizeof(sums) / sizeof(double)); k += 64) reinterpret_cast<double*>(&sums)[k] = 0.0;
             if (lane == 0) {                    // and the bookkeeping up to the next step — a prepared one, if there is one
                 s_accept = work.accepted;
                 if (mode == edsc::M_RETURN) {
@@ -417,13 +416,25 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
         }
         __syncthreads();
+        // the sums are consumed: every thread clears its share for the next evaluation (the barrier that ends the solver phase orders
+        // this before the next sweep's atomics)
+        for (int k = 1 + tid; k < (int)(sizeof(sums) / sizeof(double)); k += nthr) reinterpret_cast<double*>(&sums)[k] = 0.0;
         while (s_walk == edsc::W_NEED) {        // no step prepared for this radius: EDS_NCAND wavefronts prepare the next ones side by side
+#ifdef EDS_FUSED_STAMPS
+#define EDS12_SOLVE_STAMP(k) do { if (tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); work.st[k] += n_ - work.st_t; work.st_t = n_; } } while (0)
+#else
+#define EDS12_SOLVE_STAMP(k) do { } while (0)
+#endif
+            EDS12_SOLVE_STAMP(2);               // bookkeeping + barrier
             if (wave < EDS_NCAND) {
                 edsc::coop12_propose(sv, wave, s_cand[wave], s_step[wave], lane);
+                EDS12_SOLVE_STAMP(3);           // factorisation, substitutions, model cost change, candidate point
                 if (edsc::uniform_int(s_cand[wave].valid))
                     edsc::coop_fill_pose_block(s_cand[wave].cp, s_cand[wave].cq, s_cand[wave].cv, s_G, nb, s_pb[wave], lane);
+                EDS12_SOLVE_STAMP(4);           // pose block
             }
             __syncthreads();
+            EDS12_SOLVE_STAMP(5);               // waiting for the slowest of the proposing wavefronts
             if (tid == 0) {
                 int k = 0, head = s_head;
                 s_walk = edsc::coop12_walk(sv, s_cand, &k, &head);
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     if (tid == 0 && blockIdx.x == 0) {
         printf("[stamps12] lane-0 cycles per evaluation: points %llu  reduce %llu  solver %llu  (%d evaluations, %d threads)\n",
                st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_n, NTHR);
-        printf("[stamps12]   solver split: decide %llu linearise %llu bookkeeping %llu cholesky %llu step %llu tail %llu pose %llu\n",
+        printf("[stamps12]   solver split: decide %llu linearise %llu bookkeeping %llu propose %llu poseblock %llu wait %llu walk+rest %llu\n",
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }
 #endif
