@@ -297,6 +297,13 @@ int solve_host(eds_trk* h, int level, int first, int count) {
 int materialise_residuals(eds_trk* h, int slot) {
     Slot& s = h->slots[slot];
     if (!s.res_on_device) return EDS_OK;
+    if (s.res_in_hostmap) {             // the kernel left a copy in pinned host memory: no HIP call at all
+        const float* r = h->h_rmap + (size_t)slot * h->Np;
+        s.residuals.resize(s.N);
+        for (int i = 0; i < s.N; ++i) s.residuals[i] = r[i];
+        s.res_on_device = false; s.res_in_hostmap = false;
+        return EDS_OK;
+    }
     EDS_HIP_TRY(hipSetDevice(h->dev));
     int rc = fetch_residuals(h, slot, 1);
     if (rc) return rc;
@@ -308,16 +315,17 @@ void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     void* dptrs[] = {h->dkf, h->dpose, h->dG, h->dpart, h->dncstat,
-                     h->dmhat, h->dframe, h->dr, h->dJ, h->dstage};
+                     h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
     eds_keyframe_free(&h->kf_build);
-    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r};
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev_stage) hipEventDestroy(h->ev_stage);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -325,22 +333,26 @@ void free_all(eds_trk* h) {
 }  // namespace
 
 // Row-major H x W host frame (double or float) -> the slot's frame in HBM.  The host only narrows to fp32 (a loop the compiler
-// vectorises; no index arithmetic) into pinned staging, in EDS_UPLOAD_CHUNKS pieces: the DMA of piece i runs while piece i + 1 is
-// being narrowed.  Tiling, padding and the replicated margin (= Grid2D's clamp) happen on the device (k_store_rowmajor).
-// (Round 1 built the tiled, margin-padded image element by element on one host thread: 300 us for 640x480, more than the solve.)
-#define EDS_UPLOAD_CHUNKS 4
+// vectorises; no index arithmetic) into device-mapped pinned staging, in EDS_UPLOAD_BANDS bands of rows; behind every band a
+// launch of k_store_rowmajor reads it over PCIe and writes tiles, padding and the replicated margin (= Grid2D's clamp), while
+// the host narrows the next band.  Nothing is waited for: whatever uses the frame is ordered behind the launches on the handle's
+// stream, and the staging buffer is private to this function (its event is waited for before the next frame overwrites it).
+// (Round 1 built the tiled, margin-padded image element by element on one host thread: 300 us for 640x480, more than the solve;
+// chunked hipMemcpyAsync into HBM + one tiling launch: 80 us, 30 of them after the host had finished.)
+#define EDS_UPLOAD_BANDS 4
 template <class T>
 static int upload_frame(eds_trk* h, int slot, const T* frame) {
-    const size_t n = (size_t)h->H * h->W;
-    float* stage = h->h_f32;                                     // h_f32_elems >= Hp * Wp >= H * W
-    for (int k = 0; k < EDS_UPLOAD_CHUNKS; ++k) {
-        const size_t b = n * k / EDS_UPLOAD_CHUNKS, e = n * (k + 1) / EDS_UPLOAD_CHUNKS;
+    float* stage = h->h_fstage;
+    if (h->stage_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_stage)); h->stage_busy = false; }   // the previous frame's reads (long done)
+    for (int k = 0; k < EDS_UPLOAD_BANDS; ++k) {
+        const int rb = h->H * k / EDS_UPLOAD_BANDS, re = h->H * (k + 1) / EDS_UPLOAD_BANDS;
+        const size_t b = (size_t)rb * h->W, e = (size_t)re * h->W;
         for (size_t i = b; i < e; ++i) stage[i] = (float)frame[i];
-        EDS_HIP_TRY(hipMemcpyAsync(h->dstage + b, stage + b, (e - b) * 4, hipMemcpyHostToDevice, h->st));
+        eds_frame_store_rowmajor(h, slot, h->d_fstage, rb, re);
     }
-    eds_frame_store_rowmajor(h, slot, h->dstage);
     EDS_HIP_TRY(hipGetLastError());
-    EDS_HIP_TRY(hipStreamSynchronize(h->st));                    // the staging buffer is reused by the next call
+    EDS_HIP_TRY(hipEventRecord(h->ev_stage, h->st));
+    h->stage_busy = true;
     h->slots[slot].has_frame = true;
     return EDS_OK;
 }
@@ -427,6 +439,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming);
     if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("stream/event: ") + hipGetErrorString(e)); }
     EDS_ALLOC(h->dkf, BN * 4 * EDS_KF_PLANES);
     h->dx = h->dkf + EDS_KF_X * BN; h->dy = h->dkf + EDS_KF_Y * BN; h->drho = h->dkf + EDS_KF_RHO * BN;
@@ -435,7 +448,6 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->dcell0 = reinterpret_cast<int*>(h->dkf + EDS_KF_CELL0 * BN);
     EDS_ALLOC(h->dmhat, BN * 4); EDS_ALLOC(h->dr, BN * 4); EDS_ALLOC(h->dJ, BN * 4 * 12);
     EDS_ALLOC(h->dframe, (size_t)batch * h->Hp * h->Wp * 4);
-    EDS_ALLOC(h->dstage, (size_t)H * W * 4);
     EDS_ALLOC(h->dpose, (size_t)batch * EDS_POSE_STRIDE * 8);
     EDS_ALLOC(h->dG, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
     EDS_ALLOC(h->dpart, (size_t)batch * h->max_seg * EDS_RED_K * 8);
@@ -446,6 +458,18 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->h_f32_elems = std::max((size_t)h->Hp * h->Wp, (size_t)h->Np * 12);
     EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
     EDS_HALLOC(h->h_r, BN * 4);
+    {   // mirror of the residual plane for the first few slots (EdsArrays::r_host)
+        const size_t nr = (size_t)std::min(batch, EDS_RHOST_SLOTS) * h->Np;
+        hipError_t e_ = hipHostMalloc((void**)&h->h_rmap, nr * 4, hipHostMallocMapped);
+        if (e_ == hipSuccess) e_ = hipHostGetDevicePointer((void**)&h->d_rmap, h->h_rmap, 0);
+        if (e_ != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("hipHostMalloc (residual mirror): ") + hipGetErrorString(e_)); }
+        std::memset(h->h_rmap, 0, nr * 4);
+    }
+    {   // device-mapped: the tiling kernel reads the staging buffer in place
+        hipError_t e_ = hipHostMalloc((void**)&h->h_fstage, (size_t)H * W * 4, hipHostMallocMapped);
+        if (e_ == hipSuccess) e_ = hipHostGetDevicePointer((void**)&h->d_fstage, h->h_fstage, 0);
+        if (e_ != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("hipHostMalloc (frame staging): ") + hipGetErrorString(e_)); }
+    }
     std::memset(h->h_pose, 0, (size_t)batch * EDS_POSE_STRIDE * 8);
     std::memset(h->h_G, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
     hipMemsetAsync(h->dcell0, 0, BN * 4, h->st);
@@ -632,6 +656,7 @@ int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {
     if (!frame) return fail(EDS_ERR_INVALID, "null output");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     const size_t n = (size_t)h->Hp * h->Wp;
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));                    // set_event_frame does not wait for its own upload
     EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dframe + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
     for (int r = 0; r < h->H; ++r)
         for (int c = 0; c < h->W; ++c) frame[(size_t)r * h->W + c] = h->h_f32[eds_frame_index(r, c, h->Wp, h->tiled)];

@@ -150,18 +150,23 @@ __global__ void k_store_levels(const double* __restrict__ planes, const double* 
     frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
 }
 
-// row-major H x W fp32 image -> the handle's frame layout (tiles, padding and margin filled with the nearest border pixel)
-__global__ void k_store_rowmajor(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Hp, int Wp, int tiled) {
-    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+// row-major H x W fp32 image -> the handle's frame layout (tiles, padding and margin filled with the nearest border pixel): the
+// destination rows [r_lo, r_lo + gridDim.y), logical coordinates.  `src` may be device-mapped pinned host memory (set_event_frame
+// reads its staging buffer over PCIe, a band of rows per launch, while the host narrows the next band).
+__global__ void k_store_rowmajor(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Hp, int Wp, int tiled, int r_lo) {
+    const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y + r_lo;
     if (c >= Wp - EDS_FRAME_MARGIN) return;
     dst[eds_frame_index(r, c, Wp, tiled)] = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
 }
 
 }  // namespace
 
-void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src) {
-    hipLaunchKernelGGL(k_store_rowmajor, dim3((h->Wp + 255) / 256, h->Hp), dim3(256), 0, h->st, d_src, h->dframe + (size_t)slot * h->Hp * h->Wp,
-                       h->H, h->W, h->Hp, h->Wp, h->tiled);
+// source rows [row_b, row_e) (and, with them, the margin / padding rows that replicate row 0 or row H - 1)
+void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e) {
+    const int lo = row_b <= 0 ? -EDS_FRAME_MARGIN : row_b, hi = row_e >= h->H ? h->Hp - EDS_FRAME_MARGIN : row_e;
+    if (hi <= lo) return;
+    hipLaunchKernelGGL(k_store_rowmajor, dim3((h->Wp + 255) / 256, hi - lo), dim3(256), 0, h->st, d_src,
+                       h->dframe + (size_t)slot * h->Hp * h->Wp, h->H, h->W, h->Hp, h->Wp, h->tiled, lo);
 }
 
 void eds_frame_free(EdsFrameBuffers* fb) {

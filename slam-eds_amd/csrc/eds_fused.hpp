@@ -53,6 +53,7 @@ struct EdsFusedBuffers {
     unsigned ticket_base = 0;               // tickets handed out by earlier team launches (the device counter is never reset)
     bool team_disabled = false;             // a team once timed out on this handle
     int pending_team = 1, pending_level = 0;
+    bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (EdsArrays::r_host)
     int B = 0;
     int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
     double launch_wall_us = 0.0;
@@ -87,7 +88,7 @@ struct EdsFrameBuffers {
     int cap_events = 0;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
-void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src);     // row-major fp32 H x W in HBM -> the slot's tiled frame
+void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e);     // row-major fp32 H x W in HBM -> the slot's tiled frame
 int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
 int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
                             const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out);

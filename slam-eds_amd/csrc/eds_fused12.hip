@@ -454,7 +454,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         ++st_n;
 #endif
         if (s_accept) {                         // the candidate became the accepted point: its residuals are the ones to keep
-            for (int i = lo + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];    // each thread copies what it wrote itself
+            for (int i = lo + tid; i < hi; i += nthr) {    // each thread copies what it wrote itself
+                const float v = A.mhat[base + i];
+                A.r[base + i] = v;
+                if (A.r_host) A.r_host[base + i] = v;
+            }
         }
         if (s_state == 2) break;
     }
@@ -499,7 +503,9 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
     hipError_t e = hipSuccess;           // (start states and results: pinned host memory the kernel accesses directly, eds_fused_alloc)
-    const EdsArrays A = h->arrays();
+    EdsArrays A = h->arrays();
+    fb.pending_host_r = h->d_rmap && first + count <= EDS_RHOST_SLOTS;      // as eds_fused_solve
+    if (fb.pending_host_r) A.r_host = h->d_rmap;
     // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads,
     // 96 KB patch cache — the lower latency (0.28 ms for one 2 000-point alignment, 7.0 M LM iterations/s at 256).
     // Beyond that, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase
@@ -584,7 +590,7 @@ int eds_fused12_collect(eds_trk* h) {
         const EdsFused12Out& O = fb.h_out12[s];
         const bool ok = O.failed == 0;
         if (ok) { std::memcpy(sl.p, O.p, sizeof(sl.p)); std::memcpy(sl.q, O.q, sizeof(sl.q)); std::memcpy(sl.v, O.v, sizeof(sl.v)); }
-        sl.res_on_device = ok;
+        sl.res_on_device = ok; sl.res_in_hostmap = ok && fb.pending_host_r;
         sl.trace_on_device = false;
         sl.residuals.clear();
         sl.ntrace = 0;

@@ -21,6 +21,7 @@ struct Slot {
     std::vector<double> tr_xi, tr_cost;
     std::vector<int32_t> tr_acc;
     bool res_on_device = false;     // residuals of the last solve still only in HBM
+    bool res_in_hostmap = false;    // ... and mirrored in the handle's pinned h_rmap by the kernel that produced them (small launches)
     bool trace_on_device = false;   // trace of the last solve still only in HBM
 };
 
@@ -38,7 +39,6 @@ struct eds_trk {
     float *df0x = nullptr, *df0y = nullptr;
     int* dcell0 = nullptr;
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
-    float* dstage = nullptr;            // one row-major H x W fp32 frame: landing area of set_event_frame's chunked upload
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
     EdsPointBuffers point_ops;
@@ -46,6 +46,10 @@ struct eds_trk {
     // pinned host staging
     double *h_pose = nullptr, *h_part = nullptr, *h_G = nullptr;
     float *h_f32 = nullptr, *h_r = nullptr;
+    float *h_fstage = nullptr, *d_fstage = nullptr;   // pinned, device-mapped H x W fp32: set_event_frame narrows into it; nobody else writes it
+    hipEvent_t ev_stage = nullptr;      // recorded behind the last copy out of h_fstage
+    float *h_rmap = nullptr, *d_rmap = nullptr;       // pinned, device-mapped [min(B, EDS_RHOST_SLOTS)][Np]: EdsArrays::r_host
+    bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
     size_t h_f32_elems = 0;
     std::vector<Slot> slots;
 
@@ -54,7 +58,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.r_host = nullptr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

@@ -20,12 +20,16 @@ struct EdsArrays {
     double* G;           // [B][EDS_MAX_BLOCKS][36]
     // per-pass outputs
     float* r;            // [B][Np]
+    float* r_host;       // nullable: device-mapped pinned mirror of r for slots < EDS_RHOST_SLOTS — the persistent kernels store the
+                         // kept residuals there as well when a launch is small enough that fetching them would cost a copy call
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
     double* ncstat;      // [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC block statistics (eds_layout.hpp)
     int B, Np, H, W, max_seg;
     int Hp, Wp, tiled;   // frame allocation: padded to multiples of 4; 4x4-tiled or row-major (eds_device.hpp FrameView)
 };
+
+#define EDS_RHOST_SLOTS 8
 
 void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st);
 void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st);

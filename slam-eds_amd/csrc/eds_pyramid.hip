@@ -90,6 +90,8 @@ int eds_pyr_set_keyframe(eds_pyr* p, int level, int N, const double* norm_xy, co
 }
 
 static int build_levels(eds_pyr* p) {
+    if (hipStreamSynchronize(p->lv[0]->st) != hipSuccess)          // level 0 was written on ITS handle's stream (set_event_frame returns early)
+        return eds_internal_fail(EDS_ERR_HIP, "level-0 frame upload failed");
     for (int l = 1; l < p->levels; ++l) {
         eds_trk* s = p->lv[l - 1];
         eds_trk* d = p->lv[l];
