@@ -70,7 +70,8 @@ void fill_static(const eds_trk* h, int slot) {
     pb[EDS_PB_NCMODE] = h->cfg.nc ? 1.0 : 0.0;
 }
 
-void fill_pose(const eds_trk* h, int slot, const double* p, const double* q, const double* v) {
+void fill_pose(eds_trk* h, int slot, const double* p, const double* q, const double* v) {
+    if (h->gram_pending) { hipStreamSynchronize(h->st); h->gram_pending = false; }      // h_G as set_idepth's launch left it
     fill_static(h, slot);
     edsm::fill_pose_block(p, q, v, h->h_G + (size_t)slot * EDS_MAX_BLOCKS * 36, effective_blocks(h),
                           h->h_pose + (size_t)slot * EDS_POSE_STRIDE);
@@ -321,11 +322,12 @@ void free_all(eds_trk* h) {
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
     eds_keyframe_free(&h->kf_build);
-    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap};
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap, h->h_idp};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_stage) hipEventDestroy(h->ev_stage);
+    if (h->ev_idp) hipEventDestroy(h->ev_idp);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -440,6 +442,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_idp, hipEventDisableTiming);
     if (e != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("stream/event: ") + hipGetErrorString(e)); }
     EDS_ALLOC(h->dkf, BN * 4 * EDS_KF_PLANES);
     h->dx = h->dkf + EDS_KF_X * BN; h->dy = h->dkf + EDS_KF_Y * BN; h->drho = h->dkf + EDS_KF_RHO * BN;
@@ -458,6 +461,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->h_f32_elems = std::max((size_t)h->Hp * h->Wp, (size_t)h->Np * 12);
     EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
     EDS_HALLOC(h->h_r, BN * 4);
+    EDS_HALLOC(h->h_idp, (size_t)h->Np * 4);
     {   // mirror of the residual plane for the first few slots (EdsArrays::r_host)
         const size_t nr = (size_t)std::min(batch, EDS_RHOST_SLOTS) * h->Np;
         hipError_t e_ = hipHostMalloc((void**)&h->h_rmap, nr * 4, hipHostMallocMapped);
@@ -552,7 +556,7 @@ static int upload_points(eds_trk* h, int slot, int N, const double* norm_xy, con
     return EDS_OK;
 }
 
-static int refresh_gram(eds_trk* h, int slot) {
+static int refresh_gram(eds_trk* h, int slot, bool wait = true) {
     fill_static(h, slot);
     int rc = upload_pose(h, slot, 1);
     if (rc) return rc;
@@ -560,7 +564,8 @@ static int refresh_gram(eds_trk* h, int slot) {
     EDS_HIP_TRY(hipGetLastError());
     const size_t off = (size_t)slot * EDS_MAX_BLOCKS * 36;
     EDS_HIP_TRY(hipMemcpyAsync(h->h_G + off, h->dG + off, (size_t)EDS_MAX_BLOCKS * 36 * 8, hipMemcpyDeviceToHost, h->st));
-    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    if (wait) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); h->gram_pending = false; }
+    else h->gram_pending = true;        // the device solvers read dG on the stream; host readers of h_G wait in fill_pose
     return EDS_OK;
 }
 
@@ -591,9 +596,13 @@ int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) {
     if (N != s.N || !idp) return fail(EDS_ERR_INVALID, "idp size mismatch");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     // only the inverse-depth plane changes (the geometry uses rho' = idp + 1e-5, the model the raw idp)
-    for (int i = 0; i < h->Np; ++i) h->h_f32[i] = i < N ? (float)idp[i] : 1.f;
-    EDS_HIP_TRY(hipMemcpyAsync(h->drho + (size_t)slot * h->Np, h->h_f32, (size_t)h->Np * 4, hipMemcpyHostToDevice, h->st));
-    return refresh_gram(h, slot);
+    // (Tracker.cpp:167 re-reads the depths on every optimize: this is on the live path, so nothing here waits for the GPU)
+    if (h->idp_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_idp)); h->idp_busy = false; }
+    for (int i = 0; i < h->Np; ++i) h->h_idp[i] = i < N ? (float)idp[i] : 1.f;
+    EDS_HIP_TRY(hipMemcpyAsync(h->drho + (size_t)slot * h->Np, h->h_idp, (size_t)h->Np * 4, hipMemcpyHostToDevice, h->st));
+    EDS_HIP_TRY(hipEventRecord(h->ev_idp, h->st));
+    h->idp_busy = true;
+    return refresh_gram(h, slot, false);
 }
 
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame) {

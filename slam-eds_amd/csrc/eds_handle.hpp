@@ -49,6 +49,10 @@ struct eds_trk {
     float *h_fstage = nullptr, *d_fstage = nullptr;   // pinned, device-mapped H x W fp32: set_event_frame narrows into it; nobody else writes it
     hipEvent_t ev_stage = nullptr;      // recorded behind the last copy out of h_fstage
     float *h_rmap = nullptr, *d_rmap = nullptr;       // pinned, device-mapped [min(B, EDS_RHOST_SLOTS)][Np]: EdsArrays::r_host
+    float* h_idp = nullptr;             // pinned [Np]: set_idepth narrows into it (private, like h_fstage)
+    hipEvent_t ev_idp = nullptr;
+    bool idp_busy = false;
+    bool gram_pending = false;          // h_G's refresh is still in flight on the stream (set_idepth does not wait for it)
     bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
     size_t h_f32_elems = 0;
     std::vector<Slot> slots;
