@@ -69,7 +69,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ int s_ticket;
-    __shared__ unsigned s_xchg[EDS_TEAM_MAX][EDS_TEAM_GRANULES];
+    __shared__ unsigned s_xchg[TEAM > 1 ? TEAM : 1][EDS_TEAM_GRANULES];
     __shared__ int s_timeout;
     int team_slot = blockIdx.x, member = 0;
     if (TEAM > 1) {
@@ -329,51 +329,54 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP2(2);
         if (spec_mode) {
             // ---- damped solver with prepared candidates (eds_solver6_spec.hpp); decisions as edss::Solver6::on_eval takes them ----
+            if (TEAM > 1) {
+                // Exchange of the partial sums.  Wavefront 0 adds the workgroup's eight partials and publishes them: lane t < 28
+                // writes its double as two tagged 8-byte granules (sc1 stores).  Wavefront w gathers the granules of members
+                // w, w + 8, ... (own member included: every member then adds the same numbers in the same order) — the members sit
+                // on different XCDs (consecutive workgroup ids), so a poll is a fabric round trip, and K of them in a row on one
+                // wavefront were most of the exchange.
+                const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
+                unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * (TEAM * EDS_TEAM_GRANULES);
+                if (wave == 0 && lane < EDS_RED_N6) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)s_red[wv][lane];
+                    const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+                    __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xffffffffull),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                for (int m = wave; m < TEAM; m += nthr >> 6) {
+                    if (lane < 2 * EDS_RED_N6) {
+                        const unsigned long long* g = mb + m * EDS_TEAM_GRANULES + lane;
+                        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while ((unsigned)(v >> 32) != tag) {
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        s_xchg[m][lane] = (unsigned)v;
+                    }
+                }
+                ++pass_no;
+                __syncthreads();
+            }
             if (wave == 0) {
                 double s = 0.0;
                 if (lane < EDS_RED_N6) {
-                    float part[EDS_FUSED_MAX_WAVES];
-#pragma unroll
-                    for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) part[wv] = s_red[wv][lane];
-#pragma unroll
-                    for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)part[wv];
-                }
-                if (TEAM > 1) {
-                    // publish this member's partial sums: lane t < 28 writes its double as two tagged 8-byte granules (sc1 stores)
-                    const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
-                    unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * (TEAM * EDS_TEAM_GRANULES);
-                    if (lane < EDS_RED_N6) {
-                        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
-                        __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xffffffffull),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    // gather all members' granules (own included: every member then adds the same numbers in the same order)
-                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-                    for (int m = 0; m < TEAM; ++m) {
-                        if (lane < 2 * EDS_RED_N6) {
-                            const unsigned long long* g = mb + m * EDS_TEAM_GRANULES + lane;
-                            unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            while ((unsigned)(v >> 32) != tag) {
-                                if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
-                                __builtin_amdgcn_s_sleep(2);
-                                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            s_xchg[m][lane] = (unsigned)v;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    s = 0.0;
-                    if (lane < EDS_RED_N6) {
+                    if (TEAM > 1) {
 #pragma unroll
                         for (int m = 0; m < TEAM; ++m)
                             s += __longlong_as_double((long long)(((unsigned long long)s_xchg[m][2 * lane + 1] << 32) | s_xchg[m][2 * lane]));
+                    } else {
+                        float part[EDS_FUSED_MAX_WAVES];
+#pragma unroll
+                        for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) part[wv] = s_red[wv][lane];
+#pragma unroll
+                        for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)part[wv];
                     }
-                    ++pass_no;
                 }
                 EDS_STAMP(2);
                 EDS_STAMP2(3);
@@ -634,17 +637,25 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch)
     // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
-    // solves with register-resident points only; 4 CUs up to 64 alignments of more than 1 024 points, 2 CUs up to 128.
+    // solves with register-resident points only.  Up to 2 048 points: 4 CUs (512 points each) up to 64 alignments, 2 CUs up to 128.
+    // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
+    // (16 000 points: 0.52 ms on one CU).
     int team = 1;
-    if (!stream && damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512 && maxN <= 2048) {
+    const bool team_ok = damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512;
+    if (team_ok && maxN <= 2048) {
         if (count <= 64 && maxN > 1024) team = 4;
         else if (count <= EDS_TEAM_SLOTS) team = 2;
+    } else if (team_ok && maxN <= 1024 * EDS_TEAM6_MAX) {
+        const int k = maxN <= 4096 ? 4 : (maxN <= 8192 ? 8 : 16);
+        if (count * k <= 256) team = k;             // every member on a CU of its own
     }
-    if (const char* ev = getenv("EDS_LM6_TEAM")) {                    // tuning knob: 1 | 2 | 4
+    if (const char* ev = getenv("EDS_LM6_TEAM")) {                    // tuning knob: 1 | 2 | 4 | 8 | 16
         const int v = atoi(ev);
-        const bool feasible = !stream && damped == 1 && iters > 0 && count <= EDS_TEAM_SLOTS && maxN <= 2048;
-        if (v == 1 || ((v == 2 || v == 4) && feasible)) team = v;
+        const bool feasible = damped == 1 && iters > 0 && count <= EDS_TEAM_SLOTS && count * v <= EDS_TEAM_MEMBERS &&
+                              (v == 2 || v == 4 || v == 8 || v == 16) && maxN <= (v == 2 ? 2048 : 1024 * v);
+        if (v == 1 || feasible) team = v;
     }
+    if (team > 1) { stream = false; wide = false; }
     if (team > 1) {
         if (++fb.epoch >= (1u << 24)) {              // tags are (epoch << 8 | pass): start over with clean mailboxes
             hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
@@ -653,7 +664,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
     // few alignments: the kernel also stores the kept residuals into pinned host memory (8 KB each over PCIe, posted writes), so
     // that Tracker.cpp:223-230's read-back costs no copy call; the register-resident and streaming variants honour it
-    fb.pending_host_r = h->d_rmap && first + count <= EDS_RHOST_SLOTS && (stream || ppt > 0);
+    fb.pending_host_r = h->d_rmap && first + count <= EDS_RHOST_SLOTS && (stream || ppt > 0 || team > 1);
     if (fb.pending_host_r) A.r_host = h->d_rmap;
     fb.pending_team = team; fb.pending_level = level;
     const unsigned ticket_base = fb.ticket_base;
@@ -662,10 +673,16 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
         const bool q = bic && count * team >= 128;   // enough gathers in flight for the quad-cooperative form to pay
-        if (team == 4) {                             // 512 points per member, one per lane
+        if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
             if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_TEAM(1, 1, 0, 4);
-        } else {                                     // 1 024 points per member, two per lane
+        } else if (team == 2) {                      // 1 024 points per member, two per lane
             if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 2); else EDS_LAUNCH_TEAM(0, 2, 0, 2); } else EDS_LAUNCH_TEAM(1, 2, 0, 2);
+        } else if (team == 4) {                      // 1 024 points per member from here on
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 4); else EDS_LAUNCH_TEAM(0, 2, 0, 4); } else EDS_LAUNCH_TEAM(1, 2, 0, 4);
+        } else if (team == 8) {
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 8); else EDS_LAUNCH_TEAM(0, 2, 0, 8); } else EDS_LAUNCH_TEAM(1, 2, 0, 8);
+        } else {
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 16); else EDS_LAUNCH_TEAM(0, 2, 0, 16); } else EDS_LAUNCH_TEAM(1, 2, 0, 16);
         }
     } else if (stream) {
         eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);

@@ -177,6 +177,42 @@ def test_team_kernel_vs_oracle_and_single_cu(gpu, capi, synth, po, monkeypatch, 
                 assert rk[b].shape == (a.N,) and np.abs(rk[b] - er).max() <= 1e-5 * np.abs(er).max()
 
 
+@pytest.mark.parametrize("team,sizes", [(4, (2049, 3000, 4096)), (8, (4097, 7000, 8000)), (16, (8193, 12345, 16000))])
+def test_large_point_sets_run_on_teams_of_1024_points(gpu, capi, synth, po, monkeypatch, team, sizes):
+    """More than 2 048 points (configs[2], the finer levels of configs[3]): with few alignments per launch optimize picks 4, 8 or 16
+    CUs of 1 024 points each instead of one CU streaming them all.  The rule's own choice (no override) must agree with the oracle
+    and with the one-CU streaming kernel (EDS_LM6_TEAM=1), on ragged counts (last member nearly empty or full), with and without
+    the per-point Huber weight; residuals arrive through the pinned mirror."""
+    als = [synth.make_alignment(7400 + b, H=480, W=640, N=n) for b, n in enumerate(sizes)]
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    for tau in (0.0, 0.01):
+        res = {}
+        for k in (1, 0):
+            if k: monkeypatch.setenv("EDS_LM6_TEAM", str(k))
+            else: monkeypatch.delenv("EDS_LM6_TEAM", raising=False)
+            h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=10, huber_tau=tau),
+                            len(als), max(sizes), 480, 640)
+            for b, a in enumerate(als):
+                h.set_alignment(b, a)
+            out = []
+            for b, a in enumerate(als):          # one alignment per launch: the latency regime
+                h.set_state(b, ps, qs, a.v0)
+                h.optimize_batch(0, b, 1)
+                out.append((h.results(b, 1)[0], h.residuals(b), h.trace(b)))
+            res[k] = out
+            h.close()
+        for b, a in enumerate(als):
+            (t1, r1, tr1), (tk, rk, trk) = res[1][b], res[0][b]
+            ref = po.Oracle(a).pose6_lm(ps, qs, a.v0, iters=10, lambda0=0.01, huber_tau=tau)
+            assert tk[15] == 1.0 and tk[14] == 10
+            assert np.array_equal(trk["accepted"], ref["accepted"]) and np.array_equal(trk["accepted"], tr1["accepted"])
+            assert po.se3_distance(tk[0:3], tk[3:7], ref["p"], ref["q"]) <= TOL_POSE
+            assert po.se3_distance(tk[0:3], tk[3:7], t1[0:3], t1[3:7]) <= 1e-6
+            er = po.Oracle(a).pose6_eval(tk[0:3], tk[3:7], a.v0)["r"]
+            assert rk.shape == (a.N,) and np.abs(rk - er).max() <= 1e-5 * np.abs(er).max()
+            assert np.abs(r1 - er).max() <= 1e-5 * np.abs(er).max()
+
+
 def test_team_launches_back_to_back_and_in_sub_ranges(gpu, capi, synth, po, monkeypatch):
     """Granule tags carry the launch number: 40 team launches in a row on one handle (different sub-ranges, so a slot's mailbox
     is re-used by other alignments) keep returning the single-CU result."""
