@@ -28,7 +28,6 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 };
 
 // ---- teams: several workgroups (CUs) per alignment, partial sums exchanged as tagged 8-byte granules (eds_fused.hip) -----------
-#define EDS_TEAM_MAX 4
 #define EDS_TEAM_GRANULES 64                      // LM6, per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
 #define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
 #define EDS_TEAM6_MAX 16                          // LM6: up to 16 CUs per alignment (16 384 points)
@@ -37,8 +36,9 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 #define EDS_TEAM_MAIL_BYTES ((size_t)EDS_TEAM_MEMBERS * 2 * EDS_TEAM_GRANULES * 8)
 #define EDS_TEAM12_VALUES 157                     // REF12, per residual block: ||r||^2, J^T J (144), J^T r (12)
 #define EDS_TEAM12_GRANULES 2560                  // per member and parity: 2 x 157 x 8 blocks = 2 512, padded
-#define EDS_TEAM12_SLOTS 64
-#define EDS_TEAM12_MAIL_BYTES ((size_t)EDS_TEAM12_SLOTS * 2 * EDS_TEAM_MAX * EDS_TEAM12_GRANULES * 8)
+#define EDS_TEAM12_SLOTS 64                       // a REF12 team launch holds at most this many alignments ...
+#define EDS_TEAM12_MEMBERS 256                    // ... and at most this many workgroups (alignments x team size, up to 16 CUs each)
+#define EDS_TEAM12_MAIL_BYTES ((size_t)EDS_TEAM12_MEMBERS * 2 * EDS_TEAM12_GRANULES * 8)
 
 struct EdsFusedBuffers {
     EdsFusedIn* d_in = nullptr;             // device-side addresses of the pinned h_in / h_out / h_out12 below

@@ -374,22 +374,28 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             for (int e = tid; e < nval; e += nthr) {
+                // all 2 K granules of the entry in flight at once (the members sit on other XCDs: every load is a fabric round trip,
+                // and 2 K of them one after the other were ~4 us per evaluation), then only the late ones are polled again
                 double tot = 0.0;
+                constexpr int GM = TEAM < 4 ? TEAM : 4;             // members per round of loads
 #pragma unroll
-                for (int m = 0; m < TEAM; ++m) {
-                    unsigned half[2];
+                for (int m0 = 0; m0 < TEAM; m0 += GM) {
+                    unsigned long long v[2 * GM];
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const unsigned long long* g = mb + (size_t)m * EDS_TEAM12_GRANULES + 2 * e + hh;
-                        unsigned long long v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while ((unsigned)(v >> 32) != tag) {
+                    for (int k = 0; k < 2 * GM; ++k)
+                        v[k] = __hip_atomic_load(mb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int k = 0; k < 2 * GM; ++k) {
+                        const unsigned long long* g = mb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1);
+                        while ((unsigned)(v[k] >> 32) != tag) {
                             if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
                             __builtin_amdgcn_s_sleep(2);
-                            v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        half[hh] = (unsigned)v;
                     }
-                    tot += __longlong_as_double((long long)(((unsigned long long)half[1] << 32) | half[0]));
+#pragma unroll
+                    for (int m = 0; m < GM; ++m)
+                        tot += __longlong_as_double((long long)(((v[2 * m + 1] & 0xffffffffull) << 32) | (v[2 * m] & 0xffffffffull)));
                 }
                 *entry(e) = tot;
             }
@@ -520,10 +526,14 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     int maxN = 0;
     for (int s = first; s < first + count; ++s) maxN = std::max(maxN, h->slots[s].N);
     int team = 1;
-    if (wide && !h->cfg.nc && !fb.team_disabled && maxN > 512 && count <= EDS_TEAM12_SLOTS) team = (count <= 64 && maxN > 1024) ? 4 : 2;
-    if (const char* ev = getenv("EDS_REF12_TEAM")) {                  // tuning knob: 1 | 2 | 4
+    if (wide && !h->cfg.nc && !fb.team_disabled && maxN > 512 && count <= EDS_TEAM12_SLOTS) {
+        team = (count <= 64 && maxN > 1024) ? 4 : 2;
+        if (maxN > 8192 && count * 16 <= EDS_TEAM12_MEMBERS) team = 16;          // the finer pyramid levels (configs[2..3]): ~1 000 points per CU
+        else if (maxN > 4096 && count * 8 <= EDS_TEAM12_MEMBERS) team = 8;
+    }
+    if (const char* ev = getenv("EDS_REF12_TEAM")) {                  // tuning knob: 1 | 2 | 4 | 8 | 16
         const int v = atoi(ev);
-        if (v == 1 || ((v == 2 || v == 4) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS)) team = v;
+        if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS && count * v <= EDS_TEAM12_MEMBERS)) team = v;
     }
     if (team > 1) {
         if (!fb.d_mail12) {
@@ -550,7 +560,9 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
     bool quad = bicubic && count >= 1024;          // measured: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
-    if (team == 4) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
+    if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }
+    else if (team == 8) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 8, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 8, 0); }
+    else if (team == 4) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
     else if (team == 2) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 2, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 2, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 2, 0); }
     else if (wide) { if (bicubic) { if (quad) EDS_LAUNCH12(0, 512, 1408, 1); else EDS_LAUNCH12(0, 512, 1408, 0); } else EDS_LAUNCH12(1, 512, 1408, 0); }
     else { if (bicubic) { if (quad) EDS_LAUNCH12(0, 256, 320, 1); else EDS_LAUNCH12(0, 256, 320, 0); } else EDS_LAUNCH12(1, 256, 320, 0); }

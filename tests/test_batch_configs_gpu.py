@@ -264,3 +264,31 @@ def test_ref12_team_kernel_vs_oracle(gpu, capi, synth, po, monkeypatch, team):
             e = po.Oracle(a, num_blocks=nb, sampling=sampling).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
             assert np.abs(r - e).max() <= 2e-5 * np.abs(e).max()
         h.close()
+
+
+@pytest.mark.parametrize("n_points,nb,loss", [(5000, 1, 0), (8000, 4, 1), (12345, 1, 0), (16000, 3, 2)])
+def test_ref12_large_point_sets_run_on_teams_of_8_and_16(gpu, capi, synth, po, monkeypatch, n_points, nb, loss):
+    """The reference problem on more than 4 096 / 8 192 points in the latency regime: optimize picks 8 / 16 CUs per alignment
+    (no override).  Iteration counts, termination, pose, velocity, cost and residuals against the oracle's Ceres-LM restatement, and
+    the same solve on one CU (EDS_REF12_TEAM=1)."""
+    a = synth.make_alignment(7500 + n_points, H=480, W=640, N=n_points, start="ctor")
+    cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=nb, loss_type=loss, loss_param=0.3)
+    out = {}
+    for k in (0, 1):
+        if k: monkeypatch.setenv("EDS_REF12_TEAM", str(k))
+        else: monkeypatch.delenv("EDS_REF12_TEAM", raising=False)
+        h = capi.Handle(cfg, 1, n_points, 480, 640)
+        h.set_alignment(0, a)
+        h.optimize_batch(0, 0, 1)
+        out[k] = (h.results(0, 1)[0], h.info(0), h.residuals(0))
+        h.close()
+    ref = po.Oracle(a, num_blocks=nb, loss_type=loss, loss_param=0.3, max_num_iterations=10).solve_lm(a.p0, a.q0, a.v0)
+    for k in (0, 1):
+        tab, info, r = out[k]
+        assert info["num_iterations"] == ref["num_iterations"] and info["num_successful_steps"] == ref["num_successful_steps"], k
+        assert info["termination"] == ref["termination"]
+        assert po.se3_distance(tab[0:3], tab[3:7], ref["p"], ref["q"]) <= TOL_POSE
+        assert np.abs(tab[7:13] - ref["v"]).max() <= 1e-4
+        assert tab[13] == pytest.approx(ref["final_cost"], rel=1e-5)
+        e = po.Oracle(a, num_blocks=nb).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
+        assert np.abs(r - e).max() <= 2e-5 * np.abs(e).max()
