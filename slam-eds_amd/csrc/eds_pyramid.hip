@@ -38,6 +38,7 @@ struct eds_pyr {
     eds_trk* lv[EDS_MAX_LEVELS] = {nullptr};
     double K0[4] = {0, 0, 0, 0};
     bool has_frame = false;
+    hipEvent_t ev_levels = nullptr;     // recorded behind the last down-sampling launch
 };
 
 extern "C" {
@@ -54,6 +55,11 @@ int eds_pyr_create(const eds_trk_cfg* cfg, int levels, const int* max_points, in
         int rc = eds_trk_create(cfg, 1, max_points[l], H >> l, W >> l, &p->lv[l]);
         if (rc != EDS_OK) { for (int k = 0; k < l; ++k) eds_trk_destroy(p->lv[k]); delete p; return rc; }
     }
+    if (hipEventCreateWithFlags(&p->ev_levels, hipEventDisableTiming) != hipSuccess) {
+        for (int k = 0; k < levels; ++k) eds_trk_destroy(p->lv[k]);
+        delete p;
+        return eds_internal_fail(EDS_ERR_HIP, "hipEventCreate");
+    }
     *out = p;
     return EDS_OK;
 }
@@ -61,6 +67,7 @@ int eds_pyr_create(const eds_trk_cfg* cfg, int levels, const int* max_points, in
 void eds_pyr_destroy(eds_pyr* p) {
     if (!p) return;
     for (int l = 0; l < p->levels; ++l) eds_trk_destroy(p->lv[l]);
+    if (p->ev_levels) hipEventDestroy(p->ev_levels);
     delete p;
 }
 
@@ -89,21 +96,26 @@ int eds_pyr_set_keyframe(eds_pyr* p, int level, int N, const double* norm_xy, co
     return eds_trk_set_keyframe(p->lv[level], 0, N, norm_xy, grad_xy, idp, w, K[0], K[1], K[2], K[3]);
 }
 
+// Levels 1 .. L-1 from level 0, all on level 0's stream (whatever wrote level 0 — set_event_frame's band launches, the event-frame
+// builder — is on that stream too), one launch behind the other; the other levels' streams then wait for ONE event.  The host
+// waits for nothing: a level's solve is ordered behind its frame on the level's own stream.
 static int build_levels(eds_pyr* p) {
-    if (hipStreamSynchronize(p->lv[0]->st) != hipSuccess)          // level 0 was written on ITS handle's stream (set_event_frame returns early)
-        return eds_internal_fail(EDS_ERR_HIP, "level-0 frame upload failed");
+    hipStream_t st0 = p->lv[0]->st;
+    hipError_t e = hipSetDevice(p->lv[0]->dev);
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     for (int l = 1; l < p->levels; ++l) {
         eds_trk* s = p->lv[l - 1];
         eds_trk* d = p->lv[l];
-        hipError_t e = hipSetDevice(d->dev);
-        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
         const dim3 b(32, 8), g((d->Wp + 31) / 32, (d->Hp + 7) / 8);
-        hipLaunchKernelGGL(k_pyr_down, g, b, 0, d->st, s->dframe, s->Wp, s->tiled, d->dframe, d->H, d->W, d->Hp, d->Wp, d->tiled);
-        e = hipStreamSynchronize(d->st);                           // the next level reads this one from its own stream
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+        hipLaunchKernelGGL(k_pyr_down, g, b, 0, st0, s->dframe, s->Wp, s->tiled, d->dframe, d->H, d->W, d->Hp, d->Wp, d->tiled);
         d->slots[0].has_frame = true;
     }
+    e = hipGetLastError();
+    if (e == hipSuccess && p->levels > 1) {
+        e = hipEventRecord(p->ev_levels, st0);
+        for (int l = 1; l < p->levels && e == hipSuccess; ++l) e = hipStreamWaitEvent(p->lv[l]->st, p->ev_levels, 0);
+    }
+    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     p->has_frame = true;
     return EDS_OK;
 }
