@@ -212,7 +212,33 @@ def latency_block(capi, synth, al, a):
         h.loss_param(0, capi.LP_MAD)
         h.update_points(0, False)
     out["slice_ms"] = med(one_slice)
+
+    # the same call as the drop-in shim makes it (Tracker::optimize with a HOST fp64 frame): depths, frame upload, solve,
+    # residuals, MAD loss scale, residuals again (the MAD reorders them)
+    frame64 = np.ascontiguousarray(al.frame, dtype=np.float64)
+    idp64 = np.ascontiguousarray(al.idp, dtype=np.float64)
+
+    def live_call():
+        h.set_idepth(0, idp64)
+        h.set_event_frame(0, frame64)
+        h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+        h.residuals(0)
+        h.loss_param(0, capi.LP_MAD)
+        h.residuals(0)
+    out["live_call_ref12_ms"] = med(live_call)
+    out["live_call_ref12_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
     h.close()
+
+    # configs[3]: one coarse-to-fine call, 4 levels of one scene, 2 000 -> 16 000 points, the pose carried on
+    counts = [16000, 8000, 4000, 2000]
+    alp = synth.make_alignment(3234, H=480, W=640, N=16000, rot_deg=0.6, trans_norm=0.012, blur_ksize=15, blur_sigma=4.0)
+    for solver, key in ((capi.SOLVER_LM6, "config3_lm6_ms"), (capi.SOLVER_REF12, "config3_ref12_ms")):
+        pyr = capi.Pyramid(capi.default_config(sampling=samp, solver=solver, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters), counts, 480, 640)
+        for l, n in enumerate(counts):
+            pyr.set_keyframe(l, alp.norm_coord[:n], alp.grad[:n], alp.idp[:n], alp.weights[:n], alp.fx, alp.fy, alp.cx, alp.cy)
+        pyr.set_event_frame(alp.frame)
+        out[key] = med(lambda: pyr.optimize(alp.p0, alp.q0, alp.v0), reps=10)
+        pyr.close()
     B64 = 64
     als64 = [synth.make_alignment(5000 + b, H=al.H, W=al.W, N=al.N) for b in range(8)]
     h = capi.Handle(capi.default_config(sampling=samp, solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0),
@@ -228,7 +254,8 @@ def latency_block(capi, synth, al, a):
     out["B64_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
     h.close()
     out["note"] = ("wall time per call through the C ABI, inputs resident; B1: one 640x480-class alignment, B64: one launch of 64 (configs[4] on "
-                   "one GPU); slice: 100 k events -> frame -> REF12 (4 blocks, Huber) -> MAD -> getCoord")
+                   "one GPU); slice: 100 k events -> frame -> REF12 (4 blocks, Huber) -> MAD -> getCoord; live_call: the shim's sequence with a host fp64 "
+                   "frame; config3: one 4-level coarse-to-fine call (2 000 .. 16 000 points)")
     return out
 
 

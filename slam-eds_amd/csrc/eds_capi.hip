@@ -462,7 +462,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
     EDS_HALLOC(h->h_r, BN * 4);
     EDS_HALLOC(h->h_idp, (size_t)h->Np * 4);
-    {   // mirror of the residual plane for the first few slots (EdsArrays::r_host)
+    {   // mirror of the residual plane for the first few slots (eds_mirror_residuals)
         const size_t nr = (size_t)std::min(batch, EDS_RHOST_SLOTS) * h->Np;
         hipError_t e_ = hipHostMalloc((void**)&h->h_rmap, nr * 4, hipHostMallocMapped);
         if (e_ == hipSuccess) e_ = hipHostGetDevicePointer((void**)&h->d_rmap, h->h_rmap, 0);

@@ -159,7 +159,20 @@ __global__ void k_store_rowmajor(const float* __restrict__ src, float* __restric
     dst[eds_frame_index(r, c, Wp, tiled)] = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
 }
 
+__global__ void k_mirror_rows(const float* __restrict__ src, float* __restrict__ dst, int n) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += gridDim.x * blockDim.x) d4[i] = s4[i];
+}
+
 }  // namespace
+
+bool eds_mirror_residuals(eds_trk* h, int first, int count) {
+    if (!h->d_rmap || first + count > EDS_RHOST_SLOTS) return false;
+    const int n = count * h->Np;                                  // Np is a multiple of 4 (EDS_POINT_ALIGN)
+    hipLaunchKernelGGL(k_mirror_rows, dim3((n / 4 + 255) / 256), dim3(256), 0, h->st, h->dr + (size_t)first * h->Np, h->d_rmap + (size_t)first * h->Np, n);
+    return true;
+}
 
 // source rows [row_b, row_e) (and, with them, the margin / padding rows that replicate row 0 or row H - 1)
 void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e) {

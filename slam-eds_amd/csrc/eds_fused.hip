@@ -502,7 +502,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll                          // all along: the damped solver needs no extra pass to produce them
         for (int j = 0; j < NREG; ++j) {
             const int i = tid + j * nthr;
-            if (i < N) { A.r[base + i] = racc[j]; if (A.r_host) A.r_host[base + i] = racc[j]; }
+            if (i < N) A.r[base + i] = racc[j];
         }
     }
 #ifdef EDS_FUSED_STAMPS
@@ -598,7 +598,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
     hipError_t e = hipSuccess;
-    EdsArrays A = h->arrays();
+    const EdsArrays A = h->arrays();
     // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
     // the points-per-lane variant is picked from the largest N of the range
     // 8 wavefronts x 4 points per lane measured 12% faster than 16 x 2 at N = 2000 (fewer wavefronts to
@@ -662,10 +662,6 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
             fb.epoch = 1;
         }
     }
-    // few alignments: the kernel also stores the kept residuals into pinned host memory (8 KB each over PCIe, posted writes), so
-    // that Tracker.cpp:223-230's read-back costs no copy call; the register-resident and streaming variants honour it
-    fb.pending_host_r = h->d_rmap && first + count <= EDS_RHOST_SLOTS && (stream || ppt > 0 || team > 1);
-    if (fb.pending_host_r) A.r_host = h->d_rmap;
     fb.pending_team = team; fb.pending_level = level;
     const unsigned ticket_base = fb.ticket_base;
     if (team > 1) fb.ticket_base += (unsigned)(count * team);
@@ -707,6 +703,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH_FUSED
 #undef EDS_LAUNCH_TEAM
     hipEventRecord(h->ev1, h->st);
+    fb.pending_host_r = eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

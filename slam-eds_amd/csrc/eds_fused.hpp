@@ -55,7 +55,7 @@ struct EdsFusedBuffers {
     unsigned ticket_base = 0;               // tickets handed out by earlier team launches (the device counter is never reset)
     bool team_disabled = false;             // a team once timed out on this handle
     int pending_team = 1, pending_level = 0;
-    bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (EdsArrays::r_host)
+    bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (eds_mirror_residuals)
     int B = 0;
     int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
     double launch_wall_us = 0.0;
@@ -90,6 +90,9 @@ struct EdsFrameBuffers {
     int cap_events = 0;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
+// few alignments per launch: one more (tiny) launch writes the kept residuals into pinned host memory as well, so that reading
+// them back (Tracker.cpp:223-230) costs no copy call and no second wait; false: not mirrored (fetch as usual)
+bool eds_mirror_residuals(eds_trk* h, int first, int count);
 void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e);     // row-major fp32 H x W in HBM -> the slot's tiled frame
 int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
 int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,

@@ -460,11 +460,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         ++st_n;
 #endif
         if (s_accept) {                         // the candidate became the accepted point: its residuals are the ones to keep
-            for (int i = lo + tid; i < hi; i += nthr) {    // each thread copies what it wrote itself
-                const float v = A.mhat[base + i];
-                A.r[base + i] = v;
-                if (A.r_host) A.r_host[base + i] = v;
-            }
+            for (int i = lo + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];    // each thread copies what it wrote itself
         }
         if (s_state == 2) break;
     }
@@ -509,9 +505,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
     hipError_t e = hipSuccess;           // (start states and results: pinned host memory the kernel accesses directly, eds_fused_alloc)
-    EdsArrays A = h->arrays();
-    fb.pending_host_r = h->d_rmap && first + count <= EDS_RHOST_SLOTS;      // as eds_fused_solve
-    if (fb.pending_host_r) A.r_host = h->d_rmap;
+    const EdsArrays A = h->arrays();
     // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads,
     // 96 KB patch cache — the lower latency (0.28 ms for one 2 000-point alignment, 7.0 M LM iterations/s at 256).
     // Beyond that, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase
@@ -569,6 +563,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_
     hipEventRecord(h->ev1, h->st);
+    fb.pending_host_r = eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

@@ -20,8 +20,6 @@ struct EdsArrays {
     double* G;           // [B][EDS_MAX_BLOCKS][36]
     // per-pass outputs
     float* r;            // [B][Np]
-    float* r_host;       // nullable: device-mapped pinned mirror of r for slots < EDS_RHOST_SLOTS — the persistent kernels store the
-                         // kept residuals there as well when a launch is small enough that fetching them would cost a copy call
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
     double* ncstat;      // [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC block statistics (eds_layout.hpp)

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHR, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsA
         }
         __syncthreads();
         if (s_accept) {                         // the pass just consumed is at the accepted pose: keep its residuals
-            for (int i = tid; i < N; i += nthr) { A.r[base + i] = rcand[i]; if (A.r_host) A.r_host[base + i] = rcand[i]; }   // each thread copies what it wrote itself
+            for (int i = tid; i < N; i += nthr) A.r[base + i] = rcand[i];      // each thread copies what it wrote itself
         }
         if (s_state == 2) break;
     }
