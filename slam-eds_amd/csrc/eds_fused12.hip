@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 miss[jj] = !(cached && s_cell[li] == key);
                 if (QUAD) {
                     if (miss[jj] && cached) s_cell[li] = key;
-                    org[jj] = pack_origin(frame, pg[jj].r0, pg[jj].c0) | (miss[jj] ? (int)0x80000000 : 0);
+                    org[jj] = miss[jj] ? (pack_origin(frame, pg[jj].r0, pg[jj].c0) | (int)0x80000000) : 0;     // cached: origin 0 — its (unused) row loads fall on the first line of the allocation: no branch around the loads (+3 %)
                     continue;
                 }
                 if (miss[jj]) {
@@ -204,8 +204,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     const int oq[4] = {o0, o1, o2, o3};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        ra[jj][q] = dont_care4(); rb[jj][q] = dont_care4();
-                        if (oq[q] < 0) load_patch_row(tiles, frame.TW, oq[q] & 0x7fffffff, jr, ra[jj][q], rb[jj][q]);
+                        load_patch_row(tiles, frame.TW, oq[q], jr, ra[jj][q], rb[jj][q]);
                     }
                 }
             }
