@@ -15,6 +15,7 @@
 // rule and std::nth_element's order statistic without sorting.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -268,19 +269,24 @@ __global__ __launch_bounds__(KF_T) void k_emit(const int* __restrict__ cand, con
     }
 }
 
-// nearest depth-map point of every candidate (brute force through LDS tiles; lowest index wins exact ties)
-__global__ __launch_bounds__(KF_T) void k_nearest(const double* __restrict__ coord, int n, const double* __restrict__ dxy,
-                                                  const double* __restrict__ didp, int m, double* __restrict__ idp, double* __restrict__ dist) {
-    constexpr int TILE = 1024;
-    __shared__ double sx[TILE], sy[TILE];
-    const int i = blockIdx.x * KF_T + threadIdx.x;
+// Nearest depth-map point of every candidate (KeyFrame.cpp:1137-1166: a brute-force search; lowest index wins exact ties).
+// Two launches: the depth points are cut into gridDim.y chunks, workgroup (x, y) finds for its 64 candidates the nearest point of
+// chunk y (points staged through LDS, fp64 like the reference); the merge walks the chunks in order with a strict <, so the
+// winner is the one a single sequential scan would have found.  (One workgroup per 256 candidates scanning all m points: 95 us
+// for 886 candidates x 3 000 points — 4 workgroups on a 256-CU chip.)
+constexpr int NN_T = 64, NN_TILE = 512;
+__global__ __launch_bounds__(NN_T) void k_nearest_part(const double* __restrict__ coord, int n, const double* __restrict__ dxy, int m, int chunk,
+                                                       double* __restrict__ pd2, int* __restrict__ pidx) {
+    __shared__ double sx[NN_TILE], sy[NN_TILE];
+    const int i = blockIdx.x * NN_T + threadIdx.x;
+    const int lo = blockIdx.y * chunk, hi = min(m, lo + chunk);
     const double qx = i < n ? coord[2 * (size_t)i] : 0.0, qy = i < n ? coord[2 * (size_t)i + 1] : 0.0;
     double best = INFINITY;
     int bi = 0;
-    for (int base = 0; base < m; base += TILE) {
-        const int len = min(TILE, m - base);
+    for (int base = lo; base < hi; base += NN_TILE) {
+        const int len = min(NN_TILE, hi - base);
         __syncthreads();
-        for (int j = threadIdx.x; j < len; j += KF_T) { sx[j] = dxy[2 * (size_t)(base + j)]; sy[j] = dxy[2 * (size_t)(base + j) + 1]; }
+        for (int j = threadIdx.x; j < len; j += NN_T) { sx[j] = dxy[2 * (size_t)(base + j)]; sy[j] = dxy[2 * (size_t)(base + j) + 1]; }
         __syncthreads();
         for (int j = 0; j < len; ++j) {
             const double dx = qx - sx[j], dy = qy - sy[j];
@@ -288,11 +294,23 @@ __global__ __launch_bounds__(KF_T) void k_nearest(const double* __restrict__ coo
             if (d2 < best) { best = d2; bi = base + j; }
         }
     }
-    if (i < n) {
-        const double dx = dxy[2 * (size_t)bi] - qx, dy = dxy[2 * (size_t)bi + 1] - qy;     // cv::norm(dist)  (:1161-1162)
-        idp[i] = didp[bi];
-        dist[i] = sqrt(dx * dx + dy * dy);
+    if (i < n) { pd2[(size_t)blockIdx.y * n + i] = best; pidx[(size_t)blockIdx.y * n + i] = bi; }
+}
+__global__ __launch_bounds__(KF_T) void k_nearest_merge(const double* __restrict__ coord, int n, const double* __restrict__ dxy,
+                                                        const double* __restrict__ didp, int nchunk, const double* __restrict__ pd2,
+                                                        const int* __restrict__ pidx, double* __restrict__ idp, double* __restrict__ dist) {
+    const int i = blockIdx.x * KF_T + threadIdx.x;
+    if (i >= n) return;
+    double best = INFINITY;
+    int bi = 0;
+    for (int c = 0; c < nchunk; ++c) {
+        const double d2 = pd2[(size_t)c * n + i];
+        if (d2 < best) { best = d2; bi = pidx[(size_t)c * n + i]; }
     }
+    const double qx = coord[2 * (size_t)i], qy = coord[2 * (size_t)i + 1];
+    const double dx = dxy[2 * (size_t)bi] - qx, dy = dxy[2 * (size_t)bi + 1] - qy;     // cv::norm(dist)  (:1161-1162)
+    idp[i] = didp[bi];
+    dist[i] = sqrt(dx * dx + dy * dy);
 }
 
 // weights from the distances (:1168-1181), cleanPoints(thr) (:1566-1587): in-place, order-preserving compaction.
@@ -467,7 +485,14 @@ int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, int 
     if (ncand < 1) return eds_internal_fail(EDS_ERR_INVALID, "the selection produced no candidate point");
     const double const_idp = 1.0 / ((sel->max_depth - sel->min_depth) / 2.0);       // KeyFrame.cpp:1189
     if (n_depth > 0) {
-        hipLaunchKernelGGL(k_nearest, dim3((ncand + KF_T - 1) / KF_T), dim3(KF_T), 0, st, kb.d_coord, ncand, kb.d_dxy, kb.d_didp, n_depth, kb.d_idp, kb.d_w);
+        // per-chunk winners go to two planes the selection no longer needs (|grad| and the log image: n doubles each)
+        int nchunk = (int)std::min<size_t>(16, n / (size_t)ncand);
+        nchunk = std::max(1, std::min(nchunk, (n_depth + 63) / 64));
+        const int chunk = (n_depth + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(k_nearest_part, dim3((ncand + NN_T - 1) / NN_T, nchunk), dim3(NN_T), 0, st, kb.d_coord, ncand, kb.d_dxy, n_depth, chunk,
+                           kb.d_mag, reinterpret_cast<int*>(kb.d_log));
+        hipLaunchKernelGGL(k_nearest_merge, dim3((ncand + KF_T - 1) / KF_T), dim3(KF_T), 0, st, kb.d_coord, ncand, kb.d_dxy, kb.d_didp, nchunk,
+                           kb.d_mag, reinterpret_cast<const int*>(kb.d_log), kb.d_idp, kb.d_w);
         hipLaunchKernelGGL(k_minmax, dim3(NB), dim3(KF_T), 0, st, (const void*)kb.d_w, 2, (size_t)ncand, kb.d_partial);
     }
     hipLaunchKernelGGL(k_weights_clean, dim3(1), dim3(1024), 0, st, kb.d_coord, kb.d_grad, kb.d_idp, kb.d_w, ncand, n_depth > 0 ? 1 : 0,
