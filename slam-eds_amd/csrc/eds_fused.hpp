@@ -100,8 +100,15 @@ int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels,
 
 // ---- loss scale and point maintenance on device (eds_points.hip) --------------------------------------------
 struct EdsPointBuffers {
-    double *d_coord = nullptr, *d_track = nullptr, *d_summary = nullptr, *d_pose = nullptr, *d_tau = nullptr;
+    // getCoord's pose in and its outputs (summary, coordinates, tracks, kept indices) live in ONE device-mapped pinned block: the
+    // kernel reads / writes it over PCIe (36 B per point), the call is one launch and one wait — no copy calls (each costs
+    // 5-10 us on the live path: 93 -> 30 us per 2 000-point alignment)
+    char* h_block = nullptr;            // host address of the block
+    double *h_summary = nullptr, *h_pose = nullptr, *h_coord = nullptr, *h_track = nullptr;
+    int* h_kept = nullptr;
+    double *d_coord = nullptr, *d_track = nullptr, *d_summary = nullptr, *d_pose = nullptr;    // the same, as the device sees them
     int* d_kept = nullptr;
+    double* d_tau = nullptr;            // device loss scales of a batch (HBM)
 };
 void eds_points_free(EdsPointBuffers* pb);
 bool eds_points_supported(const eds_trk* h, int first, int count);

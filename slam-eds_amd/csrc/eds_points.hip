@@ -9,6 +9,8 @@
 //                    pixel, mean squared flow for Tracker::needNewKeyframe (Tracker.cpp:650-654)
 #include <hip/hip_runtime.h>
 
+#include <tuple>
+
 #include <cmath>
 #include <cstring>
 
@@ -187,18 +189,32 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, 
 }  // namespace
 
 void eds_points_free(EdsPointBuffers* pbuf) {
-    void* d[] = {pbuf->d_coord, pbuf->d_track, pbuf->d_kept, pbuf->d_summary, pbuf->d_pose, pbuf->d_tau};
-    for (void* p : d) if (p) hipFree(p);
+    if (pbuf->h_block) hipHostFree(pbuf->h_block);
+    if (pbuf->d_tau) hipFree(pbuf->d_tau);
     *pbuf = EdsPointBuffers();
 }
 
 static int ensure(eds_trk* h) {
     EdsPointBuffers& pb = h->point_ops;
-    if (pb.d_coord) return EDS_OK;
-    if (hipMalloc((void**)&pb.d_coord, (size_t)h->Np * 16) != hipSuccess || hipMalloc((void**)&pb.d_track, (size_t)h->Np * 16) != hipSuccess ||
-        hipMalloc((void**)&pb.d_kept, (size_t)h->Np * 4) != hipSuccess || hipMalloc((void**)&pb.d_summary, 16) != hipSuccess ||
-        hipMalloc((void**)&pb.d_pose, 16 * 8) != hipSuccess || hipMalloc((void**)&pb.d_tau, (size_t)h->B * 8) != hipSuccess)
-        return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(point buffers)");
+    if (pb.h_block) return EDS_OK;
+    const size_t Np = (size_t)h->Np;
+    const size_t bytes = 16 + 128 + Np * 16 + Np * 16 + Np * 4;        // summary | pose | coord | track | kept
+    char* dblock = nullptr;
+    if (hipHostMalloc((void**)&pb.h_block, bytes, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&dblock, pb.h_block, 0) != hipSuccess || hipMalloc((void**)&pb.d_tau, (size_t)h->B * 8) != hipSuccess) {
+        eds_points_free(&pb);
+        return eds_internal_fail(EDS_ERR_HIP, "allocation of the point buffers failed");
+    }
+    auto carve = [&](char* base) {
+        double* sum = reinterpret_cast<double*>(base);
+        double* pose = sum + 2;
+        double* coord = pose + 16;
+        double* track = coord + 2 * Np;
+        int* kept = reinterpret_cast<int*>(track + 2 * Np);
+        return std::make_tuple(sum, pose, coord, track, kept);
+    };
+    std::tie(pb.h_summary, pb.h_pose, pb.h_coord, pb.h_track, pb.h_kept) = carve(pb.h_block);
+    std::tie(pb.d_summary, pb.d_pose, pb.d_coord, pb.d_track, pb.d_kept) = carve(dblock);
     return EDS_OK;
 }
 
@@ -234,50 +250,21 @@ int eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, do
     if (rc) return rc;
     EdsPointBuffers& pb = h->point_ops;
     Slot& sl = h->slots[slot];
-    double hp[16];
+    double* hp = pb.h_pose;                     // the kernel reads the pose where the host writes it
     edsm::quat_to_RmI(sl.q, hp);
     for (int i = 0; i < 3; ++i) hp[9 + i] = sl.p[i];
     hp[12] = sl.K[0]; hp[13] = sl.K[1]; hp[14] = (double)h->W; hp[15] = (double)h->H;     // kf->img.cols / rows
-    hipError_t e = hipMemcpyAsync(pb.d_pose, hp, sizeof(hp), hipMemcpyHostToDevice, h->st);
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     const int ppt = (sl.N + EDS_PTS_THREADS - 1) / EDS_PTS_THREADS;
     hipLaunchKernelGGL(k_update_points, dim3(1), dim3(EDS_PTS_THREADS), 0, h->st, h->arrays(), slot, ppt, delete_out, pb.d_pose, pb.d_coord,
                        pb.d_track, pb.d_kept, pb.d_summary);
-    // one round trip: everything lands in the handle's pinned staging (36 N bytes fit its 48 Np), then a single sync
-    const size_t N0 = (size_t)sl.N;
-    char* stage = reinterpret_cast<char*>(h->h_f32);
-    double* h_sum = reinterpret_cast<double*>(stage);
-    double* h_coord = h_sum + 2;
-    double* h_track = h_coord + 2 * N0;
-    int32_t* h_kept = reinterpret_cast<int32_t*>(h_track + 2 * N0);
-    const bool fits = 16 + 36 * N0 <= h->h_f32_elems * 4;
-    double summary[2] = {0, 0};
-    e = hipGetLastError();
-    if (fits) {
-        if (e == hipSuccess) e = hipMemcpyAsync(h_sum, pb.d_summary, 16, hipMemcpyDeviceToHost, h->st);
-        if (e == hipSuccess && coord_xy) e = hipMemcpyAsync(h_coord, pb.d_coord, N0 * 16, hipMemcpyDeviceToHost, h->st);
-        if (e == hipSuccess && tracks_xy) e = hipMemcpyAsync(h_track, pb.d_track, N0 * 16, hipMemcpyDeviceToHost, h->st);
-        if (e == hipSuccess && kept_index) e = hipMemcpyAsync(h_kept, pb.d_kept, N0 * 4, hipMemcpyDeviceToHost, h->st);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->st);
-        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-        summary[0] = h_sum[0]; summary[1] = h_sum[1];
-        const int n = (int)summary[0];
-        if (coord_xy && n > 0) std::memcpy(coord_xy, h_coord, (size_t)n * 16);
-        if (tracks_xy && n > 0) std::memcpy(tracks_xy, h_track, (size_t)n * 16);
-        if (kept_index && n > 0) std::memcpy(kept_index, h_kept, (size_t)n * 4);
-        if (n_kept) *n_kept = n;
-        if (mean_sq_flow) *mean_sq_flow = summary[1];
-        return EDS_OK;
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(summary, pb.d_summary, 16, hipMemcpyDeviceToHost, h->st);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    const int n = (int)summary[0];
-    if (coord_xy && n > 0) e = hipMemcpy(coord_xy, pb.d_coord, (size_t)n * 16, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && tracks_xy && n > 0) e = hipMemcpy(tracks_xy, pb.d_track, (size_t)n * 16, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && kept_index && n > 0) e = hipMemcpy(kept_index, pb.d_kept, (size_t)n * 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    const int n = (int)pb.h_summary[0];
+    if (coord_xy && n > 0) std::memcpy(coord_xy, pb.h_coord, (size_t)n * 16);
+    if (tracks_xy && n > 0) std::memcpy(tracks_xy, pb.h_track, (size_t)n * 16);
+    if (kept_index && n > 0) std::memcpy(kept_index, pb.h_kept, (size_t)n * 4);
     if (n_kept) *n_kept = n;
-    if (mean_sq_flow) *mean_sq_flow = summary[1];
+    if (mean_sq_flow) *mean_sq_flow = pb.h_summary[1];
     return EDS_OK;
 }
