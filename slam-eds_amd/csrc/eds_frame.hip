@@ -105,9 +105,11 @@ __global__ void k_resize(const double* __restrict__ src, int sH, int sW, double*
 // Levels of EventFrame::create from ONE brightness image (EventFrame.cpp:348-357): level 0 is the image, level i >= 1 its
 // dilation + erosion with a (2i+1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue).  blockIdx.z
 // selects the level (level0 + z); each level's image goes to its own plane and its sum of squares is accumulated on the way.
-__global__ void k_levels(const double* __restrict__ src, double* __restrict__ planes, double* __restrict__ sumsq, int H, int W, int level0) {
+__global__ void k_levels(const double* __restrict__ src, double* __restrict__ planes, double* __restrict__ sumsq, int H, int W, int level0,
+                         double* __restrict__ clear) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, rad = level0 + (int)blockIdx.z;
     double v = 0.0;
+    if (clear && blockIdx.z == 0 && c < W) clear[(size_t)r * W + c] = 0.0;       // the vote image of the NEXT call (not `src`: the blur moved on)
     if (c < W) {
         if (rad == 0) {
             v = src[(size_t)r * W + c];
@@ -140,11 +142,15 @@ __global__ void k_levels(const double* __restrict__ src, double* __restrict__ pl
 }
 // level / ||level||_F -> fp32 in the handle's layout, one slot per level (padding and margin filled with the nearest border pixel)
 __global__ void k_store_levels(const double* __restrict__ planes, const double* __restrict__ sumsq, float* __restrict__ frames, int first_slot,
-                               int H, int W, int Hp, int Wp, int tiled, int normalise) {
+                               int H, int W, int Hp, int Wp, int tiled, int normalise, double* __restrict__ sumsq_next,
+                               double* __restrict__ total_out) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)                   // ALL of the other accumulator set, for the next call
+        for (int k = threadIdx.x; k < EDS_MAX_LEVELS * EDS_SUMSQ_WAYS; k += blockDim.x) sumsq_next[k] = 0.0;      // (which may build more levels)
     if (c >= Wp - EDS_FRAME_MARGIN) return;
     double ss = 0.0;
     for (int k = 0; k < EDS_SUMSQ_WAYS; ++k) ss += sumsq[blockIdx.z * EDS_SUMSQ_WAYS + k];      // wave-uniform, L2-resident
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) total_out[blockIdx.z] = ss;     // ||level||^2 to the host (mapped)
     const double inv = normalise ? 1.0 / sqrt(ss) : 1.0;         // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
     const double v = planes[(size_t)blockIdx.z * H * W + (size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
     frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
@@ -183,9 +189,10 @@ void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_
 }
 
 void eds_frame_free(EdsFrameBuffers* fb) {
-    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_ex, fb->d_planes};     // d_ey, d_pol are slices of d_ex
+    void* d[] = {fb->d_mapx, fb->d_mapy, fb->d_img, fb->d_tmp, fb->d_norm, fb->d_planes};
     for (void* p : d) if (p) hipFree(p);
-    if (fb->h_events) hipHostFree(fb->h_events);
+    if (fb->h_events) hipHostFree(fb->h_events);       // d_ex, d_ey, d_pol are its device view
+    if (fb->h_norm_out) hipHostFree(fb->h_norm_out);
     *fb = EdsFrameBuffers();
 }
 
@@ -221,10 +228,17 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     if (fb.img_elems < std::max(n, ns)) {
         if (fb.d_img) { hipFree(fb.d_img); hipFree(fb.d_tmp); fb.d_img = fb.d_tmp = nullptr; }
         fb.img_elems = std::max(n, ns);
+        fb.img_clean = false;
         if (hipMalloc((void**)&fb.d_img, fb.img_elems * 8) != hipSuccess || hipMalloc((void**)&fb.d_tmp, fb.img_elems * 8) != hipSuccess)
             return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(frame accumulation)");
     }
-    if (!fb.d_norm && hipMalloc((void**)&fb.d_norm, 8 * EDS_MAX_LEVELS * EDS_SUMSQ_WAYS) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(norms)");
+    constexpr size_t NORM_SET = (size_t)EDS_MAX_LEVELS * EDS_SUMSQ_WAYS;
+    if (!fb.d_norm) {
+        if (hipMalloc((void**)&fb.d_norm, 8 * 2 * NORM_SET) != hipSuccess || hipMemset(fb.d_norm, 0, 8 * 2 * NORM_SET) != hipSuccess ||
+            hipHostMalloc((void**)&fb.h_norm_out, 8 * EDS_MAX_LEVELS, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&fb.d_norm_out, fb.h_norm_out, 0) != hipSuccess)
+            return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(norms)");
+    }
     if (fb.plane_levels < nlevels) {
         if (fb.d_planes) hipFree(fb.d_planes);
         fb.d_planes = nullptr; fb.plane_levels = 0;
@@ -232,36 +246,33 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
         fb.plane_levels = nlevels;
     }
     if (n_events > fb.cap_events) {
-        if (fb.d_ex) hipFree(fb.d_ex);
         if (fb.h_events) hipHostFree(fb.h_events);
         fb.d_ex = fb.d_ey = nullptr; fb.d_pol = nullptr; fb.h_events = nullptr;
         fb.cap_events = (n_events + n_events / 4 + 1024 + 7) & ~7;
-        const size_t bytes = (size_t)fb.cap_events * 5;
-        if (hipMalloc((void**)&fb.d_ex, bytes) != hipSuccess || hipHostMalloc((void**)&fb.h_events, bytes, hipHostMallocDefault) != hipSuccess) {
+        uint8_t* dev = nullptr;
+        if (hipHostMalloc((void**)&fb.h_events, (size_t)fb.cap_events * 5, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&dev, fb.h_events, 0) != hipSuccess) {
             fb.cap_events = 0;
-            return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(events)");
+            return eds_internal_fail(EDS_ERR_HIP, "hipHostMalloc(events)");
         }
+        fb.d_ex = reinterpret_cast<uint16_t*>(dev);
         fb.d_ey = fb.d_ex + fb.cap_events;
         fb.d_pol = reinterpret_cast<uint8_t*>(fb.d_ey + fb.cap_events);
     }
     hipStream_t st = h->st;
     hipError_t e = hipSuccess;
-    if (n_events > 0) {                 // pack into the pinned staging, one asynchronous copy
+    if (n_events > 0) {                 // pack into the pinned staging; k_vote reads it over PCIe (5 bytes per event)
         const size_t cap = (size_t)fb.cap_events;
         std::memcpy(fb.h_events, ex, (size_t)n_events * 2);
         std::memcpy(fb.h_events + cap * 2, ey, (size_t)n_events * 2);
         std::memcpy(fb.h_events + cap * 4, pol, (size_t)n_events);
-        if ((size_t)n_events * 8 >= cap * 5)    // nearly full: one copy of everything; else three tight ones
-            e = hipMemcpyAsync(fb.d_ex, fb.h_events, cap * 5, hipMemcpyHostToDevice, st);
-        else {
-            e = hipMemcpyAsync(fb.d_ex, fb.h_events, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(fb.d_ey, fb.h_events + cap * 2, (size_t)n_events * 2, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(fb.d_pol, fb.h_events + cap * 4, (size_t)n_events, hipMemcpyHostToDevice, st);
-        }
     }
-    if (e == hipSuccess) e = hipMemsetAsync(fb.d_img, 0, ns * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(fb.d_norm, 0, 8 * EDS_MAX_LEVELS * EDS_SUMSQ_WAYS, st);
+    if (!fb.img_clean) e = hipMemsetAsync(fb.d_img, 0, fb.img_elems * 8, st);     // first call, or the last one could not clear it
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    fb.img_clean = false;
+    double* norm_cur = fb.d_norm + (size_t)(fb.calls & 1) * NORM_SET;
+    double* norm_next = fb.d_norm + (size_t)((fb.calls + 1) & 1) * NORM_SET;
+    ++fb.calls;
     if (n_events > 0)
         hipLaunchKernelGGL(k_vote, dim3((n_events + 255) / 256), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, fb.d_mapx, fb.d_mapy,
                            n_events, sH, sW, use_exp_weights, fb.d_img);
@@ -277,19 +288,18 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
         hipLaunchKernelGGL(k_resize, dim3((W + 255) / 256, H), b2, 0, st, cur, sH, sW, other, H, W);
         std::swap(cur, other);
     }
-    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, fb.d_norm, H, W, level0);
-    hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, nlevels), b2, 0, st, fb.d_planes, fb.d_norm, h->dframe, first_slot, H, W,
-                       h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1);
+    // the vote image can be cleared for the next call by k_levels when the image has moved on to another buffer and covers exactly
+    // the frame (sensor size == frame size)
+    double* clear = (cur != fb.d_img && ns == n && fb.img_elems == n) ? fb.d_img : nullptr;
+    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, norm_cur, H, W, level0, clear);
+    hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, nlevels), b2, 0, st, fb.d_planes, norm_cur, h->dframe, first_slot, H, W,
+                       h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, norm_next, fb.d_norm_out);
     e = hipGetLastError();
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    double ss[EDS_MAX_LEVELS * EDS_SUMSQ_WAYS];
-    e = hipMemcpyAsync(ss, fb.d_norm, 8 * nlevels * EDS_SUMSQ_WAYS, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    fb.img_clean = clear != nullptr;
     for (int i = 0; i < nlevels; ++i) {
-        double t = 0.0;
-        for (int k = 0; k < EDS_SUMSQ_WAYS; ++k) t += ss[i * EDS_SUMSQ_WAYS + k];      // the order k_store_levels adds them in
-        if (norms_out) norms_out[i] = std::sqrt(t);
+        if (norms_out) norms_out[i] = std::sqrt(fb.h_norm_out[i]);     // the accumulators added up in k_store_levels' order
         h->slots[first_slot + i].has_frame = true;
     }
     return EDS_OK;

@@ -84,10 +84,16 @@ struct EdsFrameBuffers {
     size_t img_elems = 0;                           // capacity of d_img / d_tmp (max of sensor and frame size)
     double* d_planes = nullptr;                     // the levels of one event frame, [plane_levels][H][W]
     int plane_levels = 0;
-    uint16_t *d_ex = nullptr, *d_ey = nullptr;     // slices of ONE device allocation [x | y | polarity]
+    uint8_t* h_events = nullptr;                   // pinned, device-mapped staging [x | y | polarity]: k_vote reads the events in place
+    uint16_t *d_ex = nullptr, *d_ey = nullptr;     // ... as the device sees it
     uint8_t* d_pol = nullptr;
-    uint8_t* h_events = nullptr;                   // pinned staging of the same shape: one host-to-device copy per frame
     int cap_events = 0;
+    // d_norm holds TWO sets of sum-of-squares accumulators: a call accumulates into set (calls & 1) and its last launch clears the
+    // other one for the next call; the totals come back through mapped pinned memory.  d_img is cleared by k_levels once the blur
+    // has moved the image on (img_clean says whether that happened).  A frame is then 4 launches and one wait: no memset, no copy.
+    double *h_norm_out = nullptr, *d_norm_out = nullptr;
+    unsigned calls = 0;
+    bool img_clean = false;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
 // few alignments per launch: one more (tiny) launch writes the kept residuals into pinned host memory as well, so that reading

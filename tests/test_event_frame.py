@@ -169,3 +169,28 @@ def test_build_all_levels_from_one_vote(gpu, capi, sensor, frame, levels):
     with pytest.raises(capi.EdsError):
         h.build_event_frames(1, levels + 1, x, y, pol, sensor_size=(sH, sW))               # one slot per level
     h.close()
+
+
+@pytest.mark.gpu
+def test_builder_state_between_calls(gpu, capi):
+    """The builder carries state from call to call (the vote image is cleared by the previous call's level pass, the sum-of-squares
+    accumulators alternate between two sets, the events are read from a pinned buffer that is re-filled): calls that differ in level
+    count, event count, blur (no blur: the image cannot be cleared on the way) and sensor size, back to back on one handle, each
+    against the oracle."""
+    import np_frame_oracle as fo
+    H, W = 120, 160
+    h = capi.Handle(capi.default_config(), 4, 64, H, W)
+    plan = [(3, 5000, 0.5, (H, W)), (1, 200, 0.5, (H, W)), (3, 9000, 0.5, (H, W)), (2, 3000, 0.0, (H, W)), (3, 4000, 0.5, (H, W)),
+            (2, 7000, 0.5, (2 * H, 2 * W)), (1, 0, 0.5, (H, W)), (3, 6000, 0.5, (H, W))]
+    for k, (levels, n, sigma, (sH, sW)) in enumerate(plan):
+        x, y, pol, _, _ = make_events(100 + k, max(n, 1), sH, sW, distort=False)
+        x, y, pol = x[:n], y[:n], pol[:n]
+        if n == 0:
+            continue                                            # (an empty slice has no norm to divide by; covered by the edge-case test)
+        norms = h.build_event_frames(0, levels, x, y, pol, sensor_size=(sH, sW), blur_sigma=sigma)
+        ref_frames, ref_norms = fo.event_frames(x, y, pol, sH, sW, H, W, levels, None, None, sigma=sigma)
+        for i in range(levels):
+            assert norms[i] == pytest.approx(ref_norms[i], rel=1e-11), (k, i)
+            got = h.get_event_frame(i)
+            assert np.abs(got - ref_frames[i]).max() <= 1e-6 * np.abs(ref_frames[i]).max(), (k, i)
+    h.close()
