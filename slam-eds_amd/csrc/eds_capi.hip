@@ -824,10 +824,27 @@ int eds_trk_optimize(eds_trk* h, int slot, int level, double p[3], double q[4], 
 
 int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count) { return solve_range(h, level, first, count); }
 
+// Waits for the handle's stream.  A launch of a few alignments is over in 0.1-0.3 ms, and a blocking wait adds the wake-up of the
+// calling thread to every such call; the latency regime therefore polls the stream (hipStreamQuery) for up to EDS_SPIN_US before
+// it blocks.  Batches block right away: nobody should burn a core for milliseconds.
+#define EDS_SPIN_US 500.0
+static hipError_t wait_stream(eds_trk* h) {
+    const bool spin = h->cfg.exec == EDS_EXEC_DEVICE && h->fused.pending_count > 0 && h->fused.pending_count <= 64 && !getenv("EDS_NO_SPIN");
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(h->st);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > EDS_SPIN_US) break;
+        }
+    }
+    return hipStreamSynchronize(h->st);
+}
+
 int eds_trk_sync(eds_trk* h) {
     if (!h) return fail(EDS_ERR_INVALID, "null handle");
     EDS_HIP_TRY(hipSetDevice(h->dev));
-    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    EDS_HIP_TRY(wait_stream(h));
     if (h->cfg.exec == EDS_EXEC_DEVICE) return eds_fused_collect(h);
     return EDS_OK;
 }

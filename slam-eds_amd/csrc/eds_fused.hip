@@ -78,6 +78,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
     }
     const int slot = first + team_slot;
+    if (tid == 0 && member == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned pass_no = 0;                         // exchanges so far (TEAM > 1)
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         int na = 0;
         for (int k = 0; k < sv.ntrace; ++k) na += sv.tr_acc[k];
         O.naccepted = na;
+        O.t_end = __builtin_amdgcn_s_memrealtime();
     }
     // full solver state (trace) to HBM, cooperatively
     {
@@ -667,7 +669,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     fb.pending_team = team; fb.pending_level = level;
     const unsigned ticket_base = fb.ticket_base;
     if (team > 1) fb.ticket_base += (unsigned)(count * team);
-    hipEventRecord(h->ev0, h->st);
+    fb.pending_ticks = count <= 64 && !stream;       // the latency regime: time stamps from inside the kernel instead of event packets
+    if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
         const bool q = bic && count * team >= 128;   // enough gathers in flight for the quad-cooperative form to pay
@@ -704,7 +707,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED
 #undef EDS_LAUNCH_TEAM
-    hipEventRecord(h->ev1, h->st);
+    if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
@@ -721,7 +724,13 @@ int eds_fused_collect(eds_trk* h) {
     if (fb.pending_kind == 12) return eds_fused12_collect(h);
     const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     float dev_ms = 0.f;
-    hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
+    if (fb.pending_ticks) {
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) { t0 = std::min(t0, fb.h_out[s].t_begin); t1 = std::max(t1, fb.h_out[s].t_end); }
+        dev_ms = t1 > t0 ? (float)((double)(t1 - t0) * 1e-5) : 0.f;        // 100 MHz ticks
+    } else {
+        hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
+    }
     if (fb.pending_team > 1) {                        // a team whose members did not all become resident within the bound
         bool timed_out = false;
         for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) timed_out |= fb.h_out[s].failed == 2;

@@ -19,12 +19,15 @@ struct EdsFusedOut {           // compact result of a pose-only solve (trace sta
     double initial_cost, final_cost;
     int32_t iterations, ntrace, failed, naccepted;
     double pad[3];
+    unsigned long long t_begin, t_end;   // s_memrealtime (100 MHz) when the alignment's (first) workgroup started / finished: the device time
+                                         // of small launches without the two event packets around the kernel (each costs microseconds)
 };
 struct EdsFused12Out {         // compact result of a REF12 solve
     double p[3], q[4], v[6];
     double initial_cost, final_cost;
     int32_t termination, num_successful, num_unsuccessful, failed;
     double pad;
+    unsigned long long t_begin, t_end;   // as EdsFusedOut
 };
 
 // ---- teams: several workgroups (CUs) per alignment, partial sums exchanged as tagged 8-byte granules (eds_fused.hip) -----------
@@ -55,6 +58,7 @@ struct EdsFusedBuffers {
     unsigned ticket_base = 0;               // tickets handed out by earlier team launches (the device counter is never reset)
     bool team_disabled = false;             // a team once timed out on this handle
     int pending_team = 1, pending_level = 0;
+    bool pending_ticks = false;    // device time from the kernels' own time stamps (no event records around the launch)
     bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (eds_mirror_residuals)
     int B = 0;
     int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
