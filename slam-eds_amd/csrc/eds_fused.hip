@@ -622,7 +622,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
     // Streaming variants (eds_stream6.hip: constants re-read per pass, any N).
     //  * N <= 2 048: "paired" — two 256-thread workgroups per CU, reduction / solver overlapped with the other's points —
-    //    pays off once a launch keeps every CU busy for several rounds (+3 % at 1 536 alignments, +8 % at 4 096).
+    //    round 1's choice for large batches; no longer selected (see below), EDS_LM6_KERNEL=paired forces it.
     //  * N > 2 048, where the resident kernel needs 1 024 threads at 128 registers: "wide" — one 512-thread workgroup
     //    with the whole patch cache (N = 4 000: 0.21 vs 0.30 ms for one alignment, 4.1 M vs 2.5 M it/s at 256; N = 8 000:
     //    2.1 M vs 1.7 M at 256); only a handful of very large alignments is still faster with 1 024 threads.

@@ -1,4 +1,8 @@
-// Streaming variant of the persistent pose-only kernel (eds_fused.hip) for LARGE BATCHES.
+// Streaming variants of the persistent pose-only kernel (eds_fused.hip): per-point constants re-read every pass, any N.
+// Since round 2 optimize() uses them only above 2 048 points per alignment when teams do not apply ("wide": one 512-thread
+// workgroup with the whole patch cache); the "paired" shape described next lost its place to the register-resident kernel with
+// the quad-cooperative gather and prepared candidates (13.2 M vs 10.5 M iterations/s at 4 096 alignments) and is kept for A/B
+// runs (EDS_LM6_KERNEL=paired) and for its tests.
 //
 // eds_fused6_kernel gives one alignment a whole CU (512 threads, constants in registers, 128 KB patch cache); while
 // lane 0 solves the 6x6 system and the wavefronts wait at the reduction (≈ 27 % of a pass on the bench workload) the
@@ -6,7 +10,7 @@
 // and one's reduction / solver phase overlaps the other's point phase.  The pose-only pass is bound by the scattered
 // frame reads, so this is a trade: half the cache per alignment costs ~17 % more gathers, the overlap wins back more —
 // measured +0 % at 1 024 alignments per launch, +3 % at 1 536, +5 % at 4 096; with three or four smaller workgroups per
-// CU (less cache still, more gathers in flight) it LOSES 10-30 %.  optimize() picks it from 1 536 alignments per launch.
+// CU (less cache still, more gathers in flight) it LOSES 10-30 %.  (Round 1 picked it from 1 536 alignments per launch.)
 // Per-point constants are re-read from HBM/L2 every pass (28 B per point, coalesced), two points per lane are in flight, candidate residuals go to plane 0 of the
 // (otherwise unused) Jacobian buffer and are copied to the residual plane when the pose is accepted.  Solver
 // (edss::Solver6), sums, trace and results are those of eds_fused6_kernel.

@@ -83,8 +83,9 @@ def test_config4_ref12_subset(gpu, capi, synth, po, batchmod, als64):
 
 
 def test_bench_shape_kernel_selected_by_optimize(gpu, capi, synth, po, als64):
-    """1 536 alignments at the bench shape in ONE launch — the size from which optimize() switches to its large-batch kernel —
-    with no environment override; 32 distinct alignments, every distinct one checked against the oracle in two different slots."""
+    """1 536 alignments at the bench shape in ONE launch (round 1 switched kernels at this size; today the register-resident kernel
+    with the quad-cooperative gather runs every batch size, and this is the shape the headline number is measured on) with no
+    environment override; 32 distinct alignments, every distinct one checked against the oracle in two different slots."""
     for k in ("EDS_LM6_KERNEL", "EDS_FUSED_THREADS", "EDS_FUSED_PPT"):
         assert not os.environ.get(k), f"{k} must be unset: this test exercises optimize()'s own kernel choice"
     B, D = 1536, 32

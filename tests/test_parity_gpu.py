@@ -180,7 +180,7 @@ def test_reference_problem_vs_oracle(gpu, capi, synth, po, nb, loss, ex):
 @pytest.mark.parametrize("solver,iters", [("lm6", 10), ("gn6", 3), ("lm6", 0)])
 @pytest.mark.parametrize("sampling", [0, 1], ids=["bicubic", "bilinear"])
 def test_streaming_pose_kernel_vs_oracle_and_resident_kernel(gpu, capi, synth, po, solver, iters, sampling, monkeypatch):
-    """eds_stream6_kernel (picked by optimize from 1 536 alignments per launch; forced here) against the oracle and
+    """eds_stream6_kernel (optimize picks its wide shape above 2 048 points when teams do not apply; both shapes forced here) against the oracle and
     against the register-resident kernel, on ragged point counts, with and without per-point Huber."""
     sv = capi.SOLVER_LM6 if solver == "lm6" else capi.SOLVER_GN6
     als = [synth.make_alignment(6100 + b, H=240, W=320, N=n) for b, n in enumerate((1, 63, 257, 1000, 2000, 2048))]
