@@ -137,9 +137,13 @@ int  eds_trk_get_config(const eds_trk* h, eds_trk_cfg* cfg);
  * intrinsics come from kf->K_ref (Tracker.cpp:165-166).  Converted to SoA in HBM. */
 int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, const double* grad_xy,
                          const double* idp, const double* w, double fx, double fy, double cx, double cy);
-/* The reference re-reads the inverse depths on every optimize (Tracker.cpp:167). */
+/* The reference re-reads the inverse depths on every optimize (Tracker.cpp:167).  Like eds_trk_set_event_frame this returns
+ * once the caller's array has been read (it may be reused at once); the device-side part is ordered before whatever the handle
+ * does next and is not waited for. */
 int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp);
-/* Replaces `const std::vector<double>* event_frame` (Tracker.hpp:80): H*W row-major. */
+/* Replaces `const std::vector<double>* event_frame` (Tracker.hpp:80): H*W row-major.  Returns as soon as the frame has been
+ * narrowed to fp32 into the handle's staging buffer (the caller's buffer is free again); tiling on the device is ordered before the
+ * next solve and not waited for. */
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
 /* ---- event-frame construction on the device ---------------------------------------- */
