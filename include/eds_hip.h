@@ -159,6 +159,13 @@ int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy);
  * the frame was divided by (EventFrame::norm[level]). */
 int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y,
                               const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norm_out);
+/* The batched tracker's counterpart (BASELINE.json configs[4]: one event frame per alignment): `count` independent event slices into
+ * slots first_slot .. first_slot + count - 1 in one pass over the device per 32 slices — slice b's events are elements
+ * offsets[b] .. offsets[b + 1] - 1 of x / y / polarity (offsets: count + 1 non-decreasing ints), each slice in time order, all at the
+ * handle's H x W.  level, blur_sigma, use_exp_weights as above; norms (optional, count doubles) receives each frame's Frobenius norm.
+ * Every frame equals what eds_trk_build_event_frame builds from the same slice. */
+int eds_trk_build_event_frame_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* x, const uint16_t* y,
+                                    const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norms);
 /* EventFrame::create as a whole (EventFrame.cpp:302-389): ALL `num_levels` frames of one event slice from a single vote, into slots
  * first_slot .. first_slot + num_levels - 1 (level i in slot first_slot + i; EventFrame::event_frame[i], norms[i] = EventFrame::norm[i]).
  * sensor_H x sensor_W is the size the events and the undistortion LUT live in; when it differs from the handle's H x W (out_scale != 1)

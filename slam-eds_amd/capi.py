@@ -33,7 +33,7 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
-    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames",
+    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch",
     "eds_trk_get_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
@@ -127,6 +127,8 @@ def lib():
         L.eds_trk_set_undistort_map_sized.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_int]
         L.eds_trk_build_event_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                  C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, _dp]
+        L.eds_trk_build_event_frame_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                                      C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_set_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_results.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -289,6 +291,20 @@ class Handle:
                                                 x.ctypes.data_as(C.POINTER(C.c_uint16)), y.ctypes.data_as(C.POINTER(C.c_uint16)),
                                                 pol.ctypes.data_as(C.POINTER(C.c_uint8)), int(sH), int(sW), float(blur_sigma),
                                                 int(bool(use_exp_weights)), _p(norms)))
+        return norms
+
+    def build_event_frame_batch(self, first_slot, slices, level=0, blur_sigma=0.5, use_exp_weights=True):
+        """`slices`: one (x, y, polarity) triple per slot, first_slot onwards; returns the norms."""
+        offs = np.zeros(len(slices) + 1, dtype=np.int32)
+        for b, (x, _, _) in enumerate(slices):
+            offs[b + 1] = offs[b] + len(x)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(sl[k], dtype=dt) for sl in slices]) if len(slices) else np.zeros(0, dt), dtype=dt)
+        x, y, pol = cat(0, np.uint16), cat(1, np.uint16), cat(2, np.uint8)
+        norms = np.zeros(len(slices))
+        _check(lib().eds_trk_build_event_frame_batch(self._h, int(first_slot), len(slices), offs.ctypes.data_as(_ip),
+                                                     x.ctypes.data_as(C.POINTER(C.c_uint16)), y.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                     pol.ctypes.data_as(C.POINTER(C.c_uint8)), int(level), float(blur_sigma),
+                                                     int(bool(use_exp_weights)), _p(norms)))
         return norms
 
     def set_undistort_map_sized(self, mapx, mapy, sensor_size):

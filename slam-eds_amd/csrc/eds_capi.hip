@@ -659,6 +659,17 @@ int eds_trk_build_event_frames(eds_trk* h, int first_slot, int num_levels, int n
     return eds_frame_build_levels(h, first_slot, 0, num_levels, n_events, x, y, polarity, sensor_H, sensor_W, blur_sigma, use_exp_weights, norms);
 }
 
+int eds_trk_build_event_frame_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* x, const uint16_t* y,
+                                    const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norms) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (count < 1 || first_slot < 0 || first_slot + count > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds");
+    if (!offsets || offsets[0] < 0) return fail(EDS_ERR_INVALID, "bad offsets");
+    if (level < 0 || level > 16) return fail(EDS_ERR_INVALID, "bad level");
+    if (offsets[count] > offsets[0] && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return eds_frame_build_batch(h, first_slot, count, offsets, x, y, polarity, level, blur_sigma, use_exp_weights, norms);
+}
+
 int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {
     int rc = check_slot(h, slot);
     if (rc) return rc;

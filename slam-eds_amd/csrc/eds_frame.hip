@@ -20,12 +20,9 @@
 
 namespace {
 
-__global__ void k_vote(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey, const uint8_t* __restrict__ pol,
-                       const float* __restrict__ mapx, const float* __restrict__ mapy, int n, int H, int W, int use_exp,
-                       double* __restrict__ img) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int px = ex[i], py = ey[i];
+// one event of a slice of n events (i: its position in the slice, for the window weight) into `img` (drawValuesPoints, Utils.cpp:50-122)
+__device__ __forceinline__ void vote_one(int px, int py, int positive, int i, int n, const float* __restrict__ mapx, const float* __restrict__ mapy,
+                                         int H, int W, int use_exp, double* __restrict__ img) {
     double ux = px, uy = py;
     if (mapx) {
         const int cx = px < W ? px : W - 1, cy = py < H ? py : H - 1;     // the LUT has the sensor's size
@@ -37,7 +34,7 @@ __global__ void k_vote(const uint16_t* __restrict__ ex, const uint16_t* __restri
         const double value = ((double)i / (double)n - 0.5) / (1.0 / 6.0);
         weight = exp(-0.5 * value * value);
     }
-    const double val = weight * (pol[i] ? 1.0 : -1.0);
+    const double val = weight * (positive ? 1.0 : -1.0);
     int x0 = (int)floor(ux), y0 = (int)floor(uy);
     int x1 = x0 + 1, y1 = y0 + 1;
     // voting weights; 0 if the tap is outside the image (Utils.cpp:92-95)
@@ -51,6 +48,22 @@ __global__ void k_vote(const uint16_t* __restrict__ ex, const uint16_t* __restri
     if (wb != 0.0) atomicAdd(&img[(size_t)y1 * W + x0], val * wb);
     if (wc != 0.0) atomicAdd(&img[(size_t)y0 * W + x1], val * wc);
     if (wd != 0.0) atomicAdd(&img[(size_t)y1 * W + x1], val * wd);
+}
+__global__ void k_vote(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey, const uint8_t* __restrict__ pol,
+                       const float* __restrict__ mapx, const float* __restrict__ mapy, int n, int H, int W, int use_exp,
+                       double* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vote_one(ex[i], ey[i], pol[i], i, n, mapx, mapy, H, W, use_exp, img);
+}
+// many slices at once: blockIdx.y = slice, its events are [offsets[y], offsets[y + 1]) of the concatenated arrays, its image img + y * H * W
+__global__ void k_vote_batch(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey, const uint8_t* __restrict__ pol,
+                             const int* __restrict__ offsets, const float* __restrict__ mapx, const float* __restrict__ mapy, int H, int W,
+                             int use_exp, double* __restrict__ img) {
+    const int o = offsets[blockIdx.y], n = offsets[blockIdx.y + 1] - o;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    vote_one(ex[o + i], ey[o + i], pol[o + i], i, n, mapx, mapy, H, W, use_exp, img + (size_t)blockIdx.y * H * W);
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -66,6 +79,7 @@ __device__ __forceinline__ double blur_row_at(const double* __restrict__ row, in
 __global__ void k_blur3(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     if (c >= W) return;
+    src += (size_t)blockIdx.z * H * W; dst += (size_t)blockIdx.z * H * W;      // blockIdx.z: image of a batch (0 otherwise)
     const double a = blur_row_at(src + (size_t)reflect101(r - 1, H) * W, c, W, k0, k1);
     const double b = blur_row_at(src + (size_t)r * W, c, W, k0, k1);
     const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
@@ -105,9 +119,11 @@ __global__ void k_resize(const double* __restrict__ src, int sH, int sW, double*
 // Levels of EventFrame::create from ONE brightness image (EventFrame.cpp:348-357): level 0 is the image, level i >= 1 its
 // dilation + erosion with a (2i+1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue).  blockIdx.z
 // selects the level (level0 + z); each level's image goes to its own plane and its sum of squares is accumulated on the way.
+// (batch != 0: blockIdx.z selects one of many IMAGES instead — src + z * H * W — all at level `level0`)
 __global__ void k_levels(const double* __restrict__ src, double* __restrict__ planes, double* __restrict__ sumsq, int H, int W, int level0,
-                         double* __restrict__ clear) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, rad = level0 + (int)blockIdx.z;
+                         double* __restrict__ clear, int batch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, rad = level0 + (batch ? 0 : (int)blockIdx.z);
+    if (batch) src += (size_t)blockIdx.z * H * W;
     double v = 0.0;
     if (clear && blockIdx.z == 0 && c < W) clear[(size_t)r * W + c] = 0.0;       // the vote image of the NEXT call (not `src`: the blur moved on)
     if (c < W) {
@@ -145,7 +161,7 @@ __global__ void k_store_levels(const double* __restrict__ planes, const double* 
                                int H, int W, int Hp, int Wp, int tiled, int normalise, double* __restrict__ sumsq_next,
                                double* __restrict__ total_out) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)                   // ALL of the other accumulator set, for the next call
+    if (sumsq_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)     // ALL of the other accumulator set, for the next call
         for (int k = threadIdx.x; k < EDS_MAX_LEVELS * EDS_SUMSQ_WAYS; k += blockDim.x) sumsq_next[k] = 0.0;      // (which may build more levels)
     if (c >= Wp - EDS_FRAME_MARGIN) return;
     double ss = 0.0;
@@ -193,6 +209,9 @@ void eds_frame_free(EdsFrameBuffers* fb) {
     for (void* p : d) if (p) hipFree(p);
     if (fb->h_events) hipHostFree(fb->h_events);       // d_ex, d_ey, d_pol are its device view
     if (fb->h_norm_out) hipHostFree(fb->h_norm_out);
+    void* bd[] = {fb->b_img, fb->b_tmp, fb->b_planes, fb->b_norm};
+    for (void* q : bd) if (q) hipFree(q);
+    if (fb->h_bmeta) hipHostFree(fb->h_bmeta);
     *fb = EdsFrameBuffers();
 }
 
@@ -291,7 +310,7 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     // the vote image can be cleared for the next call by k_levels when the image has moved on to another buffer and covers exactly
     // the frame (sensor size == frame size)
     double* clear = (cur != fb.d_img && ns == n && fb.img_elems == n) ? fb.d_img : nullptr;
-    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, norm_cur, H, W, level0, clear);
+    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, norm_cur, H, W, level0, clear, 0);
     hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, nlevels), b2, 0, st, fb.d_planes, norm_cur, h->dframe, first_slot, H, W,
                        h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, norm_next, fb.d_norm_out);
     e = hipGetLastError();
@@ -301,6 +320,87 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     for (int i = 0; i < nlevels; ++i) {
         if (norms_out) norms_out[i] = std::sqrt(fb.h_norm_out[i]);     // the accumulators added up in k_store_levels' order
         h->slots[first_slot + i].has_frame = true;
+    }
+    return EDS_OK;
+}
+
+// `count` independent event slices (one per alignment of a batch: BASELINE.json configs[4] has 64 (keyframe, event frame) pairs) into
+// slots first_slot .. first_slot + count - 1, level `level` each, in chunks of up to EDS_FRAME_BATCH images per pass: one vote launch
+// over all slices of a chunk, one blur, one level + sum-of-squares launch, one normalise + tile launch (blockIdx.z = image).  Same
+// arithmetic per image as eds_frame_build_levels.
+#define EDS_FRAME_BATCH 32
+int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol,
+                          int level, double blur_sigma, int use_exp_weights, double* norms_out) {
+    EdsFrameBuffers& fb = h->frame_build;
+    const int H = h->H, W = h->W;
+    const size_t n = (size_t)H * W;
+    if (fb.d_mapx && (fb.map_H != H || fb.map_W != W)) return eds_internal_fail(EDS_ERR_INVALID, "undistortion map and frame size differ");
+    const int C = std::min(count, EDS_FRAME_BATCH);
+    if (fb.batch_cap < C) {
+        void* d[] = {fb.b_img, fb.b_tmp, fb.b_planes, fb.b_norm};
+        for (void* q : d) if (q) hipFree(q);
+        if (fb.h_bmeta) hipHostFree(fb.h_bmeta);
+        fb.b_img = fb.b_tmp = fb.b_planes = fb.b_norm = nullptr; fb.h_bmeta = nullptr; fb.batch_cap = 0;
+        char* dmeta = nullptr;
+        if (hipMalloc((void**)&fb.b_img, C * n * 8) != hipSuccess || hipMalloc((void**)&fb.b_tmp, C * n * 8) != hipSuccess ||
+            hipMalloc((void**)&fb.b_planes, C * n * 8) != hipSuccess || hipMalloc((void**)&fb.b_norm, (size_t)C * EDS_SUMSQ_WAYS * 8) != hipSuccess ||
+            hipHostMalloc((void**)&fb.h_bmeta, (size_t)C * 8 + (size_t)(C + 1) * 4, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&dmeta, fb.h_bmeta, 0) != hipSuccess)
+            return eds_internal_fail(EDS_ERR_HIP, "allocation of the batched event-frame buffers failed");
+        fb.d_bmeta = dmeta;
+        fb.batch_cap = C;
+    }
+    double* h_tot = reinterpret_cast<double*>(fb.h_bmeta);                       // [cap] totals out
+    int* h_off = reinterpret_cast<int*>(fb.h_bmeta + (size_t)fb.batch_cap * 8);     // [cap + 1] event offsets of the chunk, relative
+    double* d_tot = reinterpret_cast<double*>(fb.d_bmeta);
+    int* d_off = reinterpret_cast<int*>(fb.d_bmeta + (size_t)fb.batch_cap * 8);
+    hipStream_t st = h->st;
+    const dim3 b2(256);
+    for (int c0 = 0; c0 < count; c0 += fb.batch_cap) {
+        const int cn = std::min(fb.batch_cap, count - c0);
+        const int e0 = offsets[c0], ne = offsets[c0 + cn] - e0;
+        int maxn = 0;
+        for (int b = 0; b <= cn; ++b) h_off[b] = offsets[c0 + b] - e0;
+        for (int b = 0; b < cn; ++b) { if (h_off[b + 1] < h_off[b]) return eds_internal_fail(EDS_ERR_INVALID, "offsets must not decrease"); maxn = std::max(maxn, h_off[b + 1] - h_off[b]); }
+        if (ne > fb.cap_events) {           // the mapped staging of the single-slice builder, grown
+            if (fb.h_events) hipHostFree(fb.h_events);
+            fb.h_events = nullptr; fb.d_ex = fb.d_ey = nullptr; fb.d_pol = nullptr;
+            fb.cap_events = (ne + ne / 4 + 1024 + 7) & ~7;
+            uint8_t* dev = nullptr;
+            if (hipHostMalloc((void**)&fb.h_events, (size_t)fb.cap_events * 5, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&dev, fb.h_events, 0) != hipSuccess) { fb.cap_events = 0; return eds_internal_fail(EDS_ERR_HIP, "hipHostMalloc(events)"); }
+            fb.d_ex = reinterpret_cast<uint16_t*>(dev);
+            fb.d_ey = fb.d_ex + fb.cap_events;
+            fb.d_pol = reinterpret_cast<uint8_t*>(fb.d_ey + fb.cap_events);
+        }
+        if (ne > 0) {
+            const size_t cap = (size_t)fb.cap_events;
+            std::memcpy(fb.h_events, ex + e0, (size_t)ne * 2);
+            std::memcpy(fb.h_events + cap * 2, ey + e0, (size_t)ne * 2);
+            std::memcpy(fb.h_events + cap * 4, pol + e0, (size_t)ne);
+        }
+        hipError_t e = hipMemsetAsync(fb.b_img, 0, (size_t)cn * n * 8, st);
+        if (e == hipSuccess) e = hipMemsetAsync(fb.b_norm, 0, (size_t)cn * EDS_SUMSQ_WAYS * 8, st);
+        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+        if (maxn > 0)
+            hipLaunchKernelGGL(k_vote_batch, dim3((maxn + 255) / 256, cn), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, d_off, fb.d_mapx, fb.d_mapy,
+                               H, W, use_exp_weights, fb.b_img);
+        double* cur = fb.b_img;
+        if (blur_sigma > 0.0) {
+            const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), sk = 1.0 + 2.0 * t;
+            hipLaunchKernelGGL(k_blur3, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk);
+            cur = fb.b_tmp;
+        }
+        hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
+        hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + c0, H, W,
+                           h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+        for (int b = 0; b < cn; ++b) {
+            if (norms_out) norms_out[c0 + b] = std::sqrt(h_tot[b]);
+            h->slots[first_slot + c0 + b].has_frame = true;
+        }
     }
     return EDS_OK;
 }

@@ -96,10 +96,17 @@ struct EdsFrameBuffers {
     // other one for the next call; the totals come back through mapped pinned memory.  d_img is cleared by k_levels once the blur
     // has moved the image on (img_clean says whether that happened).  A frame is then 4 launches and one wait: no memset, no copy.
     double *h_norm_out = nullptr, *d_norm_out = nullptr;
+    // batched builder (eds_frame_build_batch): accumulation / blur / level images of up to batch_cap slices, their accumulators, and a
+    // mapped block [totals | event offsets]
+    double *b_img = nullptr, *b_tmp = nullptr, *b_planes = nullptr, *b_norm = nullptr;
+    char *h_bmeta = nullptr, *d_bmeta = nullptr;
+    int batch_cap = 0;
     unsigned calls = 0;
     bool img_clean = false;
 };
 void eds_frame_free(EdsFrameBuffers* fb);
+int  eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* ex, const uint16_t* ey, const uint8_t* pol,
+                           int level, double blur_sigma, int use_exp_weights, double* norms_out);
 // few alignments per launch: one more (tiny) launch writes the kept residuals into pinned host memory as well, so that reading
 // them back (Tracker.cpp:223-230) costs no copy call and no second wait; false: not mirrored (fetch as usual)
 bool eds_mirror_residuals(eds_trk* h, int first, int count);

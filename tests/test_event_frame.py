@@ -194,3 +194,41 @@ def test_builder_state_between_calls(gpu, capi):
             got = h.get_event_frame(i)
             assert np.abs(got - ref_frames[i]).max() <= 1e-6 * np.abs(ref_frames[i]).max(), (k, i)
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level,distort", [(0, True), (1, False)])
+def test_build_event_frame_batch_vs_oracle(gpu, capi, level, distort):
+    """eds_trk_build_event_frame_batch: 37 independent slices (more than one chunk of 32) of ragged sizes — one of them empty, one a
+    single event — into consecutive slots in one call; every frame and norm against the oracle's single-slice builder, and the
+    neighbouring slots untouched."""
+    import np_frame_oracle as fo
+    H, W, B = 60, 80, 40
+    rng = np.random.default_rng(3)
+    sizes = [int(v) for v in rng.integers(50, 4000, 37)]
+    sizes[5] = 0; sizes[20] = 1
+    slices = []
+    mapx = mapy = None
+    for b, n in enumerate(sizes):
+        x, y, pol, mx, my = make_events(500 + b, max(n, 1), H, W, distort=distort)
+        slices.append((x[:n], y[:n], pol[:n]))
+        mapx, mapy = mx, my
+    h = capi.Handle(capi.default_config(), B, 64, H, W)
+    if distort:
+        h.set_undistort_map(mapx, mapy)
+    marker = np.full((H, W), 0.25)
+    h.set_event_frame(1, marker); h.set_event_frame(39, marker)
+    norms = h.build_event_frame_batch(2, slices, level=level)
+    for b, (x, y, pol) in enumerate(slices):
+        got = h.get_event_frame(2 + b)
+        if len(x) == 0:
+            assert norms[b] == 0.0 and np.isnan(got).all()                  # 0 / 0 like the reference
+            continue
+        ref, ref_norm = fo.event_frame(x, y, pol, H, W, mapx, mapy, level=level)
+        assert norms[b] == pytest.approx(ref_norm, rel=1e-11), b
+        assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), b
+    assert np.array_equal(h.get_event_frame(1), marker.astype(np.float32).astype(np.float64))
+    assert np.array_equal(h.get_event_frame(39), marker.astype(np.float32).astype(np.float64))
+    with pytest.raises(capi.EdsError):
+        h.build_event_frame_batch(10, slices)                            # 10 + 37 slots do not fit 40
+    h.close()

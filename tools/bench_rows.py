@@ -48,3 +48,24 @@ for md in (3000, 30000):
         t = time.perf_counter(); ref = ko.keyframe(img, K, method, npts, depth_xy=dxy, depth_idp=didp); dcpu = time.perf_counter() - t
         print(f"keyframe set-up 640x480 {name:10s} depth map {md:6d}: GPU {dt*1e3:7.2f} ms incl. image upload + readback of {len(out['idp']):6d} points | numpy oracle {dcpu*1e3:8.1f} ms")
     hk.close()
+# batched event frames (configs[4]: one frame per alignment): 64 slices in one call vs 64 single calls
+hb = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE), 64, 2000, H, W)
+for n in (10_000, 100_000):
+    sl = [(rng.integers(0, W, n).astype(np.uint16), rng.integers(0, H, n).astype(np.uint16), rng.integers(0, 2, n).astype(np.uint8)) for b in range(64)]
+    offs = np.arange(65, dtype=np.int32) * n
+    cx = np.concatenate([s_[0] for s_ in sl]); cy = np.concatenate([s_[1] for s_ in sl]); cp = np.concatenate([s_[2] for s_ in sl])
+    import ctypes as C
+    norms = np.zeros(64)
+    call = lambda: capi.lib().eds_trk_build_event_frame_batch(hb._h, 0, 64, offs.ctypes.data_as(C.POINTER(C.c_int32)), cx.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                               cy.ctypes.data_as(C.POINTER(C.c_uint16)), cp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, 0.5, 1,
+                                                               norms.ctypes.data_as(C.POINTER(C.c_double)))
+    call()
+    t = time.perf_counter()
+    for _ in range(5): call()
+    tb = (time.perf_counter() - t) / 5
+    for b in range(64): hb.build_event_frame(b, *sl[b])
+    t = time.perf_counter()
+    for b in range(64): hb.build_event_frame(b, *sl[b])
+    ts = time.perf_counter() - t
+    print(f"64 event frames of {n:7d} events: one batched call {tb*1e6:8.1f} us ({tb/64*1e6:5.1f} us per frame) | 64 single calls {ts*1e6:8.1f} us ({ts/64*1e6:5.1f} each)")
+hb.close()
