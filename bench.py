@@ -252,10 +252,32 @@ def latency_block(capi, synth, al, a):
         h.optimize_batch(0, 0, B64, sync=True)
     out["B64_ms"] = med(batch64)
     out["B64_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
+
+    # a whole tracking step of 64 trackers at once (configs[4] end to end on one GPU): 64 event slices of 20 k events -> frames (one
+    # batched call), the 64 solves, the 64 MAD scales, getCoord / culling / keyframe criterion of all 64
+    slices = []
+    for b in range(B64):
+        fr = als64[b % 8].frame
+        strong64 = np.argwhere(np.abs(fr) > 0.25 * np.abs(fr).max())
+        pk = strong64[rng.integers(0, len(strong64), 20_000)]
+        slices.append((pk[:, 1].astype(np.uint16), pk[:, 0].astype(np.uint16), (fr[pk[:, 0], pk[:, 1]] > 0).astype(np.uint8)))
+    import ctypes as C
+    offs = (np.arange(B64 + 1) * 20_000).astype(np.int32)
+    cx = np.concatenate([s_[0] for s_ in slices]); cy = np.concatenate([s_[1] for s_ in slices]); cp = np.concatenate([s_[2] for s_ in slices])
+
+    def step64():
+        rc = capi.lib().eds_trk_build_event_frame_batch(h._h, 0, B64, offs.ctypes.data_as(C.POINTER(C.c_int32)), cx.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                        cy.ctypes.data_as(C.POINTER(C.c_uint16)), cp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, 0.5, 1, None)
+        assert rc == 0
+        h.set_states(0, P0, Q0, V0)
+        h.optimize_batch(0, 0, B64, sync=True)
+        h.loss_param_batch(capi.LP_MAD, 0, B64)
+        h.update_points_batch(0, B64, False, want_points=False)
+    out["B64_step_ms"] = med(step64, reps=10)
     h.close()
     out["note"] = ("wall time per call through the C ABI, inputs resident; B1: one 640x480-class alignment, B64: one launch of 64 (configs[4] on "
                    "one GPU); slice: 100 k events -> frame -> REF12 (4 blocks, Huber) -> MAD -> getCoord; live_call: the shim's sequence with a host fp64 "
-                   "frame; config3: one 4-level coarse-to-fine call (2 000 .. 16 000 points)")
+                   "frame; config3: one 4-level coarse-to-fine call (2 000 .. 16 000 points); B64_step: events -> 64 frames -> 64 solves -> MAD -> getCoord criterion, batched calls")
     return out
 
 

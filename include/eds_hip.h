@@ -238,6 +238,13 @@ int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, doubl
 int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* coord_xy, double* tracks_xy,
                           int32_t* kept_index, int* n_kept, double* mean_sq_flow);
 
+/* The same for slots first .. first + count - 1 in one launch per 64 alignments (one workgroup each).  Outputs of alignment b start at
+ * point index b * stride of coord_xy / tracks_xy / kept_index (stride >= the largest point count) and at n_kept[b], mean_sq_flow[b]; with
+ * the three point arrays NULL only the culling, the counts and the keyframe criterion are produced (nothing but 16 bytes per
+ * alignment comes back). */
+int eds_trk_update_points_batch(eds_trk* h, int first, int count, int delete_out_points, int stride, double* coord_xy, double* tracks_xy,
+                                int32_t* kept_index, int* n_kept, double* mean_sq_flow);
+
 /* ---- keyframe point set-up on the device -------------------------------------------- */
 enum eds_kf_method { EDS_KF_MAX = 0, EDS_KF_MEDIAN = 1 };   /* eds::tracking::CANDIDATE_POINT_METHOD */
 enum eds_img_type { EDS_IMG_U8 = 0, EDS_IMG_F32 = 1, EDS_IMG_F64 = 2 };

@@ -38,7 +38,7 @@ EXPORTS = (
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
-    "eds_trk_loss_param_batch", "eds_trk_update_points",
+    "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
@@ -142,6 +142,7 @@ def lib():
         L.eds_trk_loss_param.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
         L.eds_trk_loss_param_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
         L.eds_trk_update_points.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp]
+        L.eds_trk_update_points_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp, _ip, _ip, _dp]
         L.eds_kf_select_default.argtypes = [C.POINTER(KfSelect)]
         L.eds_kf_select_default.restype = None
         L.eds_trk_build_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(KfSelect), C.c_int, _dp, _dp,
@@ -415,6 +416,27 @@ class Handle:
                                            kept.ctypes.data_as(_ip), C.cast(C.byref(n), _ip), C.cast(C.byref(flow), _dp)))
         self._N[slot] = n.value
         return dict(coord=coord[:n.value], tracks=tracks[:n.value], kept=kept[:n.value], mean_sq_flow=flow.value)
+
+    def update_points_batch(self, first=0, count=None, delete_out_points=True, want_points=True):
+        """Tracker::getCoord(delete_out_point) for a range of slots in one call: list of dicts like update_points (coord / tracks /
+        kept are None with want_points=False: only culling, counts and the mean squared flow)."""
+        count = self.batch - first if count is None else count
+        stride = max(self._N[first:first + count] + [1])
+        n = np.zeros(count, dtype=np.int32); flow = np.zeros(count)
+        if want_points:
+            coord, tracks = np.zeros((count, stride, 2)), np.zeros((count, stride, 2))
+            kept = np.zeros((count, stride), dtype=np.int32)
+            _check(lib().eds_trk_update_points_batch(self._h, first, count, int(bool(delete_out_points)), stride, _p(coord), _p(tracks),
+                                                     kept.ctypes.data_as(_ip), n.ctypes.data_as(_ip), _p(flow)))
+        else:
+            _check(lib().eds_trk_update_points_batch(self._h, first, count, int(bool(delete_out_points)), stride, None, None, None,
+                                                     n.ctypes.data_as(_ip), _p(flow)))
+        out = []
+        for b in range(count):
+            self._N[first + b] = int(n[b])
+            out.append(dict(coord=coord[b, :n[b]] if want_points else None, tracks=tracks[b, :n[b]] if want_points else None,
+                            kept=kept[b, :n[b]] if want_points else None, mean_sq_flow=float(flow[b]), n=int(n[b])))
+        return out
 
     # -- keyframe set-up on the device ------------------------------------------------------
     def build_keyframe(self, slot, img, K, method=KF_MEDIAN, num_points=0, cell=20, depth_xy=None, depth_idp=None,

@@ -1016,6 +1016,36 @@ int eds_trk_update_points(eds_trk* h, int slot, int delete_out_points, double* c
     return EDS_OK;
 }
 
+int eds_trk_update_points_batch(eds_trk* h, int first, int count, int delete_out_points, int stride, double* coord_xy, double* tracks_xy,
+                                int32_t* kept_index, int* n_kept, double* mean_sq_flow) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (count < 1 || first < 0 || first + count > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds");
+    int maxN = 0;
+    for (int s = first; s < first + count; ++s) {
+        if (!h->slots[s].has_kf) return fail(EDS_ERR_STATE, "keyframe not set");
+        maxN = std::max(maxN, h->slots[s].N);
+    }
+    if ((coord_xy || tracks_xy || kept_index) && stride < maxN) return fail(EDS_ERR_INVALID, "stride smaller than the largest point count");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    std::vector<int> n(count);
+    int rc = eds_points_update_batch(h, first, count, delete_out_points != 0, stride, coord_xy, tracks_xy, kept_index, n.data(), mean_sq_flow);
+    if (rc) return rc;
+    bool any = false;
+    for (int b = 0; b < count; ++b) {
+        Slot& s = h->slots[first + b];
+        if (n_kept) n_kept[b] = n[b];
+        if (n[b] != s.N) {                  // points were erased: every index-aligned plane was compacted on the device
+            s.N = n[b];
+            s.residuals.clear();
+            s.res_on_device = false;
+            if (n[b] > 0) { if ((rc = refresh_gram(h, first + b, false))) return rc; any = true; }
+            else s.has_kf = false;
+        }
+    }
+    if (any) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); h->gram_pending = false; }
+    return EDS_OK;
+}
+
 /* ---- keyframe point set-up on the device ------------------------------------------ */
 void eds_kf_select_default(eds_kf_select* sel) {
     if (!sel) return;

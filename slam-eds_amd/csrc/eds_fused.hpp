@@ -121,6 +121,7 @@ struct EdsPointBuffers {
     // kernel reads / writes it over PCIe (36 B per point), the call is one launch and one wait — no copy calls (each costs
     // 5-10 us on the live path: 93 -> 30 us per 2 000-point alignment)
     char* h_block = nullptr;            // host address of the block
+    int cap = 0;                        // alignments it has room for (the batched entry point grows it)
     double *h_summary = nullptr, *h_pose = nullptr, *h_coord = nullptr, *h_track = nullptr;
     int* h_kept = nullptr;
     double *d_coord = nullptr, *d_track = nullptr, *d_summary = nullptr, *d_pose = nullptr;    // the same, as the device sees them
@@ -132,6 +133,8 @@ bool eds_points_supported(const eds_trk* h, int first, int count);
 int  eds_points_loss_param(eds_trk* h, int first, int count, int method, double* tau_out);
 int  eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, double* tracks_xy, int32_t* kept_index, int* n_kept,
                        double* mean_sq_flow);
+int  eds_points_update_batch(eds_trk* h, int first, int count, int delete_out, int stride, double* coord_xy, double* tracks_xy,
+                             int32_t* kept_index, int* n_kept, double* mean_sq_flow);
 
 // ---- keyframe point set-up on device (eds_keyframe.hip) ------------------------------------------------------
 struct eds_kf_select;

@@ -9,6 +9,7 @@
 //                    pixel, mean squared flow for Tracker::needNewKeyframe (Tracker.cpp:650-654)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <tuple>
 
 #include <cmath>
@@ -86,10 +87,17 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_loss_param(EdsArrays A, int
 
 // One workgroup per alignment; per sweep lane t owns the CONTIGUOUS points [t*cppt, (t+1)*cppt) so that an exclusive scan of the
 // per-lane keep counts gives order-preserving destinations.
-__global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, int slot, int ppt, int delete_out, const double* __restrict__ pose_in,
+// (blockIdx.x: alignment of a batch — slot first + blockIdx.x, its pose, outputs and summary at their blockIdx.x-th places; coord /
+// track / kept may be null: only the compaction, the count and the mean squared flow are wanted)
+__global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, int first, int ppt, int delete_out, const double* __restrict__ pose_in,
                                                                   double* __restrict__ coord, double* __restrict__ track,
                                                                   int* __restrict__ kept, double* __restrict__ summary) {
     const int tid = threadIdx.x;
+    const int slot = first + (int)blockIdx.x;
+    pose_in += 16 * (size_t)blockIdx.x; summary += 2 * (size_t)blockIdx.x;
+    if (coord) coord += 2 * (size_t)A.Np * blockIdx.x;
+    if (track) track += 2 * (size_t)A.Np * blockIdx.x;
+    if (kept) kept += (size_t)A.Np * blockIdx.x;
     double* pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const int N = (int)pb[EDS_PB_N];
     const size_t base = (size_t)slot * A.Np;
@@ -162,10 +170,10 @@ __global__ __launch_bounds__(EDS_PTS_THREADS) void k_update_points(EdsArrays A, 
             const size_t o = base + dst;
             const_cast<float*>(A.x)[o] = fx_[k]; const_cast<float*>(A.y)[o] = fy_[k]; const_cast<float*>(A.rho)[o] = frho[k]; const_cast<float*>(A.gx)[o] = fgx[k]; const_cast<float*>(A.gy)[o] = fgy[k]; const_cast<float*>(A.w)[o] = fw[k];
             const_cast<float*>(A.f0x)[o] = ff0x[k]; const_cast<float*>(A.f0y)[o] = ff0y[k]; const_cast<int*>(A.cell0)[o] = fcell[k];
-            coord[2 * dst] = xp[k]; coord[2 * dst + 1] = yp[k];
+            if (coord) { coord[2 * dst] = xp[k]; coord[2 * dst + 1] = yp[k]; }
             const double u0 = (double)(short)(fcell[k] & 0xffff) + (double)ff0x[k], v0 = (double)(fcell[k] >> 16) + (double)ff0y[k];
-            track[2 * dst] = xp[k] - u0; track[2 * dst + 1] = yp[k] - v0;
-            kept[dst] = c0 + tid * cppt + k;
+            if (track) { track[2 * dst] = xp[k] - u0; track[2 * dst + 1] = yp[k] - v0; }
+            if (kept) kept[dst] = c0 + tid * cppt + k;
             ++dst;
         }
         if (tid == 0) s_run = run + ctotal;
@@ -194,23 +202,27 @@ void eds_points_free(EdsPointBuffers* pbuf) {
     *pbuf = EdsPointBuffers();
 }
 
-static int ensure(eds_trk* h) {
+#define EDS_PTS_BATCH 64                // alignments per launch of the batched getCoord (4.7 MB of pinned outputs at 2 048 points)
+static int ensure(eds_trk* h, int cap = 1) {
     EdsPointBuffers& pb = h->point_ops;
-    if (pb.h_block) return EDS_OK;
+    if (pb.h_block && pb.cap >= cap) return EDS_OK;
+    if (pb.h_block) { hipHostFree(pb.h_block); pb.h_block = nullptr; }
     const size_t Np = (size_t)h->Np;
-    const size_t bytes = 16 + 128 + Np * 16 + Np * 16 + Np * 4;        // summary | pose | coord | track | kept
+    const size_t bytes = (size_t)cap * (16 + 128 + Np * 16 + Np * 16 + Np * 4);        // summary | pose | coord | track | kept, `cap` of each
     char* dblock = nullptr;
     if (hipHostMalloc((void**)&pb.h_block, bytes, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer((void**)&dblock, pb.h_block, 0) != hipSuccess || hipMalloc((void**)&pb.d_tau, (size_t)h->B * 8) != hipSuccess) {
+        hipHostGetDevicePointer((void**)&dblock, pb.h_block, 0) != hipSuccess ||
+        (!pb.d_tau && hipMalloc((void**)&pb.d_tau, (size_t)h->B * 8) != hipSuccess)) {
         eds_points_free(&pb);
         return eds_internal_fail(EDS_ERR_HIP, "allocation of the point buffers failed");
     }
+    pb.cap = cap;
     auto carve = [&](char* base) {
         double* sum = reinterpret_cast<double*>(base);
-        double* pose = sum + 2;
-        double* coord = pose + 16;
-        double* track = coord + 2 * Np;
-        int* kept = reinterpret_cast<int*>(track + 2 * Np);
+        double* pose = sum + 2 * (size_t)cap;
+        double* coord = pose + 16 * (size_t)cap;
+        double* track = coord + 2 * Np * cap;
+        int* kept = reinterpret_cast<int*>(track + 2 * Np * cap);
         return std::make_tuple(sum, pose, coord, track, kept);
     };
     std::tie(pb.h_summary, pb.h_pose, pb.h_coord, pb.h_track, pb.h_kept) = carve(pb.h_block);
@@ -244,27 +256,47 @@ int eds_points_loss_param(eds_trk* h, int first, int count, int method, double* 
     return EDS_OK;
 }
 
-int eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, double* tracks_xy, int32_t* kept_index, int* n_kept,
-                      double* mean_sq_flow) {
-    int rc = ensure(h);
+// getCoord (+ culling) of slots [first, first + count) — one workgroup per alignment, EDS_PTS_BATCH alignments per launch.  Outputs of
+// alignment b start at index b * stride of the caller's arrays (points) resp. b (n_kept, mean_sq_flow).
+int eds_points_update_batch(eds_trk* h, int first, int count, int delete_out, int stride, double* coord_xy, double* tracks_xy, int32_t* kept_index,
+                            int* n_kept, double* mean_sq_flow) {
+    int rc = ensure(h, std::min(count, EDS_PTS_BATCH));
     if (rc) return rc;
     EdsPointBuffers& pb = h->point_ops;
-    Slot& sl = h->slots[slot];
-    double* hp = pb.h_pose;                     // the kernel reads the pose where the host writes it
-    edsm::quat_to_RmI(sl.q, hp);
-    for (int i = 0; i < 3; ++i) hp[9 + i] = sl.p[i];
-    hp[12] = sl.K[0]; hp[13] = sl.K[1]; hp[14] = (double)h->W; hp[15] = (double)h->H;     // kf->img.cols / rows
-    const int ppt = (sl.N + EDS_PTS_THREADS - 1) / EDS_PTS_THREADS;
-    hipLaunchKernelGGL(k_update_points, dim3(1), dim3(EDS_PTS_THREADS), 0, h->st, h->arrays(), slot, ppt, delete_out, pb.d_pose, pb.d_coord,
-                       pb.d_track, pb.d_kept, pb.d_summary);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
-    if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-    const int n = (int)pb.h_summary[0];
-    if (coord_xy && n > 0) std::memcpy(coord_xy, pb.h_coord, (size_t)n * 16);
-    if (tracks_xy && n > 0) std::memcpy(tracks_xy, pb.h_track, (size_t)n * 16);
-    if (kept_index && n > 0) std::memcpy(kept_index, pb.h_kept, (size_t)n * 4);
-    if (n_kept) *n_kept = n;
-    if (mean_sq_flow) *mean_sq_flow = pb.h_summary[1];
+    const size_t Np = (size_t)h->Np;
+    for (int c0 = 0; c0 < count; c0 += pb.cap) {
+        const int cn = std::min(pb.cap, count - c0);
+        int maxN = 0;
+        for (int b = 0; b < cn; ++b) {
+            const Slot& sl = h->slots[first + c0 + b];
+            double* hp = pb.h_pose + 16 * (size_t)b;                // the kernel reads the poses where the host writes them
+            edsm::quat_to_RmI(sl.q, hp);
+            for (int i = 0; i < 3; ++i) hp[9 + i] = sl.p[i];
+            hp[12] = sl.K[0]; hp[13] = sl.K[1]; hp[14] = (double)h->W; hp[15] = (double)h->H;     // kf->img.cols / rows
+            maxN = std::max(maxN, sl.N);
+        }
+        const int ppt = (maxN + EDS_PTS_THREADS - 1) / EDS_PTS_THREADS;
+        hipLaunchKernelGGL(k_update_points, dim3(cn), dim3(EDS_PTS_THREADS), 0, h->st, h->arrays(), first + c0, ppt, delete_out, pb.d_pose,
+                           coord_xy ? pb.d_coord : nullptr, tracks_xy ? pb.d_track : nullptr, kept_index ? pb.d_kept : nullptr, pb.d_summary);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+        for (int b = 0; b < cn; ++b) {
+            const int n = (int)pb.h_summary[2 * b];
+            const size_t o = (size_t)(c0 + b) * stride;
+            if (coord_xy && n > 0) std::memcpy(coord_xy + 2 * o, pb.h_coord + 2 * Np * b, (size_t)n * 16);
+            if (tracks_xy && n > 0) std::memcpy(tracks_xy + 2 * o, pb.h_track + 2 * Np * b, (size_t)n * 16);
+            if (kept_index && n > 0) std::memcpy(kept_index + o, pb.h_kept + Np * b, (size_t)n * 4);
+            if (n_kept) n_kept[c0 + b] = n;
+            if (mean_sq_flow) mean_sq_flow[c0 + b] = pb.h_summary[2 * b + 1];
+        }
+    }
     return EDS_OK;
+}
+
+int eds_points_update(eds_trk* h, int slot, int delete_out, double* coord_xy, double* tracks_xy, int32_t* kept_index, int* n_kept,
+                      double* mean_sq_flow) {
+    // (single alignment: all three outputs are produced — the caller of the single-slot entry point nearly always wants them, and the
+    // kernel is the same)
+    return eds_points_update_batch(h, slot, 1, delete_out, h->Np, coord_xy, tracks_xy, kept_index, n_kept, mean_sq_flow);
 }

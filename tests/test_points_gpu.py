@@ -129,3 +129,54 @@ def test_point_maintenance_and_loss_scale_beyond_4096_points(gpu, capi, synth, p
     e = po.Oracle(al2).pose6_eval(pe, qe, al.v0)
     assert g["r"].shape == (len(keep),) and np.abs(g["r"] - e["r"]).max() <= 1e-5 * np.abs(e["r"]).max()
     h.close()
+
+
+@pytest.mark.parametrize("want_points", [True, False])
+def test_update_points_batch_vs_oracle_and_single_calls(gpu, capi, synth, po, want_points):
+    """eds_trk_update_points_batch: 70 alignments (more than one launch of 64) of ragged point counts, each at its own pose — kept
+    indices, coordinates, tracks, counts and mean squared flow per alignment against the oracle; the compacted planes then solve like
+    keyframes uploaded with the kept points only; with the point arrays NULL only counts and flow come back."""
+    import np_points_oracle as pto
+    B = 70
+    rng = np.random.default_rng(17)
+    als = [synth.make_alignment(700 + b, H=120, W=160, N=int(rng.integers(64, 900)), margin=2) for b in range(8)]
+    h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=4), B + 2, 900, 120, 160)
+    poses, refs = [], []
+    for b in range(B):
+        al = als[b % 8]
+        h.set_alignment(1 + b, al)
+        p = np.array([0.06, -0.03, 0.01]) * rng.uniform(-1.0, 1.0, 3)
+        q = synth.quat_from_axis_angle(rng.standard_normal(3), 0.05 * rng.uniform())
+        h.set_state(1 + b, p, q, al.v0)
+        poses.append((p, q))
+        refs.append(pto.get_coord(al.norm_coord, al.idp, al.coord, (al.fx, al.fy, al.cx, al.cy), al.H, al.W, p, q, True))
+    h.set_alignment(0, als[0]); h.set_alignment(B + 1, als[1])                 # neighbours that must stay as they are
+    outs = h.update_points_batch(1, B, True, want_points=want_points)
+    erased = 0
+    for b in range(B):
+        ref, out = refs[b], outs[b]
+        assert out["n"] == len(ref["kept"]), b
+        erased += als[b % 8].N - out["n"]
+        assert out["mean_sq_flow"] == pytest.approx(ref["mean_sq_flow"], rel=1e-5)
+        if want_points:
+            assert np.array_equal(out["kept"], ref["kept"])
+            assert np.abs(out["coord"] - ref["coord"]).max() < 5e-5
+            assert np.abs(out["tracks"] - ref["tracks"]).max() < 5e-5
+    assert erased > 100                                                        # the poses do push points out
+    # the compacted planes: a solve equals the oracle's on the kept points (a few alignments)
+    for b in (0, 13, 64, 69):
+        al, keep = als[b % 8], refs[b]["kept"]
+        if len(keep) < 32:
+            continue
+        al2 = type(al)(**{**al.__dict__, "norm_coord": al.norm_coord[keep], "grad": al.grad[keep], "idp": al.idp[keep],
+                          "weights": al.weights[keep], "coord": al.coord[keep]})
+        h.set_state(1 + b, al.p0, al.q0, al.v0)
+        h.optimize_batch(0, 1 + b, 1)
+        tab = h.results(1 + b, 1)[0]
+        ref = po.Oracle(al2).pose6_lm(al.p0, al.q0, al.v0, iters=4, lambda0=0.01)
+        assert po.se3_distance(tab[0:3], tab[3:7], ref["p"], ref["q"]) <= 1e-4
+    # neighbours untouched
+    for s_, al in ((0, als[0]), (B + 1, als[1])):
+        out = h.update_points(s_, False)
+        assert out["coord"].shape[0] == al.N
+    h.close()

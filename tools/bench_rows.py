@@ -69,3 +69,30 @@ for n in (10_000, 100_000):
     ts = time.perf_counter() - t
     print(f"64 event frames of {n:7d} events: one batched call {tb*1e6:8.1f} us ({tb/64*1e6:5.1f} us per frame) | 64 single calls {ts*1e6:8.1f} us ({ts/64*1e6:5.1f} each)")
 hb.close()
+# one tracking step of 64 trackers on one GPU (configs[4] end to end): 64 event slices -> frames, LM6 solves, MAD scales, getCoord / culling
+hs = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10), 64, 2000, H, W)
+als64 = [synth.make_alignment(5000 + i) for i in range(8)]
+for b in range(64): hs.set_alignment(b, als64[b % 8])
+sl = []
+for b in range(64):
+    fr = als64[b % 8].frame
+    strong = np.argwhere(np.abs(fr) > 0.25 * np.abs(fr).max())
+    pick = strong[rng.integers(0, len(strong), 20_000)]
+    sl.append((pick[:, 1].astype(np.uint16), pick[:, 0].astype(np.uint16), (fr[pick[:, 0], pick[:, 1]] > 0).astype(np.uint8)))
+offs = (np.arange(65) * 20_000).astype(np.int32)
+cx = np.concatenate([s_[0] for s_ in sl]); cy = np.concatenate([s_[1] for s_ in sl]); cp = np.concatenate([s_[2] for s_ in sl])
+P0 = np.stack([als64[b % 8].p0 for b in range(64)]); Q0 = np.stack([als64[b % 8].q0 for b in range(64)]); V0 = np.stack([als64[b % 8].v0 for b in range(64)])
+import ctypes as C
+def step64():
+    capi.lib().eds_trk_build_event_frame_batch(hs._h, 0, 64, offs.ctypes.data_as(C.POINTER(C.c_int32)), cx.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               cy.ctypes.data_as(C.POINTER(C.c_uint16)), cp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, 0.5, 1, None)
+    hs.set_states(0, P0, Q0, V0)
+    hs.optimize_batch(0, 0, 64)
+    hs.loss_param_batch(capi.LP_MAD, 0, 64)
+    hs.update_points_batch(0, 64, False, want_points=False)
+for _ in range(3): step64()
+t = time.perf_counter()
+for _ in range(10): step64()
+dt = (time.perf_counter() - t) / 10
+print(f"one step of 64 trackers (20 k events each -> frames, LM6 x10, MAD, getCoord criterion): {dt*1e6:.1f} us = {dt/64*1e6:.1f} us per tracker")
+hs.close()
