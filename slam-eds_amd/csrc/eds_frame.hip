@@ -76,14 +76,30 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 __device__ __forceinline__ double blur_row_at(const double* __restrict__ row, int c, int W, double k0, double k1) {
     return k0 * row[reflect101(c - 1, W)] + k1 * row[c] + k0 * row[reflect101(c + 1, W)];
 }
-__global__ void k_blur3(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1) {
+#define EDS_SUMSQ_WAYS 64
+// (SUMSQ: the blurred image IS level 0 — it goes straight to the level plane and its sum of squares is accumulated here, one launch
+// and one pass over the image less than blur -> k_levels; blockIdx.z: image of a batch, 0 otherwise)
+template <bool SUMSQ>
+__global__ void k_blur3(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1, double* __restrict__ sumsq) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= W) return;
-    src += (size_t)blockIdx.z * H * W; dst += (size_t)blockIdx.z * H * W;      // blockIdx.z: image of a batch (0 otherwise)
-    const double a = blur_row_at(src + (size_t)reflect101(r - 1, H) * W, c, W, k0, k1);
-    const double b = blur_row_at(src + (size_t)r * W, c, W, k0, k1);
-    const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
-    dst[(size_t)r * W + c] = k0 * a + k1 * b + k0 * d;
+    src += (size_t)blockIdx.z * H * W; dst += (size_t)blockIdx.z * H * W;
+    double v = 0.0;
+    if (c < W) {
+        const double a = blur_row_at(src + (size_t)reflect101(r - 1, H) * W, c, W, k0, k1);
+        const double b = blur_row_at(src + (size_t)r * W, c, W, k0, k1);
+        const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
+        v = k0 * a + k1 * b + k0 * d;
+        dst[(size_t)r * W + c] = v;
+    }
+    if (SUMSQ) {                        // as k_levels
+        double s = v * v;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        __shared__ double sh[4];
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&sumsq[blockIdx.z * EDS_SUMSQ_WAYS + ((blockIdx.y * gridDim.x + blockIdx.x) & (EDS_SUMSQ_WAYS - 1))],
+                                        sh[0] + sh[1] + sh[2] + sh[3]);
+    }
 }
 // cv::resize(src, dst, out_size, cv::INTER_CUBIC) as the reference WRITES it (EventFrame.cpp:345, KeyFrame.cpp:355): the fourth
 // positional parameter of cv::resize is `fx`, not the interpolation, so the call runs with the default INTER_LINEAR — and OpenCV
@@ -115,7 +131,6 @@ __global__ void k_resize(const double* __restrict__ src, int sH, int sW, double*
     const double h1 = src[(size_t)y1 * sW + x0] * a0 + src[(size_t)y1 * sW + x1] * a1;
     dst[(size_t)r * W + c] = h0 * b0 + h1 * b1;
 }
-#define EDS_SUMSQ_WAYS 64
 // Levels of EventFrame::create from ONE brightness image (EventFrame.cpp:348-357): level 0 is the image, level i >= 1 its
 // dilation + erosion with a (2i+1)^2 box; pixels outside the image are ignored (cv::morphologyDefaultBorderValue).  blockIdx.z
 // selects the level (level0 + z); each level's image goes to its own plane and its sum of squares is accumulated on the way.
@@ -159,8 +174,9 @@ __global__ void k_levels(const double* __restrict__ src, double* __restrict__ pl
 // level / ||level||_F -> fp32 in the handle's layout, one slot per level (padding and margin filled with the nearest border pixel)
 __global__ void k_store_levels(const double* __restrict__ planes, const double* __restrict__ sumsq, float* __restrict__ frames, int first_slot,
                                int H, int W, int Hp, int Wp, int tiled, int normalise, double* __restrict__ sumsq_next,
-                               double* __restrict__ total_out) {
+                               double* __restrict__ total_out, double* __restrict__ clear) {
     const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x) - EDS_FRAME_MARGIN, r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+    if (clear && blockIdx.z == 0 && r >= 0 && r < H && c >= 0 && c < W) clear[(size_t)r * W + c] = 0.0;   // the vote image of the NEXT call
     if (sumsq_next && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)     // ALL of the other accumulator set, for the next call
         for (int k = threadIdx.x; k < EDS_MAX_LEVELS * EDS_SUMSQ_WAYS; k += blockDim.x) sumsq_next[k] = 0.0;      // (which may build more levels)
     if (c >= Wp - EDS_FRAME_MARGIN) return;
@@ -298,21 +314,24 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     const dim3 b2(256);
     double* cur = fb.d_img;
     double* other = fb.d_tmp;
+    // one plain level at the sensor's size: the blurred image is the level — blur, plane and sum of squares in one launch
+    const bool fused0 = blur_sigma > 0.0 && nlevels == 1 && level0 == 0 && sH == H && sW == W;
     if (blur_sigma > 0.0) {             // cv::getGaussianKernel(3, sigma): exp(-x^2 / (2 sigma^2)), normalised
         const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), s = 1.0 + 2.0 * t;
-        hipLaunchKernelGGL(k_blur3, dim3((sW + 255) / 256, sH), b2, 0, st, cur, other, sH, sW, t / s, 1.0 / s);
+        if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((sW + 255) / 256, sH), b2, 0, st, cur, fb.d_planes, sH, sW, t / s, 1.0 / s, norm_cur);
+        else hipLaunchKernelGGL(k_blur3<false>, dim3((sW + 255) / 256, sH), b2, 0, st, cur, other, sH, sW, t / s, 1.0 / s, (double*)nullptr);
         std::swap(cur, other);
     }
     if (sH != H || sW != W) {           // out_scale != 1 (EventFrame.cpp:342-346)
         hipLaunchKernelGGL(k_resize, dim3((W + 255) / 256, H), b2, 0, st, cur, sH, sW, other, H, W);
         std::swap(cur, other);
     }
-    // the vote image can be cleared for the next call by k_levels when the image has moved on to another buffer and covers exactly
-    // the frame (sensor size == frame size)
-    double* clear = (cur != fb.d_img && ns == n && fb.img_elems == n) ? fb.d_img : nullptr;
-    hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, norm_cur, H, W, level0, clear, 0);
+    // the vote image can be cleared for the next call once the blur has read it (by k_levels, or by the store when k_levels is not
+    // run), provided it covers exactly the frame (sensor size == frame size)
+    double* clear = (blur_sigma > 0.0 && ns == n && fb.img_elems == n) ? fb.d_img : nullptr;
+    if (!fused0) hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, nlevels), b2, 0, st, cur, fb.d_planes, norm_cur, H, W, level0, clear, 0);
     hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, nlevels), b2, 0, st, fb.d_planes, norm_cur, h->dframe, first_slot, H, W,
-                       h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, norm_next, fb.d_norm_out);
+                       h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, norm_next, fb.d_norm_out, fused0 ? clear : (double*)nullptr);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
@@ -386,14 +405,16 @@ int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offs
             hipLaunchKernelGGL(k_vote_batch, dim3((maxn + 255) / 256, cn), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, d_off, fb.d_mapx, fb.d_mapy,
                                H, W, use_exp_weights, fb.b_img);
         double* cur = fb.b_img;
+        const bool fused0 = blur_sigma > 0.0 && level == 0;       // the blurred image is the level: blur + plane + sum of squares in one launch
         if (blur_sigma > 0.0) {
             const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), sk = 1.0 + 2.0 * t;
-            hipLaunchKernelGGL(k_blur3, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk);
+            if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, H, W, t / sk, 1.0 / sk, fb.b_norm);
+            else hipLaunchKernelGGL(k_blur3<false>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk, (double*)nullptr);
             cur = fb.b_tmp;
         }
-        hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
+        if (!fused0) hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
         hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + c0, H, W,
-                           h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot);
+                           h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot, (double*)nullptr);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
