@@ -126,7 +126,7 @@ struct EdsPointBuffers {
     int* h_kept = nullptr;
     double *d_coord = nullptr, *d_track = nullptr, *d_summary = nullptr, *d_pose = nullptr;    // the same, as the device sees them
     int* d_kept = nullptr;
-    double* d_tau = nullptr;            // device loss scales of a batch (HBM)
+    double *h_tau = nullptr, *d_tau = nullptr;    // loss scales of a batch: mapped pinned memory, host / device view
 };
 void eds_points_free(EdsPointBuffers* pb);
 bool eds_points_supported(const eds_trk* h, int first, int count);
