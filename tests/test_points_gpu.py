@@ -180,3 +180,25 @@ def test_update_points_batch_vs_oracle_and_single_calls(gpu, capi, synth, po, wa
         out = h.update_points(s_, False)
         assert out["coord"].shape[0] == al.N
     h.close()
+
+
+def test_batched_entry_points_with_one_slot_equal_the_single_slot_ones(gpu, capi, synth):
+    """count = 1 of the batched getCoord / loss scale / event-frame entry points against their single-slot twins (same kernels, the
+    batch dimension collapsed): identical outputs."""
+    al = synth.make_alignment(77, H=120, W=160, N=700, margin=2)
+    p = np.array([0.05, -0.02, 0.01]); q = synth.quat_from_axis_angle([0.2, 1.0, 0.1], 0.04)
+    outs = []
+    for batched in (False, True):
+        h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=3), 2, al.N, al.H, al.W)
+        h.set_alignment(1, al)
+        h.set_state(1, al.p0, al.q0, al.v0)
+        h.optimize_batch(0, 1, 1)
+        tau = h.loss_param_batch(capi.LP_MAD, 1, 1)[0] if batched else h.loss_param(1, capi.LP_MAD)
+        h.set_state(1, p, q, al.v0)
+        o = h.update_points_batch(1, 1, True)[0] if batched else h.update_points(1, True)
+        outs.append((tau, o))
+        h.close()
+    (t0, o0), (t1, o1) = outs
+    assert t0 == pytest.approx(t1, rel=1e-12)
+    assert np.array_equal(o0["kept"], o1["kept"]) and np.array_equal(o0["coord"], o1["coord"]) and np.array_equal(o0["tracks"], o1["tracks"])
+    assert o0["mean_sq_flow"] == o1["mean_sq_flow"] and 0 < len(o0["kept"]) < al.N
