@@ -202,3 +202,22 @@ def test_batched_entry_points_with_one_slot_equal_the_single_slot_ones(gpu, capi
     assert t0 == pytest.approx(t1, rel=1e-12)
     assert np.array_equal(o0["kept"], o1["kept"]) and np.array_equal(o0["coord"], o1["coord"]) and np.array_equal(o0["tracks"], o1["tracks"])
     assert o0["mean_sq_flow"] == o1["mean_sq_flow"] and 0 < len(o0["kept"]) < al.N
+
+
+def test_loss_param_on_device_with_all_equal_and_duplicated_residuals(gpu, capi, synth, po):
+    """Radix select corner cases: most residuals equal (zero weights -> residual 0: no pass ever narrows to one candidate, median and
+    MAD both inside the run), and heavy duplication (half the weights zero: the median sits at the edge of a run of equal keys)."""
+    for N, zero_from in ((300, 40), (1001, 400), (2000, 1000)):      # (40 live points: the median AND the MAD lie in the run of zeros)
+        al = synth.make_alignment(990 + N, H=120, W=160, N=N)
+        w = al.weights.copy(); w[zero_from:] = 0.0
+        h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=2), 1, N, 120, 160)
+        h.set_keyframe(0, al.norm_coord, al.grad, al.idp, w, al.fx, al.fy, al.cx, al.cy)
+        h.set_event_frame(0, al.frame)
+        h.set_state(0, al.p0, al.q0, al.v0)
+        h.optimize_batch(0, 0, 1)
+        tau_dev = h.loss_param_batch(capi.LP_MAD, 0, 1)[0]
+        r = h.residuals(0)
+        assert (r == 0).sum() >= N - zero_from
+        tau_exact, _ = po.loss_param(r, po.LP_MAD)
+        assert tau_dev == pytest.approx(tau_exact, rel=1e-12, abs=1e-300)
+        h.close()
