@@ -358,33 +358,48 @@ int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offs
     if (fb.batch_cap < C) {
         void* d[] = {fb.b_img, fb.b_tmp, fb.b_planes, fb.b_norm};
         for (void* q : d) if (q) hipFree(q);
-        if (fb.h_bmeta) hipHostFree(fb.h_bmeta);
-        fb.b_img = fb.b_tmp = fb.b_planes = fb.b_norm = nullptr; fb.h_bmeta = nullptr; fb.batch_cap = 0;
-        char* dmeta = nullptr;
+        fb.b_img = fb.b_tmp = fb.b_planes = fb.b_norm = nullptr; fb.batch_cap = 0;
         if (hipMalloc((void**)&fb.b_img, C * n * 8) != hipSuccess || hipMalloc((void**)&fb.b_tmp, C * n * 8) != hipSuccess ||
-            hipMalloc((void**)&fb.b_planes, C * n * 8) != hipSuccess || hipMalloc((void**)&fb.b_norm, (size_t)C * EDS_SUMSQ_WAYS * 8) != hipSuccess ||
-            hipHostMalloc((void**)&fb.h_bmeta, (size_t)C * 8 + (size_t)(C + 1) * 4, hipHostMallocMapped) != hipSuccess ||
-            hipHostGetDevicePointer((void**)&dmeta, fb.h_bmeta, 0) != hipSuccess)
+            hipMalloc((void**)&fb.b_planes, C * n * 8) != hipSuccess || hipMalloc((void**)&fb.b_norm, (size_t)C * EDS_SUMSQ_WAYS * 8) != hipSuccess)
             return eds_internal_fail(EDS_ERR_HIP, "allocation of the batched event-frame buffers failed");
-        fb.d_bmeta = dmeta;
         fb.batch_cap = C;
     }
-    double* h_tot = reinterpret_cast<double*>(fb.h_bmeta);                       // [cap] totals out
-    int* h_off = reinterpret_cast<int*>(fb.h_bmeta + (size_t)fb.batch_cap * 8);     // [cap + 1] event offsets of the chunk, relative
-    double* d_tot = reinterpret_cast<double*>(fb.d_bmeta);
-    int* d_off = reinterpret_cast<int*>(fb.d_bmeta + (size_t)fb.batch_cap * 8);
+    // A GROUP of chunks is queued without waiting in between: events of chunk k + 1 are copied into the pinned staging while the device
+    // works on chunk k (every chunk has its own part of the staging, of the offsets and of the totals; the image buffers are reused
+    // in stream order).  Groups are bounded by EDS_FRAME_GROUP_EVENTS so that the pinned staging stays small.
+    constexpr long long EDS_FRAME_GROUP_EVENTS = 8ll << 20;
     hipStream_t st = h->st;
     const dim3 b2(256);
-    for (int c0 = 0; c0 < count; c0 += fb.batch_cap) {
-        const int cn = std::min(fb.batch_cap, count - c0);
-        const int e0 = offsets[c0], ne = offsets[c0 + cn] - e0;
-        int maxn = 0;
-        for (int b = 0; b <= cn; ++b) h_off[b] = offsets[c0 + b] - e0;
-        for (int b = 0; b < cn; ++b) { if (h_off[b + 1] < h_off[b]) return eds_internal_fail(EDS_ERR_INVALID, "offsets must not decrease"); maxn = std::max(maxn, h_off[b + 1] - h_off[b]); }
-        if (ne > fb.cap_events) {           // the mapped staging of the single-slice builder, grown
+    int g0 = 0;
+    while (g0 < count) {
+        int g1 = g0;                                                // group = slices [g0, g1): whole chunks, at least one
+        long long gev = 0;
+        while (g1 < count) {
+            const int c1 = std::min(count, g1 + fb.batch_cap);
+            const long long ev = (long long)offsets[c1] - offsets[g1];
+            if (ev < 0) return eds_internal_fail(EDS_ERR_INVALID, "offsets must not decrease");
+            if (g1 > g0 && gev + ev > EDS_FRAME_GROUP_EVENTS) break;
+            gev += ev; g1 = c1;
+        }
+        const int gn = g1 - g0;
+        if (fb.meta_cap < gn) {
+            if (fb.h_bmeta) hipHostFree(fb.h_bmeta);
+            fb.h_bmeta = nullptr; fb.meta_cap = 0;
+            char* dmeta = nullptr;
+            const int cap = std::max(gn, 64);
+            if (hipHostMalloc((void**)&fb.h_bmeta, (size_t)cap * 8 + (size_t)(cap + 1) * 4, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&dmeta, fb.h_bmeta, 0) != hipSuccess)
+                return eds_internal_fail(EDS_ERR_HIP, "allocation of the batched event-frame buffers failed");
+            fb.d_bmeta = dmeta; fb.meta_cap = cap;
+        }
+        double* h_tot = reinterpret_cast<double*>(fb.h_bmeta);                       // [meta_cap] totals out
+        int* h_off = reinterpret_cast<int*>(fb.h_bmeta + (size_t)fb.meta_cap * 8);     // [meta_cap + 1] event offsets relative to the group
+        double* d_tot = reinterpret_cast<double*>(fb.d_bmeta);
+        int* d_off = reinterpret_cast<int*>(fb.d_bmeta + (size_t)fb.meta_cap * 8);
+        if (gev > fb.cap_events) {           // the mapped staging of the single-slice builder, grown
             if (fb.h_events) hipHostFree(fb.h_events);
             fb.h_events = nullptr; fb.d_ex = fb.d_ey = nullptr; fb.d_pol = nullptr;
-            fb.cap_events = (ne + ne / 4 + 1024 + 7) & ~7;
+            fb.cap_events = (int)((gev + gev / 4 + 1024 + 7) & ~7ll);
             uint8_t* dev = nullptr;
             if (hipHostMalloc((void**)&fb.h_events, (size_t)fb.cap_events * 5, hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&dev, fb.h_events, 0) != hipSuccess) { fb.cap_events = 0; return eds_internal_fail(EDS_ERR_HIP, "hipHostMalloc(events)"); }
@@ -392,36 +407,46 @@ int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offs
             fb.d_ey = fb.d_ex + fb.cap_events;
             fb.d_pol = reinterpret_cast<uint8_t*>(fb.d_ey + fb.cap_events);
         }
-        if (ne > 0) {
-            const size_t cap = (size_t)fb.cap_events;
-            std::memcpy(fb.h_events, ex + e0, (size_t)ne * 2);
-            std::memcpy(fb.h_events + cap * 2, ey + e0, (size_t)ne * 2);
-            std::memcpy(fb.h_events + cap * 4, pol + e0, (size_t)ne);
+        const int ge0 = offsets[g0];
+        for (int b = 0; b <= gn; ++b) h_off[b] = offsets[g0 + b] - ge0;
+        for (int b = 0; b < gn; ++b) if (h_off[b + 1] < h_off[b]) return eds_internal_fail(EDS_ERR_INVALID, "offsets must not decrease");
+        const size_t cap = (size_t)fb.cap_events;
+        for (int c0 = 0; c0 < gn; c0 += fb.batch_cap) {             // chunks of the group
+            const int cn = std::min(fb.batch_cap, gn - c0);
+            const int e0 = h_off[c0], ne = h_off[c0 + cn] - e0;
+            int maxn = 0;
+            for (int b = 0; b < cn; ++b) maxn = std::max(maxn, h_off[c0 + b + 1] - h_off[c0 + b]);
+            if (ne > 0) {
+                std::memcpy(fb.h_events + (size_t)e0 * 2, ex + ge0 + e0, (size_t)ne * 2);
+                std::memcpy(fb.h_events + cap * 2 + (size_t)e0 * 2, ey + ge0 + e0, (size_t)ne * 2);
+                std::memcpy(fb.h_events + cap * 4 + (size_t)e0, pol + ge0 + e0, (size_t)ne);
+            }
+            hipError_t e = hipMemsetAsync(fb.b_img, 0, (size_t)cn * n * 8, st);
+            if (e == hipSuccess) e = hipMemsetAsync(fb.b_norm, 0, (size_t)cn * EDS_SUMSQ_WAYS * 8, st);
+            if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+            if (maxn > 0)
+                hipLaunchKernelGGL(k_vote_batch, dim3((maxn + 255) / 256, cn), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, d_off + c0, fb.d_mapx,
+                                   fb.d_mapy, H, W, use_exp_weights, fb.b_img);
+            double* cur = fb.b_img;
+            const bool fused0 = blur_sigma > 0.0 && level == 0;       // the blurred image is the level: blur + plane + sum of squares in one launch
+            if (blur_sigma > 0.0) {
+                const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), sk = 1.0 + 2.0 * t;
+                if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, H, W, t / sk, 1.0 / sk, fb.b_norm);
+                else hipLaunchKernelGGL(k_blur3<false>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk, (double*)nullptr);
+                cur = fb.b_tmp;
+            }
+            if (!fused0) hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
+            hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + g0 + c0, H, W,
+                               h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot + c0, (double*)nullptr);
         }
-        hipError_t e = hipMemsetAsync(fb.b_img, 0, (size_t)cn * n * 8, st);
-        if (e == hipSuccess) e = hipMemsetAsync(fb.b_norm, 0, (size_t)cn * EDS_SUMSQ_WAYS * 8, st);
-        if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-        if (maxn > 0)
-            hipLaunchKernelGGL(k_vote_batch, dim3((maxn + 255) / 256, cn), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, d_off, fb.d_mapx, fb.d_mapy,
-                               H, W, use_exp_weights, fb.b_img);
-        double* cur = fb.b_img;
-        const bool fused0 = blur_sigma > 0.0 && level == 0;       // the blurred image is the level: blur + plane + sum of squares in one launch
-        if (blur_sigma > 0.0) {
-            const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), sk = 1.0 + 2.0 * t;
-            if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, H, W, t / sk, 1.0 / sk, fb.b_norm);
-            else hipLaunchKernelGGL(k_blur3<false>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk, (double*)nullptr);
-            cur = fb.b_tmp;
-        }
-        if (!fused0) hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
-        hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + c0, H, W,
-                           h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot, (double*)nullptr);
-        e = hipGetLastError();
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
-        for (int b = 0; b < cn; ++b) {
-            if (norms_out) norms_out[c0 + b] = std::sqrt(h_tot[b]);
-            h->slots[first_slot + c0 + b].has_frame = true;
+        for (int b = 0; b < gn; ++b) {
+            if (norms_out) norms_out[g0 + b] = std::sqrt(h_tot[b]);
+            h->slots[first_slot + g0 + b].has_frame = true;
         }
+        g0 = g1;
     }
     return EDS_OK;
 }

@@ -100,7 +100,7 @@ struct EdsFrameBuffers {
     // mapped block [totals | event offsets]
     double *b_img = nullptr, *b_tmp = nullptr, *b_planes = nullptr, *b_norm = nullptr;
     char *h_bmeta = nullptr, *d_bmeta = nullptr;
-    int batch_cap = 0;
+    int batch_cap = 0, meta_cap = 0;
     unsigned calls = 0;
     bool img_clean = false;
 };

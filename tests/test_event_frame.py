@@ -232,3 +232,22 @@ def test_build_event_frame_batch_vs_oracle(gpu, capi, level, distort):
     with pytest.raises(capi.EdsError):
         h.build_event_frame_batch(10, slices)                            # 10 + 37 slots do not fit 40
     h.close()
+
+
+@pytest.mark.gpu
+def test_build_event_frame_batch_in_several_groups(gpu, capi):
+    """More events than one staging group holds (8 Mi): the call is cut into groups of whole chunks, each waited for; 36 slices of
+    250 k events, spot-checked against the oracle, all norms against the single-slice builder."""
+    import np_frame_oracle as fo
+    H, W, B, n = 48, 64, 36, 250_000
+    rng = np.random.default_rng(5)
+    slices = [(rng.integers(0, W, n).astype(np.uint16), rng.integers(0, H, n).astype(np.uint16), rng.integers(0, 2, n).astype(np.uint8)) for _ in range(B)]
+    h = capi.Handle(capi.default_config(), B + 1, 64, H, W)
+    norms = h.build_event_frame_batch(0, slices)
+    for b in (0, 17, 31, 32, 35):
+        ref, ref_norm = fo.event_frame(*slices[b], H, W)
+        assert norms[b] == pytest.approx(ref_norm, rel=1e-11), b
+        assert np.abs(h.get_event_frame(b) - ref).max() <= 1e-6 * np.abs(ref).max(), b
+    for b in range(B):
+        assert h.build_event_frame(B, *slices[b]) == pytest.approx(norms[b], rel=1e-11)
+    h.close()
