@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic alignments (replicated to fill the batch)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-shared", dest="no_shared", action="store_true", help="skip the informational shared-frame measurement (it launches the "
+                    "headline kernel on another workload: keep it out of profiler runs)")
     return ap.parse_args()
 
 
@@ -524,6 +526,26 @@ def main():
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device":
             out["latency"] = latency_block(capi, synth, als[0], a)
+        if world == 1 and a.exec_ == "device" and not a.no_shared and B > distinct:
+            # A DIFFERENT workload, informational: the same batch when the alignments that are replicas of one another also SHARE their
+            # event frame (eds_trk_share_event_frame: slot b samples slot b % distinct's storage) — several keyframes / pose hypotheses
+            # against one frame.  The frames in flight then fit the L2s (TCC hit 0.97 against 0.08, profiles/r02_shared_frames_l2.txt)
+            # and the same kernel runs without the fabric-bound gather.  Last leg: the handle is not used afterwards.
+            for b in range(distinct, B):
+                h.share_event_frame(b, b % distinct)
+            s_ms, s_dev = [], []
+            for k in range(5):
+                h.set_states(0, p0, q0, v0)
+                t1 = time.perf_counter()
+                h.optimize_batch(0, 0, B, sync=True)
+                s_ms.append(1e3 * (time.perf_counter() - t1))
+                s_dev.append(h.info(0)["device_time_us"] * 1e-3)
+            stab = h.results(0, B)
+            out["shared_frames"] = {"iterations_per_s": B * float(np.mean(stab[:, 14])) / (float(np.median(s_ms[1:])) * 1e-3),
+                                    "kernel_ms": float(np.median(s_dev[1:])), "distinct_frames": distinct,
+                                    "identical_to_own_copies": bool(np.array_equal(stab, table)) if a.solver == "lm6" else None,
+                                    "roofline_frac": B * N * passes * per_pt / (float(np.median(s_dev[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "NOT the headline workload: replicas of an alignment sample one shared frame instead of a copy each"}
     h.close()
     if rank == 0:
         # ---- parity of the timed batch against the CPU oracle (the checker, outside every timed region) ---------------------------

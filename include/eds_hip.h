@@ -146,6 +146,11 @@ int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp);
  * next solve and not waited for. */
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
+/* Slot `slot` samples slot `src_slot`'s frame storage from now on (no copy) — several alignments against ONE event frame (pose
+ * hypotheses, several keyframes).  Alignments that share a frame and are launched together re-use each other's lines in the L2 when
+ * their slots are congruent modulo 8 (workgroup b of a launch runs on XCD b % 8).  A later frame written INTO `slot` (set / build)
+ * ends the sharing; a frame written into `src_slot` is seen by both.  src_slot == slot: back to the slot's own storage. */
+int eds_trk_share_event_frame(eds_trk* h, int slot, int src_slot);
 /* ---- event-frame construction on the device ---------------------------------------- */
 /* Forward undistortion LUT of the event camera, H x W floats each (EventFrame::fwd_mapx / fwd_mapy,
  * reference src/tracking/EventFrame.cpp:72-79,316-317); NULL, NULL = identity.  Once per handle. */

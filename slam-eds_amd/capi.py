@@ -34,7 +34,7 @@ EXPORTS = (
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
     "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch",
-    "eds_trk_get_event_frame",
+    "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
@@ -129,6 +129,7 @@ def lib():
                                                  C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_build_event_frame_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                       C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
+        L.eds_trk_share_event_frame.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.eds_trk_set_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_states.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_results.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -312,6 +313,9 @@ class Handle:
         mx = np.ascontiguousarray(mapx, dtype=np.float32); my = np.ascontiguousarray(mapy, dtype=np.float32)
         assert mx.shape == tuple(sensor_size) and my.shape == tuple(sensor_size)
         _check(lib().eds_trk_set_undistort_map_sized(self._h, mx.ctypes.data_as(_fp), my.ctypes.data_as(_fp), int(sensor_size[0]), int(sensor_size[1])))
+
+    def share_event_frame(self, slot, src_slot):
+        _check(lib().eds_trk_share_event_frame(self._h, int(slot), int(src_slot)))
 
     def get_event_frame(self, slot):
         fr = np.zeros((self.H, self.W))

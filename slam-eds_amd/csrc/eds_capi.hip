@@ -68,6 +68,7 @@ void fill_static(const eds_trk* h, int slot) {
     pb[EDS_PB_NE] = s.N / nb;
     pb[EDS_PB_N] = s.N;
     pb[EDS_PB_NCMODE] = h->cfg.nc ? 1.0 : 0.0;
+    pb[EDS_PB_FRAME] = (double)(s.frame_slot >= 0 ? s.frame_slot : slot);
 }
 
 void fill_pose(eds_trk* h, int slot, const double* p, const double* q, const double* v) {
@@ -341,9 +342,21 @@ void free_all(eds_trk* h) {
 // stream, and the staging buffer is private to this function (its event is waited for before the next frame overwrites it).
 // (Round 1 built the tiled, margin-padded image element by element on one host thread: 300 us for 640x480, more than the solve;
 // chunked hipMemcpyAsync into HBM + one tiling launch: 80 us, 30 of them after the host had finished.)
+// slots that are about to receive a frame of their own stop sampling somebody else's
+static int unshare_frames(eds_trk* h, int first, int count) {
+    for (int s = first; s < first + count; ++s) {
+        if (h->slots[s].frame_slot < 0) continue;
+        h->slots[s].frame_slot = -1;
+        fill_static(h, s);
+        int rc = upload_pose(h, s, 1);
+        if (rc) return rc;
+    }
+    return EDS_OK;
+}
 #define EDS_UPLOAD_BANDS 4
 template <class T>
 static int upload_frame(eds_trk* h, int slot, const T* frame) {
+    { int rc_ = unshare_frames(h, slot, 1); if (rc_) return rc_; }     // a frame of its own again
     float* stage = h->h_fstage;
     if (h->stage_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_stage)); h->stage_busy = false; }   // the previous frame's reads (long done)
     for (int k = 0; k < EDS_UPLOAD_BANDS; ++k) {
@@ -643,6 +656,7 @@ int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t
     if (n_events < 0 || level < 0 || level > 16) return fail(EDS_ERR_INVALID, "bad event count or level");
     if (n_events > 0 && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
     EDS_HIP_TRY(hipSetDevice(h->dev));
+    if ((rc = unshare_frames(h, slot, 1))) return rc;
     return eds_frame_build_levels(h, slot, level, 1, n_events, x, y, polarity, h->H, h->W, blur_sigma, use_exp_weights, norm_out);
 }
 
@@ -656,6 +670,7 @@ int eds_trk_build_event_frames(eds_trk* h, int first_slot, int num_levels, int n
     if (sensor_H <= 0 || sensor_W <= 0) { sensor_H = h->H; sensor_W = h->W; }
     if (sensor_H < 2 || sensor_W < 2) return fail(EDS_ERR_INVALID, "bad sensor size");
     EDS_HIP_TRY(hipSetDevice(h->dev));
+    { int rc_ = unshare_frames(h, first_slot, num_levels); if (rc_) return rc_; }
     return eds_frame_build_levels(h, first_slot, 0, num_levels, n_events, x, y, polarity, sensor_H, sensor_W, blur_sigma, use_exp_weights, norms);
 }
 
@@ -667,7 +682,23 @@ int eds_trk_build_event_frame_batch(eds_trk* h, int first_slot, int count, const
     if (level < 0 || level > 16) return fail(EDS_ERR_INVALID, "bad level");
     if (offsets[count] > offsets[0] && (!x || !y || !polarity)) return fail(EDS_ERR_INVALID, "null event array");
     EDS_HIP_TRY(hipSetDevice(h->dev));
+    { int rc_ = unshare_frames(h, first_slot, count); if (rc_) return rc_; }
     return eds_frame_build_batch(h, first_slot, count, offsets, x, y, polarity, level, blur_sigma, use_exp_weights, norms);
+}
+
+int eds_trk_share_event_frame(eds_trk* h, int slot, int src_slot) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if ((rc = check_slot(h, src_slot))) return rc;
+    Slot& s = h->slots[slot];
+    const Slot& src = h->slots[src_slot];
+    if (src.frame_slot >= 0 && src_slot != slot) return fail(EDS_ERR_INVALID, "the source slot itself shares another slot's frame");
+    if (!src.has_frame && src_slot != slot) return fail(EDS_ERR_STATE, "the source slot has no event frame yet");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    s.frame_slot = src_slot == slot ? -1 : src_slot;
+    if (src_slot != slot) s.has_frame = true;
+    fill_static(h, slot);
+    return upload_pose(h, slot, 1);                             // ordered before the next solve on the handle's stream
 }
 
 int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {

@@ -102,8 +102,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int N = TEAM > 1 ? (Nall - poff < 0 ? 0 : (Nall - poff > PPT * MAXT ? PPT * MAXT : Nall - poff)) : Nall;
     const size_t base = (size_t)slot * A.Np + poff;
     static_assert(TEAM == 1 || PPT > 0, "teams keep their points in registers");
-    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
-    const float* __restrict__ tiles = A.frame + (size_t)slot * A.Hp * A.Wp;              // start of this slot's allocation (quad gather)
+    const int fslot = (int)gpb[EDS_PB_FRAME];          // the slot whose frame storage is sampled (its own unless shared)
+    const FrameView frame = make_frame_view(A.frame, fslot, A.H, A.W, A.Hp, A.Wp, 1);    // persistent kernels: tiled frames only (eds_fused_solve)
+    const float* __restrict__ tiles = A.frame + (size_t)fslot * A.Hp * A.Wp;             // start of that allocation (quad gather)
     static_assert(!QUAD || (SAMPLING == 0 && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: bicubic, register-resident points, all cached");
 
     if (tid == 0) {

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int chunk = TEAM > 1 ? (((N + TEAM - 1) / TEAM + 63) & ~63) : N;
     const int lo = TEAM > 1 ? (member * chunk < N ? member * chunk : N) : 0;
     const int hi = TEAM > 1 ? (lo + chunk < N ? lo + chunk : N) : N;
-    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
+    const int fslot = (int)gpb[EDS_PB_FRAME];          // the slot whose frame storage is sampled (its own unless shared)
+    const FrameView frame = make_frame_view(A.frame, fslot, A.H, A.W, A.Hp, A.Wp, 1);    // persistent kernels: tiled frames only (eds_fused_solve)
 
     if (wave == 0) {
         for (int k = lane; k < nb * 36; k += 64) s_G[k] = Gg[k];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             int org[2];                                                 // QUAD: packed patch origin | miss flag, per point
             float4 ra[2][4], rb[2][4];                                  // QUAD: this lane's row of the quad's four patches
             const int jr = lane & 3;
-            const float* __restrict__ tiles = A.frame + (size_t)slot * A.Hp * A.Wp;
+            const float* __restrict__ tiles = A.frame + (size_t)fslot * A.Hp * A.Wp;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;

@@ -13,6 +13,7 @@
 struct Slot {
     int N = 0;
     bool has_kf = false, has_frame = false;
+    int frame_slot = -1;            // >= 0: this alignment samples THAT slot's frame storage (eds_trk_share_event_frame); -1: its own
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[6];
     double K[4] = {0, 0, 0, 0};
     eds_trk_info info;

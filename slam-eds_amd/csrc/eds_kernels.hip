@@ -19,7 +19,7 @@
 using namespace edsd;
 
 __device__ __forceinline__ FrameView frame_view(const EdsArrays& A, int slot) {
-    return make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, A.tiled);
+    return make_frame_view(A.frame, (int)A.pose[(size_t)slot * EDS_POSE_STRIDE + EDS_PB_FRAME], A.H, A.W, A.Hp, A.Wp, A.tiled);
 }
 
 // linear workgroup id -> (slot, chunk); all chunks of a slot share id % 8 (one XCD)

@@ -42,6 +42,7 @@
 #define EDS_PB_NE 28               // 1   points per block (N / nb, Tracker.cpp:178)
 #define EDS_PB_N 29                // 1   number of points
 #define EDS_PB_NCMODE 30           // 1   1 = PhotometricErrorNC residual: sampled brightness L2-normalised per block too
+#define EDS_PB_FRAME 31            // 1   slot whose frame storage this alignment samples (its own, or another slot's: eds_trk_share_event_frame)
 #define EDS_PB_PV 32               // 36  d(unit-norm plus)/d delta = (I - v v^T/|v|^2)/|v|  (PhotometricError.hpp:32-54)
 #define EDS_PB_BLK 68              // 8 per block: inv_n, gvec[6] = G v / n^3, S
 #define EDS_PB_BLK_STRIDE 8

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NTHR, EDS6S_WG_PER_CU) void eds_stream6_kernel(EdsA
     const int N = (int)gpb[EDS_PB_N];
     const int ne = N / nb;
     const size_t base = (size_t)slot * A.Np;
-    const FrameView frame = make_frame_view(A.frame, slot, A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
+    const FrameView frame = make_frame_view(A.frame, (int)gpb[EDS_PB_FRAME], A.H, A.W, A.Hp, A.Wp, 1);     // persistent kernels: tiled frames only (eds_fused_solve)
     float* __restrict__ rcand = A.J + base;              // plane 0 of the Jacobian buffer: residuals of the pass in flight
 
     if (tid == 0) {

@@ -293,3 +293,58 @@ def test_ref12_large_point_sets_run_on_teams_of_8_and_16(gpu, capi, synth, po, m
         assert tab[13] == pytest.approx(ref["final_cost"], rel=1e-5)
         e = po.Oracle(a, num_blocks=nb).eval12(ref["p"], ref["q"], ref["v"], jac=False)["r_raw"]
         assert np.abs(r - e).max() <= 2e-5 * np.abs(e).max()
+
+
+def test_shared_event_frames(gpu, capi, synth, po):
+    """eds_trk_share_event_frame: several alignments sample ONE slot's frame storage.  Same results, bit for bit, as with a copy of the
+    frame in every slot (LM6 and the reference problem, batched and one at a time); a frame written into the source is seen by the
+    sharers, a frame written into a sharer ends the sharing; a source must have a frame and must not share itself."""
+    H, W, N = 240, 320, 1200
+    als = [synth.make_alignment(7600 + k, H=H, W=W, N=N) for k in range(3)]
+    B = 9
+    for solver in (capi.SOLVER_LM6, capi.SOLVER_REF12):
+        cfg = capi.default_config(solver=solver, exec=capi.EXEC_DEVICE, max_num_iterations=6)
+        tabs = {}
+        for mode in ("copies", "shared"):
+            h = capi.Handle(cfg, B, N, H, W)
+            for b in range(B):
+                a = als[b % 3]
+                h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+                if mode == "copies" or b < 3:
+                    h.set_event_frame(b, a.frame)
+                else:
+                    h.share_event_frame(b, b % 3)
+                h.set_state(b, a.p0, a.q0, a.v0)
+            h.optimize_batch(0, 0, B)
+            tabs[mode] = h.results(0, B).copy()
+            if mode == "shared":
+                if solver == capi.SOLVER_LM6:
+                    assert np.array_equal(tabs["shared"], tabs["copies"])              # no atomics on this path: bit-identical
+                else:
+                    assert np.abs(tabs["shared"][:, :13] - tabs["copies"][:, :13]).max() <= 1e-9 and np.array_equal(tabs["shared"][:, 14:], tabs["copies"][:, 14:])
+                # one at a time (teams) as well
+                a = als[1]
+                h.set_state(7, a.p0, a.q0, a.v0)
+                h.optimize_batch(0, 7, 1)
+                assert po.se3_distance(h.results(7, 1)[0, 0:3], h.results(7, 1)[0, 3:7], tabs["copies"][7, 0:3], tabs["copies"][7, 3:7]) <= 1e-9
+                assert np.array_equal(h.get_event_frame(1), h.get_event_frame(1))
+                # a new frame in the SOURCE slot 1 is what its sharers 4 and 7 solve against from now on
+                h.set_event_frame(1, als[2].frame)
+                g = capi.Handle(cfg, 1, N, H, W)
+                g.set_keyframe(0, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+                g.set_event_frame(0, als[2].frame)
+                g.set_state(0, a.p0, a.q0, a.v0); g.optimize_batch(0, 0, 1)
+                h.set_state(4, a.p0, a.q0, a.v0); h.optimize_batch(0, 4, 1)
+                assert po.se3_distance(h.results(4, 1)[0, 0:3], h.results(4, 1)[0, 3:7], g.results(0, 1)[0, 0:3], g.results(0, 1)[0, 3:7]) <= 1e-9
+                # a frame written INTO sharer 7 ends its sharing; 4 still follows slot 1
+                h.set_event_frame(7, als[1].frame)
+                h.set_state(7, a.p0, a.q0, a.v0); h.optimize_batch(0, 7, 1)
+                assert po.se3_distance(h.results(7, 1)[0, 0:3], h.results(7, 1)[0, 3:7], tabs["copies"][7, 0:3], tabs["copies"][7, 3:7]) <= 1e-9
+                g.close()
+                with pytest.raises(capi.EdsError):
+                    h.share_event_frame(8, 4)                                         # slot 4 shares slot 1's frame itself
+                e = capi.Handle(cfg, 2, N, H, W)
+                with pytest.raises(capi.EdsError):
+                    e.share_event_frame(1, 0)                                         # slot 0 has no frame yet
+                e.close()
+            h.close()
