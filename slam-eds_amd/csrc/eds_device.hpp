@@ -123,13 +123,16 @@ __device__ __forceinline__ void quad_transpose(float (&m)[4], int lane) {
     }
 }
 // Origin of a patch packed for the in-quad broadcast: clamped like load_patch16 (rows -2..H, columns -2..W), biased by 2.
+// (bits 0-15: column + 2; 16-28: row + 2; 29-30: (column - 1) & 3, the barrel-shift amount of the patch's rows, where every lane that
+// loads a row of this patch can turn each bit into a select mask with ONE v_bfe_i32; bit 31 is the caller's "gather it" flag)
 __device__ __forceinline__ int pack_origin(const FrameView& f, int r0, int c0) {
-    return ((clampi(r0, -2, f.H) + 2) << 16) | (clampi(c0, -2, f.W) + 2);
+    const int c = clampi(c0, -2, f.W);
+    return (((c - 1) & 3) << 29) | ((clampi(r0, -2, f.H) + 2) << 16) | (c + 2);
 }
 // Row `jr` (0..3) of the patch at a packed origin: the two aligned 16-byte tile pieces that hold columns c0-1 .. c0+2.
 // `tiles` is the START of the frame's allocation (tile (0,0) of the margin), offsets are unsigned 32-bit element counts.
 __device__ __forceinline__ void load_patch_row(const float* __restrict__ tiles, int TW, int origin, int jr, float4& a, float4& b) {
-    const unsigned r = (unsigned)((origin >> 16) & 0x7fff) + (unsigned)(jr + EDS_FRAME_MARGIN - 3);   // allocation row, >= 1
+    const unsigned r = (unsigned)((origin >> 16) & 0x1fff) + (unsigned)(jr + EDS_FRAME_MARGIN - 3);   // allocation row, >= 1
     const unsigned cc = (unsigned)(origin & 0xffff) + (unsigned)(EDS_FRAME_MARGIN - 2);              // allocation column of c0
     // byte offsets from the start of the allocation, 32-bit: uniform base + per-lane offset (global_load ... saddr form)
     const unsigned row_b = (r >> 2) * ((unsigned)TW * 64u) + ((r & 3u) << 4);
@@ -147,11 +150,14 @@ __device__ __forceinline__ float4 dont_care4() {
 // (bit-mask selects, one v_bfi_b32 each: written as ?: on the vector components the compiler turns the shift into a
 // dynamically indexed private array, i.e. scratch memory traffic inside the point loop)
 __device__ __forceinline__ float bit_select(int mask, float yes, float no) {
-    return __int_as_float((mask & __float_as_int(yes)) | (~mask & __float_as_int(no)));
+    // v_bfi_b32 D = (S0 & S1) | (~S0 & S2), spelled out: from the C expression the compiler derives ~mask arithmetically (mask = -(bit)
+    // gives ~mask = bit - 1) and then no longer recognises the pattern — three instructions (and, and, or) per select instead of one
+    float r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(yes), "v"(no));
+    return r;
 }
 __device__ __forceinline__ void shift_patch_row(const float4& a, const float4& b, int origin, float (&t)[4]) {
-    const int s = (origin & 0xffff) - 3;                       // (c0 - 1); only its two low bits matter
-    const int m2 = -((s >> 1) & 1), m1 = -(s & 1);
+    const int m2 = __builtin_amdgcn_sbfe(origin, 30, 1), m1 = __builtin_amdgcn_sbfe(origin, 29, 1);    // all ones / zero: bit 1 / bit 0 of (c0 - 1) & 3
     const float t0 = bit_select(m2, a.z, a.x), t1 = bit_select(m2, a.w, a.y), t2 = bit_select(m2, b.x, a.z), t3 = bit_select(m2, b.y, a.w),
                 t4 = bit_select(m2, b.z, b.x);
     t[0] = bit_select(m1, t1, t0); t[1] = bit_select(m1, t2, t1); t[2] = bit_select(m1, t3, t2); t[3] = bit_select(m1, t4, t3);

@@ -674,7 +674,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-        const bool q = bic && count * team >= 128;   // enough gathers in flight for the quad-cooperative form to pay
+        const bool q = bic && count * team >= 128 && h->H < 8000;   // enough gathers in flight for the quad-cooperative form to pay
         if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
             if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_TEAM(1, 1, 0, 4);
         } else if (team == 2) {                      // 1 024 points per member, two per lane
@@ -697,7 +697,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // gather, not the instruction stream, bounds the pass: 152 vs 184 us at 64 alignments, 114 vs 102 us for a lone one
     bool quad = count >= 32;
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
-    quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP;       // every point's patch has a cache line of its own
+    quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP && h->H < 8000;     // every point's patch has a cache line of its own; 13-bit row field (pack_origin)
     switch (ppt) {
         case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_FUSED_T(1, 1, 0); break;
         case 2: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_FUSED_T(1, 2, 0); break;

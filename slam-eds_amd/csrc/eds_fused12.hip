@@ -557,6 +557,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
     bool quad = bicubic && count >= 1024;          // measured: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
+    quad = quad && h->H < 8000;                   // 13-bit row field of the packed origins (pack_origin)
     if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }
     else if (team == 8) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 8, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 8, 0); }
     else if (team == 4) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
