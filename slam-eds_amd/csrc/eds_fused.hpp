@@ -34,8 +34,8 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 #define EDS_TEAM_GRANULES 64                      // LM6, per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
 #define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
 #define EDS_TEAM6_MAX 16                          // LM6: up to 16 CUs per alignment (16 384 points)
-#define EDS_TEAM_SLOTS 128                        // an LM6 team launch holds at most this many alignments ...
-#define EDS_TEAM_MEMBERS 512                      // ... and at most this many workgroups (alignments x team size)
+#define EDS_TEAM_SLOTS 128                        // up to 2 048 points: teams of two up to this many alignments per launch
+#define EDS_TEAM_MEMBERS 4096                     // workgroups (alignments x team size) one team LAUNCH holds: the mailboxes' capacity; larger ranges go out in several launches
 #define EDS_TEAM_MAIL_BYTES ((size_t)EDS_TEAM_MEMBERS * 2 * EDS_TEAM_GRANULES * 8)
 #define EDS_TEAM12_VALUES 157                     // REF12, per residual block: ||r||^2, J^T J (144), J^T r (12)
 #define EDS_TEAM12_GRANULES 2560                  // per member and parity: 2 x 157 x 8 blocks = 2 512, padded

@@ -348,3 +348,32 @@ def test_shared_event_frames(gpu, capi, synth, po):
                     e.share_event_frame(1, 0)                                         # slot 0 has no frame yet
                 e.close()
             h.close()
+
+
+def test_large_point_sets_in_large_batches_go_out_in_several_team_launches(gpu, capi, synth, po, monkeypatch):
+    """More than 2 048 points at ANY batch size run on teams; a range that needs more workgroups than the mailboxes hold (4 096) is cut
+    into several launches.  1 100 alignments of 2 100 points (4 CUs each: 4 400 workgroups, two launches): every result equals the
+    one-CU streaming kernel's, a few are checked against the oracle."""
+    H, W, N, B = 120, 160, 2100, 1100
+    als = [synth.make_alignment(7700 + k, H=H, W=W, N=N) for k in range(5)]
+    res = {}
+    for k in (0, 1):
+        if k: monkeypatch.setenv("EDS_LM6_TEAM", "1")
+        else: monkeypatch.delenv("EDS_LM6_TEAM", raising=False)
+        h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=5), B, N, H, W)
+        for b in range(B):
+            a = als[b % 5]
+            h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+            if b < 5: h.set_event_frame(b, a.frame)
+            else: h.share_event_frame(b, b % 5)
+        h.set_states(0, np.stack([als[b % 5].p0 for b in range(B)]), np.stack([als[b % 5].q0 for b in range(B)]), np.stack([als[b % 5].v0 for b in range(B)]))
+        h.optimize_batch(0, 0, B)
+        res[k] = h.results(0, B).copy()
+        h.close()
+    assert (res[0][:, 15] == 1.0).all() and (res[0][:, 14] == 5).all()
+    for b in range(B):
+        assert po.se3_distance(res[0][b, 0:3], res[0][b, 3:7], res[1][b, 0:3], res[1][b, 3:7]) <= 1e-6, b
+    for b in (0, 1023, 1024, 1099):                      # either side of the launch boundary
+        a = als[b % 5]
+        ref = po.Oracle(a).pose6_lm(a.p0, a.q0, a.v0, iters=5, lambda0=0.01)
+        assert po.se3_distance(res[0][b, 0:3], res[0][b, 3:7], ref["p"], ref["q"]) <= TOL_POSE
