@@ -40,7 +40,7 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 #define EDS_TEAM12_VALUES 157                     // REF12, per residual block: ||r||^2, J^T J (144), J^T r (12)
 #define EDS_TEAM12_GRANULES 2560                  // per member and parity: 2 x 157 x 8 blocks = 2 512, padded
 #define EDS_TEAM12_SLOTS 64                       // a REF12 team launch holds at most this many alignments ...
-#define EDS_TEAM12_MEMBERS 256                    // ... and at most this many workgroups (alignments x team size, up to 16 CUs each)
+#define EDS_TEAM12_MEMBERS 512                    // ... and at most this many workgroups (alignments x team size, up to 16 CUs each)
 #define EDS_TEAM12_MAIL_BYTES ((size_t)EDS_TEAM12_MEMBERS * 2 * EDS_TEAM12_GRANULES * 8)
 
 struct EdsFusedBuffers {
