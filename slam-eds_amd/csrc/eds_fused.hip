@@ -256,7 +256,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     float t[4];
                     shift_patch_row(ra[j][q], rb[j][q], oq[q], t);
                     const int m = oq[q] >> 31;                   // all ones: gathered this pass
-                    t[0] = bit_select(m, t[0], c[q].x); t[1] = bit_select(m, t[1], c[q].y); t[2] = bit_select(m, t[2], c[q].z); t[3] = bit_select(m, t[3], c[q].w);
+                    t[0] = flag_select(m != 0, t[0], c[q].x); t[1] = flag_select(m != 0, t[1], c[q].y); t[2] = flag_select(m != 0, t[2], c[q].z); t[3] = flag_select(m != 0, t[3], c[q].w);
                     *reinterpret_cast<float4*>(cache + cq[q] + 16 * j * nthr) = make_float4(t[0], t[1], t[2], t[3]);
                     hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
                 }

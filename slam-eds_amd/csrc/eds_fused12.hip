@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                             float t[4];
                             shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
                             const int m = oq[q] >> 31;               // all ones: gathered this pass
-                            t[0] = bit_select(m, t[0], c.x); t[1] = bit_select(m, t[1], c.y); t[2] = bit_select(m, t[2], c.z); t[3] = bit_select(m, t[3], c.w);
+                            t[0] = flag_select(m != 0, t[0], c.x); t[1] = flag_select(m != 0, t[1], c.y); t[2] = flag_select(m != 0, t[2], c.z); t[3] = flag_select(m != 0, t[3], c.w);
                             if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
                             hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
                         }
