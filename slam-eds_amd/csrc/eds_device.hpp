@@ -315,6 +315,39 @@ __device__ __forceinline__ void project_sample(const FrameView& frame, const Pos
     finish_point(ps, g, E, Er, Ec, o);
 }
 
+// The same for four consecutive points held by the four lanes of a quad, bicubic sampler, tiled frame: the quad-cooperative gather
+// of the persistent kernels without a patch cache — lane j loads ROW j of each of the quad's four patches, runs that row's spline,
+// and a 4x4 DPP transpose returns the four row results of a point to its own lane.  EVERY lane of the quad must call it (a lane
+// without a point passes valid = false: its patch travels as origin 0 and its result is not used).  Same arithmetic, same order of
+// operations as project_sample<0>.
+__device__ __forceinline__ void project_sample_quad(const FrameView& frame, const float* __restrict__ tiles, const PoseF& ps, const PointKf& k,
+                                                    bool valid, int lane, PointProj& o) {
+    PointGeom g;
+    project_point(ps, k, g);
+    const int org = valid ? pack_origin(frame, g.r0, g.c0) : 0;
+    const int o0 = quad_bcast_i<0>(org), o1 = quad_bcast_i<1>(org), o2 = quad_bcast_i<2>(org), o3 = quad_bcast_i<3>(org);
+    const int oq[4] = {o0, o1, o2, o3};
+    const float x0 = quad_bcast_f<0>(g.ax), x1 = quad_bcast_f<1>(g.ax), x2 = quad_bcast_f<2>(g.ax), x3 = quad_bcast_f<3>(g.ax);
+    const float xq[4] = {x0, x1, x2, x3};
+    const int jr = lane & 3;
+    float4 ra[4], rb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_patch_row(tiles, frame.TW, oq[q], jr, ra[q], rb[q]);
+    float f[4], d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float t[4];
+        shift_patch_row(ra[q], rb[q], oq[q], t);
+        hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
+    }
+    quad_transpose(f, lane);
+    quad_transpose(d, lane);
+    float E, Er, Ec, unused;
+    hermite(f[0], f[1], f[2], f[3], g.ay, E, Er);
+    hermite(d[0], d[1], d[2], d[3], g.ay, Ec, unused);
+    finish_point(ps, g, E, Er, Ec, o);
+}
+
 // SE(3) left-perturbation row: J = -w [gradE_P, P x gradE_P]  (= DSO's row, CoarseTracker.cpp:311-321)
 __device__ __forceinline__ void jacobian6(const PointProj& pp, float w, float (&J)[6]) {
     J[0] = -w * pp.g0;

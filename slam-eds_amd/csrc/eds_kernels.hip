@@ -101,16 +101,25 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
     const double* __restrict__ pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const int N = (int)pb[EDS_PB_N];
     const int i = chunk * EDS_TPB + threadIdx.x;
-    if (i >= N) return;
+    // bicubic on the tiled frame: the quad-cooperative gather (eds_device.hpp) — four consecutive points per quad, every lane of a
+    // quad takes part in the loads whether or not it has a point, so lanes beyond N stay until the sample is formed
+    const bool quad = SAMPLING == 0 && A.tiled && A.H < 8000;
+    if (i >= N && !(quad && (i & ~3) < N)) return;      // whole quads beyond N (and every lane beyond N without the quad gather) leave
     PoseF ps;
     load_pose(pb, ps);
-    const size_t o = (size_t)slot * A.Np + i;
+    const size_t o = (size_t)slot * A.Np + i;           // (i < Np: the planes are padded, a lane beyond N reads padding)
     const FrameView frame = frame_view(A, slot);
     PointKf kf;
     kf.x = A.x[o]; kf.y = A.y[o]; kf.rhop = A.rho[o] + 1e-5f;   // rho' = idp + eps (PhotometricError.hpp:100,200)
     kf.f0x = A.f0x[o]; kf.f0y = A.f0y[o]; kf.cell0 = A.cell0[o];
     PointProj pp;
-    project_sample<SAMPLING>(frame, ps, kf, pp);
+    if (quad) {
+        const int fslot = (int)pb[EDS_PB_FRAME];
+        project_sample_quad(frame, A.frame + (size_t)fslot * A.Hp * A.Wp, ps, kf, i < N, threadIdx.x & 63, pp);
+        if (i >= N) return;
+    } else {
+        project_sample<SAMPLING>(frame, ps, kf, pp);
+    }
     const float w = A.w[o];
     const size_t plane = (size_t)A.B * A.Np;
     float* __restrict__ Jo = A.J + o;
