@@ -21,7 +21,7 @@ notes = [
     ("k_store_levels", 3.72, "per level: fp64 plane in, tiled fp32 frame out"),
     ("k_update_points", 0.22, "2 000 points: 9 planes in/out in HBM; coordinates, tracks, kept indices (36 B/point) to pinned host memory"),
     ("k_loss_param", 0.51, "64 alignments x 2 000 residuals: radix select of the median, then of the MAD (residual plane re-read per pass, L2)"),
-    ("k_select", 3.69, "fp64 magnitude in, candidates out"),
+    ("k_select", 3.69, "fp64 magnitude in, candidates out: one bitonic sort per 20 x 20 cell in LDS"),
     ("k_minmax", 0.31, "image in"),
     ("k_nearest_part", 0.06, "886 candidates x 3 000 depth points, 16 chunks staged through LDS"),
     ("k_nearest_merge", 0.25, "16 partial winners per candidate in, inverse depth + distance out"),
