@@ -139,7 +139,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         for (int j = 0; j < reps; ++j) {
             const int i = tid + j * nthr;
             const bool in_range = i < N;
-            const size_t o = base + (in_range ? i : 0);
+            // (a lane without a point reads the SLOT's first point: `base` itself lies beyond the slot's planes for a team member whose
+            // slice starts past the padded point count — 8 722 points on 16 members: slices from 9 216 on, planes end at 8 960)
+            const size_t o = in_range ? base + i : (size_t)slot * A.Np;
             const float x = A.x[o], y = A.y[o], rho = A.rho[o];
             float a[6];
             model_row(x, y, rho, A.gx[o], A.gy[o], a);
