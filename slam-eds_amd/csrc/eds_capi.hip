@@ -708,7 +708,8 @@ int eds_trk_get_event_frame(eds_trk* h, int slot, double* frame) {
     EDS_HIP_TRY(hipSetDevice(h->dev));
     const size_t n = (size_t)h->Hp * h->Wp;
     EDS_HIP_TRY(hipStreamSynchronize(h->st));                    // set_event_frame does not wait for its own upload
-    EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dframe + (size_t)slot * n, n * 4, hipMemcpyDeviceToHost));
+    const int fs = h->slots[slot].frame_slot >= 0 ? h->slots[slot].frame_slot : slot;      // a sharing slot: the frame it samples
+    EDS_HIP_TRY(hipMemcpy(h->h_f32, h->dframe + (size_t)fs * n, n * 4, hipMemcpyDeviceToHost));
     for (int r = 0; r < h->H; ++r)
         for (int c = 0; c < h->W; ++c) frame[(size_t)r * h->W + c] = h->h_f32[eds_frame_index(r, c, h->Wp, h->tiled)];
     return EDS_OK;

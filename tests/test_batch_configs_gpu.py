@@ -327,7 +327,7 @@ def test_shared_event_frames(gpu, capi, synth, po):
                 h.set_state(7, a.p0, a.q0, a.v0)
                 h.optimize_batch(0, 7, 1)
                 assert po.se3_distance(h.results(7, 1)[0, 0:3], h.results(7, 1)[0, 3:7], tabs["copies"][7, 0:3], tabs["copies"][7, 3:7]) <= 1e-9
-                assert np.array_equal(h.get_event_frame(1), h.get_event_frame(1))
+                assert np.array_equal(h.get_event_frame(7), h.get_event_frame(1))     # a sharer reports the frame it samples
                 # a new frame in the SOURCE slot 1 is what its sharers 4 and 7 solve against from now on
                 h.set_event_frame(1, als[2].frame)
                 g = capi.Handle(cfg, 1, N, H, W)
