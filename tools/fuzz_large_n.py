@@ -1,4 +1,5 @@
-"""Random (N > 2 048, batch, sampler, Huber) cases: the team path optimize picks against the one-CU streaming kernel (EDS_LM6_TEAM=1)
+"""Random (N, batch, sampler, Huber) cases — by default N > 2 048; `fuzz_large_n.py seed trials nmin nmax` for another range, e.g. 513 2048
+for the small teams on handles that are exactly as large as their alignments: the team path optimize picks against the one-CU streaming kernel (EDS_LM6_TEAM=1)
 on the same handle — poses within 1e-6, accept patterns identical — and REF12 teams of 8 / 16 against EDS_REF12_TEAM=1."""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -7,9 +8,11 @@ capi = importlib.import_module("slam-eds_amd.capi"); synth = importlib.import_mo
 import pyoracle as po
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 2049
+nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 12000
 bad = 0
 for t in range(trials):
-    N = int(rng.integers(2049, 12000)); B = int(rng.integers(1, 24)); sampling = int(rng.integers(0, 2)); tau = float(rng.choice([0.0, 0.01]))
+    N = int(rng.integers(nmin, nmax)); B = int(rng.integers(1, 24)); sampling = int(rng.integers(0, 2)); tau = float(rng.choice([0.0, 0.01]))
     ref12 = bool(rng.integers(0, 3) == 0)
     H, W = 240, 320
     als = [synth.make_alignment(8800 + 10 * t + k, H=H, W=W, N=N, start="ctor" if ref12 else "truth_velocity") for k in range(2)]
