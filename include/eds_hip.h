@@ -164,6 +164,13 @@ int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy);
  * the frame was divided by (EventFrame::norm[level]). */
 int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t* x, const uint16_t* y,
                               const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norm_out);
+/* The same from the reference's own container, an array of structs (EventFrame::create takes `const std::vector<base::samples::Event>&`,
+ * EventFrame.hpp:78-85, and reads it->x, it->y, it->polarity, EventFrame.cpp:314-318): `events` points at n_events records of `stride`
+ * bytes; x and y are uint16 fields at byte offsets off_x, off_y (2-byte aligned), the polarity is the byte at off_polarity (non-zero =
+ * positive).  The records are copied as they are and picked apart on the device: no repacking loop on the caller's side. */
+int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, int n_events, const void* events, int stride, int off_x,
+                                   int off_y, int off_polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights,
+                                   double* norms);
 /* The batched tracker's counterpart (BASELINE.json configs[4]: one event frame per alignment): `count` independent event slices into
  * slots first_slot .. first_slot + count - 1 in one pass over the device per 32 slices — slice b's events are elements
  * offsets[b] .. offsets[b + 1] - 1 of x / y / polarity (offsets: count + 1 non-decreasing ints), each slice in time order, all at the

@@ -33,7 +33,7 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
-    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch",
+    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos",
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
@@ -127,6 +127,8 @@ def lib():
         L.eds_trk_set_undistort_map_sized.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_int]
         L.eds_trk_build_event_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                  C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, _dp]
+        L.eds_trk_build_event_frames_aos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_build_event_frame_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                       C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_share_event_frame.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -293,6 +295,18 @@ class Handle:
                                                 x.ctypes.data_as(C.POINTER(C.c_uint16)), y.ctypes.data_as(C.POINTER(C.c_uint16)),
                                                 pol.ctypes.data_as(C.POINTER(C.c_uint8)), int(sH), int(sW), float(blur_sigma),
                                                 int(bool(use_exp_weights)), _p(norms)))
+        return norms
+
+    def build_event_frames_aos(self, first_slot, num_levels, events, sensor_size=None, blur_sigma=0.5, use_exp_weights=True):
+        """`events`: a numpy structured array with fields x, y (uint16) and polarity (1 byte) — e.g. the memory of a
+        std::vector<base::samples::Event>."""
+        ev = np.ascontiguousarray(events)
+        f = ev.dtype.fields
+        sH, sW = sensor_size if sensor_size is not None else (0, 0)
+        norms = np.zeros(num_levels)
+        _check(lib().eds_trk_build_event_frames_aos(self._h, int(first_slot), int(num_levels), int(ev.shape[0]), ev.ctypes.data_as(C.c_void_p),
+                                                    int(ev.dtype.itemsize), int(f["x"][1]), int(f["y"][1]), int(f["polarity"][1]), int(sH), int(sW),
+                                                    float(blur_sigma), int(bool(use_exp_weights)), _p(norms)))
         return norms
 
     def build_event_frame_batch(self, first_slot, slices, level=0, blur_sigma=0.5, use_exp_weights=True):

@@ -674,6 +674,24 @@ int eds_trk_build_event_frames(eds_trk* h, int first_slot, int num_levels, int n
     return eds_frame_build_levels(h, first_slot, 0, num_levels, n_events, x, y, polarity, sensor_H, sensor_W, blur_sigma, use_exp_weights, norms);
 }
 
+int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, int n_events, const void* events, int stride, int off_x,
+                                   int off_y, int off_polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights, double* norms) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (num_levels < 1 || num_levels > EDS_MAX_LEVELS) return fail(EDS_ERR_INVALID, "num_levels out of range");
+    if (first_slot < 0 || first_slot + num_levels > h->B) return fail(EDS_ERR_INVALID, "slot range out of bounds (one slot per level)");
+    if (n_events < 0 || (n_events > 0 && !events)) return fail(EDS_ERR_INVALID, "bad event array");
+    if (stride < 5 || off_x < 0 || off_y < 0 || off_polarity < 0 || off_x + 2 > stride || off_y + 2 > stride || off_polarity + 1 > stride ||
+        (off_x & 1) || (off_y & 1) || (stride & 1))
+        return fail(EDS_ERR_INVALID, "bad event layout (x, y: 2-byte aligned uint16 fields inside an even stride)");
+    if (sensor_H <= 0 || sensor_W <= 0) { sensor_H = h->H; sensor_W = h->W; }
+    if (sensor_H < 2 || sensor_W < 2) return fail(EDS_ERR_INVALID, "bad sensor size");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    { int rc_ = unshare_frames(h, first_slot, num_levels); if (rc_) return rc_; }
+    const EdsEventAos aos = {events, stride, off_x, off_y, off_polarity};
+    return eds_frame_build_levels(h, first_slot, 0, num_levels, n_events, nullptr, nullptr, nullptr, sensor_H, sensor_W, blur_sigma, use_exp_weights,
+                                  norms, &aos);
+}
+
 int eds_trk_build_event_frame_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* x, const uint16_t* y,
                                     const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norms) {
     if (!h) return fail(EDS_ERR_INVALID, "null handle");

@@ -56,6 +56,14 @@ __global__ void k_vote(const uint16_t* __restrict__ ex, const uint16_t* __restri
     if (i >= n) return;
     vote_one(ex[i], ey[i], pol[i], i, n, mapx, mapy, H, W, use_exp, img);
 }
+// the same from an array of structs (x, y: uint16 fields, polarity: one byte, non-zero = positive)
+__global__ void k_vote_aos(const uint8_t* __restrict__ ev, int stride, int ox, int oy, int op, const float* __restrict__ mapx,
+                           const float* __restrict__ mapy, int n, int H, int W, int use_exp, double* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* e = ev + (size_t)i * stride;
+    vote_one(*reinterpret_cast<const uint16_t*>(e + ox), *reinterpret_cast<const uint16_t*>(e + oy), e[op] != 0, i, n, mapx, mapy, H, W, use_exp, img);
+}
 // many slices at once: blockIdx.y = slice, its events are [offsets[y], offsets[y + 1]) of the concatenated arrays, its image img + y * H * W
 __global__ void k_vote_batch(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey, const uint8_t* __restrict__ pol,
                              const int* __restrict__ offsets, const float* __restrict__ mapx, const float* __restrict__ mapy, int H, int W,
@@ -225,6 +233,7 @@ void eds_frame_free(EdsFrameBuffers* fb) {
     for (void* p : d) if (p) hipFree(p);
     if (fb->h_events) hipHostFree(fb->h_events);       // d_ex, d_ey, d_pol are its device view
     if (fb->h_norm_out) hipHostFree(fb->h_norm_out);
+    if (fb->h_aos) hipHostFree(fb->h_aos);
     void* bd[] = {fb->b_img, fb->b_tmp, fb->b_planes, fb->b_norm};
     for (void* q : bd) if (q) hipFree(q);
     if (fb->h_bmeta) hipHostFree(fb->h_bmeta);
@@ -255,7 +264,7 @@ int eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, 
 // events -> brightness image at the sensor's size (sH x sW) -> 3x3 Gaussian -> resize to the handle's H x W when they differ
 // (out_scale != 1) -> every level + its Frobenius norm in one launch -> normalise + store every level in one launch.
 int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
-                           const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out) {
+                           const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out, const EdsEventAos* aos) {
     EdsFrameBuffers& fb = h->frame_build;
     const int H = h->H, W = h->W;
     const size_t n = (size_t)H * W, ns = (size_t)sH * sW;
@@ -280,6 +289,19 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
         if (hipMalloc((void**)&fb.d_planes, n * 8 * nlevels) != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, "hipMalloc(level planes)");
         fb.plane_levels = nlevels;
     }
+    if (aos) {
+        const size_t bytes = (size_t)n_events * aos->stride;
+        if (bytes > fb.cap_aos) {
+            if (fb.h_aos) hipHostFree(fb.h_aos);
+            fb.h_aos = fb.d_aos = nullptr;
+            fb.cap_aos = bytes + bytes / 4 + 4096;
+            if (hipHostMalloc((void**)&fb.h_aos, fb.cap_aos, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&fb.d_aos, fb.h_aos, 0) != hipSuccess) {
+                fb.cap_aos = 0;
+                return eds_internal_fail(EDS_ERR_HIP, "hipHostMalloc(events)");
+            }
+        }
+    } else
     if (n_events > fb.cap_events) {
         if (fb.h_events) hipHostFree(fb.h_events);
         fb.d_ex = fb.d_ey = nullptr; fb.d_pol = nullptr; fb.h_events = nullptr;
@@ -296,7 +318,9 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     }
     hipStream_t st = h->st;
     hipError_t e = hipSuccess;
-    if (n_events > 0) {                 // pack into the pinned staging; k_vote reads it over PCIe (5 bytes per event)
+    if (n_events > 0 && aos) {
+        std::memcpy(fb.h_aos, aos->data, (size_t)n_events * aos->stride);     // as they are: k_vote_aos picks the fields
+    } else if (n_events > 0) {          // pack into the pinned staging; k_vote reads it over PCIe (5 bytes per event)
         const size_t cap = (size_t)fb.cap_events;
         std::memcpy(fb.h_events, ex, (size_t)n_events * 2);
         std::memcpy(fb.h_events + cap * 2, ey, (size_t)n_events * 2);
@@ -308,7 +332,10 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     double* norm_cur = fb.d_norm + (size_t)(fb.calls & 1) * NORM_SET;
     double* norm_next = fb.d_norm + (size_t)((fb.calls + 1) & 1) * NORM_SET;
     ++fb.calls;
-    if (n_events > 0)
+    if (n_events > 0 && aos)
+        hipLaunchKernelGGL(k_vote_aos, dim3((n_events + 255) / 256), dim3(256), 0, st, fb.d_aos, aos->stride, aos->off_x, aos->off_y, aos->off_pol,
+                           fb.d_mapx, fb.d_mapy, n_events, sH, sW, use_exp_weights, fb.d_img);
+    else if (n_events > 0)
         hipLaunchKernelGGL(k_vote, dim3((n_events + 255) / 256), dim3(256), 0, st, fb.d_ex, fb.d_ey, fb.d_pol, fb.d_mapx, fb.d_mapy,
                            n_events, sH, sW, use_exp_weights, fb.d_img);
     const dim3 b2(256);

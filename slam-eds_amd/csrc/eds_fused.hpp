@@ -95,6 +95,8 @@ struct EdsFrameBuffers {
     // d_norm holds TWO sets of sum-of-squares accumulators: a call accumulates into set (calls & 1) and its last launch clears the
     // other one for the next call; the totals come back through mapped pinned memory.  d_img is cleared by k_levels once the blur
     // has moved the image on (img_clean says whether that happened).  A frame is then 4 launches and one wait: no memset, no copy.
+    uint8_t *h_aos = nullptr, *d_aos = nullptr;    // mapped pinned staging of array-of-struct events (copied as they are, read strided by k_vote_aos)
+    size_t cap_aos = 0;
     double *h_norm_out = nullptr, *d_norm_out = nullptr;
     // batched builder (eds_frame_build_batch): accumulation / blur / level images of up to batch_cap slices, their accumulators, and a
     // mapped block [totals | event offsets]
@@ -112,8 +114,11 @@ int  eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* off
 bool eds_mirror_residuals(eds_trk* h, int first, int count);
 void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e);     // row-major fp32 H x W in HBM -> the slot's tiled frame
 int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
+// events as an array of structs (what the reference holds: std::vector<base::samples::Event>): stride and field offsets in bytes
+struct EdsEventAos { const void* data; int stride, off_x, off_y, off_pol; };
 int  eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, int n_events, const uint16_t* ex, const uint16_t* ey,
-                            const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out);
+                            const uint8_t* pol, int sH, int sW, double blur_sigma, int use_exp_weights, double* norms_out,
+                            const EdsEventAos* aos = nullptr);
 
 // ---- loss scale and point maintenance on device (eds_points.hip) --------------------------------------------
 struct EdsPointBuffers {

@@ -251,3 +251,36 @@ def test_build_event_frame_batch_in_several_groups(gpu, capi):
     for b in range(B):
         assert h.build_event_frame(B, *slices[b]) == pytest.approx(norms[b], rel=1e-11)
     h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["rock_event", "packed"])
+def test_build_event_frames_from_array_of_structs(gpu, capi, layout):
+    """eds_trk_build_event_frames_aos: the events as the reference holds them (std::vector<base::samples::Event>: time stamp, x, y,
+    polarity in a 16-byte record) — and as a tightly packed 6-byte record — against the structure-of-arrays entry point and the oracle,
+    all levels from one vote, with an undistortion map and a sensor twice the frame's size."""
+    import np_frame_oracle as fo
+    (sH, sW), (H, W), levels = (120, 160), (60, 80), 2
+    x, y, pol, mapx, mapy = make_events(77, 30000, sH, sW, distort=True)
+    if layout == "rock_event":
+        dt = np.dtype([("ts", np.int64), ("x", np.uint16), ("y", np.uint16), ("polarity", np.uint8)], align=True)
+        assert dt.itemsize == 16 and dt.fields["x"][1] == 8
+    else:
+        dt = np.dtype([("x", np.uint16), ("polarity", np.uint8), ("pad", np.uint8), ("y", np.uint16)])
+        assert dt.itemsize == 6
+    ev = np.zeros(len(x), dtype=dt)
+    ev["x"], ev["y"], ev["polarity"] = x, y, pol * 255                # any non-zero byte means positive
+    if "ts" in dt.fields:
+        ev["ts"] = np.arange(len(x)) * 1000
+    h = capi.Handle(capi.default_config(), 2 * levels, 64, H, W)
+    h.set_undistort_map_sized(mapx, mapy, (sH, sW))
+    n_aos = h.build_event_frames_aos(0, levels, ev, sensor_size=(sH, sW))
+    n_soa = h.build_event_frames(levels, levels, x, y, pol, sensor_size=(sH, sW))
+    ref_frames, ref_norms = fo.event_frames(x, y, pol, sH, sW, H, W, levels, mapx, mapy)
+    for i in range(levels):
+        assert n_aos[i] == pytest.approx(ref_norms[i], rel=1e-11) and n_aos[i] == pytest.approx(n_soa[i], rel=1e-12)
+        got = h.get_event_frame(i)
+        assert np.abs(got - ref_frames[i]).max() <= 1e-6 * np.abs(ref_frames[i]).max()
+    with pytest.raises(capi.EdsError):                                 # an odd offset for a uint16 field
+        capi._check(capi.lib().eds_trk_build_event_frames_aos(h._h, 0, 1, 10, ev.ctypes.data, 16, 9, 10, 12, sH, sW, 0.5, 1, None))
+    h.close()
