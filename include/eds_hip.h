@@ -141,6 +141,10 @@ int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, con
  * once the caller's array has been read (it may be reused at once); the device-side part is ordered before whatever the handle
  * does next and is not waited for. */
 int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp);
+/* The same straight from DepthPoints' own storage: the reference keeps [mu, sigma^2, a, b] per point (std::vector<Eigen::Vector4d>,
+ * DepthPoints.hpp:38,53) and getIDepth copies every first element into a fresh vector on each optimize (DepthPoints.cpp:230-237); here
+ * the inverse depth of point i is idp[i * stride] (stride in doubles: 4 for that container), no intermediate copy. */
+int eds_trk_set_idepth_strided(eds_trk* h, int slot, int N, const double* idp, int stride);
 /* Replaces `const std::vector<double>* event_frame` (Tracker.hpp:80): H*W row-major.  Returns as soon as the frame has been
  * narrowed to fp32 into the handle's staging buffer (the caller's buffer is free again); tiling on the device is ordered before the
  * next solve and not waited for. */

@@ -32,7 +32,7 @@ EXPORTS = (
     "eds_abi_version", "eds_device_count", "eds_last_error", "eds_trk_cfg_default", "eds_trk_cfg_size",
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
-    "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
+    "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_idepth_strided", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
     "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos",
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
@@ -116,6 +116,7 @@ def lib():
         L.eds_trk_set_keyframe.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double,
                                            C.c_double, C.c_double]
         L.eds_trk_set_idepth.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+        L.eds_trk_set_idepth_strided.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]
         L.eds_trk_set_event_frame.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_trk_set_event_frame_f32.argtypes = [C.c_void_p, C.c_int, _fp]
         L.eds_trk_set_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
@@ -251,6 +252,11 @@ class Handle:
     def set_idepth(self, slot, idp):
         d = _f64(idp)
         _check(lib().eds_trk_set_idepth(self._h, slot, int(d.shape[0]), _p(d)))
+
+    def set_idepth_strided(self, slot, table, column=0):
+        """Inverse depths as column `column` of a row-major N x k table of doubles (DepthPoints keeps N x 4)."""
+        t = np.ascontiguousarray(table, dtype=np.float64)
+        _check(lib().eds_trk_set_idepth_strided(self._h, slot, int(t.shape[0]), t[:, column:].ctypes.data_as(_dp), int(t.shape[1])))
 
     def set_event_frame(self, slot, frame):
         fr = np.asarray(frame)

@@ -601,7 +601,10 @@ int eds_trk_set_keyframe(eds_trk* h, int slot, int N, const double* norm_xy, con
     return EDS_OK;
 }
 
-int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) {
+int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) { return eds_trk_set_idepth_strided(h, slot, N, idp, 1); }
+
+int eds_trk_set_idepth_strided(eds_trk* h, int slot, int N, const double* idp, int stride) {
+    if (stride < 1) return fail(EDS_ERR_INVALID, "stride must be at least 1");
     int rc = check_slot(h, slot);
     if (rc) return rc;
     Slot& s = h->slots[slot];
@@ -611,7 +614,7 @@ int eds_trk_set_idepth(eds_trk* h, int slot, int N, const double* idp) {
     // only the inverse-depth plane changes (the geometry uses rho' = idp + 1e-5, the model the raw idp)
     // (Tracker.cpp:167 re-reads the depths on every optimize: this is on the live path, so nothing here waits for the GPU)
     if (h->idp_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_idp)); h->idp_busy = false; }
-    for (int i = 0; i < h->Np; ++i) h->h_idp[i] = i < N ? (float)idp[i] : 1.f;
+    for (int i = 0; i < h->Np; ++i) h->h_idp[i] = i < N ? (float)idp[(size_t)i * stride] : 1.f;
     EDS_HIP_TRY(hipMemcpyAsync(h->drho + (size_t)slot * h->Np, h->h_idp, (size_t)h->Np * 4, hipMemcpyHostToDevice, h->st));
     EDS_HIP_TRY(hipEventRecord(h->ev_idp, h->st));
     h->idp_busy = true;

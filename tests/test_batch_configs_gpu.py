@@ -377,3 +377,22 @@ def test_large_point_sets_in_large_batches_go_out_in_several_team_launches(gpu, 
         a = als[b % 5]
         ref = po.Oracle(a).pose6_lm(a.p0, a.q0, a.v0, iters=5, lambda0=0.01)
         assert po.se3_distance(res[0][b, 0:3], res[0][b, 3:7], ref["p"], ref["q"]) <= TOL_POSE
+
+
+def test_idepth_straight_from_the_depth_table(gpu, capi, synth):
+    """eds_trk_set_idepth_strided: the inverse depths as column 0 of DepthPoints' N x 4 table [mu, sigma^2, a, b] — the same solve, bit for
+    bit, as after eds_trk_set_idepth with a copy of that column."""
+    a = synth.make_alignment(7800, H=120, W=160, N=900)
+    rng = np.random.default_rng(1)
+    table = np.column_stack([a.idp * rng.uniform(0.9, 1.1, a.N), rng.uniform(0, 1, a.N), rng.uniform(0, 1, a.N), rng.uniform(0, 1, a.N)])
+    tabs = []
+    for strided in (False, True):
+        h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=5), 1, a.N, a.H, a.W)
+        h.set_alignment(0, a)
+        if strided: h.set_idepth_strided(0, table)
+        else: h.set_idepth(0, np.ascontiguousarray(table[:, 0]))
+        h.set_state(0, a.p0, a.q0, a.v0)
+        h.optimize_batch(0, 0, 1)
+        tabs.append(h.results(0, 1).copy())
+        h.close()
+    assert np.array_equal(tabs[0], tabs[1]) and tabs[0][0, 15] == 1.0
