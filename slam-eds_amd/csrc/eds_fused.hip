@@ -542,6 +542,34 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 }
 
 // ---------------------------------------------------------------------------------------
+// Two translation units from this one source (Makefile).  The machine scheduler's ILP-first strategy is worth +2 % on the bicubic
+// instantiations (and 6 % on a lone alignment) but costs the bilinear ones 9 % (20.6 -> 18.7 M iterations/s at 4 096 alignments),
+// and the strategy is a per-TU compiler flag: eds_fused_bilinear.o (-DEDS_FUSED_BILINEAR_TU, register-pressure trackers only) holds
+// the SAMPLING = 1 instantiations behind eds_fused6_launch_bilinear(); eds_fused.o holds the rest and the host side.
+#ifdef EDS_FUSED_BILINEAR_TU
+void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team) {
+    edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(L.sv);
+#define EDS_BL(P, T, K)                                                                                                            \
+    hipLaunchKernelGGL((eds_fused6_kernel<1, P, T, 0, K>), dim3(L.count * K), dim3(L.threads), 0, L.st, *L.A, L.in, L.out, svp,      \
+                       L.first, L.iters, L.damped, L.lambda0, L.tau, L.nb, L.mail, L.ticket, L.ticket_base, L.epoch)
+    if (team > 1) {
+        if (ppt == 1) { EDS_BL(1, 512, 4); }
+        else if (team == 2) { EDS_BL(2, 512, 2); }
+        else if (team == 4) { EDS_BL(2, 512, 4); }
+        else if (team == 8) { EDS_BL(2, 512, 8); }
+        else { EDS_BL(2, 512, 16); }
+        return;
+    }
+    const bool big = L.threads > 512;
+    switch (ppt) {
+        case 1: if (big) EDS_BL(1, 1024, 1); else EDS_BL(1, 512, 1); break;
+        case 2: if (big) EDS_BL(2, 1024, 1); else EDS_BL(2, 512, 1); break;
+        case 4: if (big) EDS_BL(4, 1024, 1); else EDS_BL(4, 512, 1); break;
+        default: if (big) EDS_BL(0, 1024, 1); else EDS_BL(0, 512, 1); break;
+    }
+#undef EDS_BL
+}
+#else
 int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     fb->B = B;
     // start states and compact results live in pinned host memory that the kernels read / write directly (a solve moves ~100 bytes
@@ -640,6 +668,11 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q, 1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u, 0u)
+#define EDS_LAUNCH_BILINEAR(P, K) do {                                                                                             \
+        const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, first, count, (K) > 1 ? 512 : threads, iters, damped, h->cfg.lambda0, tau, nb, \
+                                (K) > 1 ? fb.d_mail : nullptr, (K) > 1 ? fb.d_ticket : nullptr, (K) > 1 ? ticket_base : 0u,         \
+                                (K) > 1 ? fb.epoch : 0u, h->st};                                                                   \
+        eds_fused6_launch_bilinear(L, P, K); } while (0)
 #define EDS_LAUNCH_TEAM(S, P, Q, K)                                                                                                \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch)
@@ -648,6 +681,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
     // (16 000 points: 0.52 ms on one CU).
     int team = 1;
+    unsigned ticket_base = 0;          // (team launches shadow it with their own stretch of tickets)
     const bool team_ok = damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512;
     if (team_ok && maxN <= 2048) {
         if (count <= 64 && maxN > 1024) team = 4;
@@ -681,15 +715,15 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         const unsigned ticket_base = fb.ticket_base;
         fb.ticket_base += (unsigned)(count * team);
         if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_TEAM(1, 1, 0, 4);
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_BILINEAR(1, 4);
         } else if (team == 2) {                      // 1 024 points per member, two per lane
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 2); else EDS_LAUNCH_TEAM(0, 2, 0, 2); } else EDS_LAUNCH_TEAM(1, 2, 0, 2);
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 2); else EDS_LAUNCH_TEAM(0, 2, 0, 2); } else EDS_LAUNCH_BILINEAR(2, 2);
         } else if (team == 4) {                      // 1 024 points per member from here on
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 4); else EDS_LAUNCH_TEAM(0, 2, 0, 4); } else EDS_LAUNCH_TEAM(1, 2, 0, 4);
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 4); else EDS_LAUNCH_TEAM(0, 2, 0, 4); } else EDS_LAUNCH_BILINEAR(2, 4);
         } else if (team == 8) {
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 8); else EDS_LAUNCH_TEAM(0, 2, 0, 8); } else EDS_LAUNCH_TEAM(1, 2, 0, 8);
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 8); else EDS_LAUNCH_TEAM(0, 2, 0, 8); } else EDS_LAUNCH_BILINEAR(2, 8);
         } else {
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 16); else EDS_LAUNCH_TEAM(0, 2, 0, 16); } else EDS_LAUNCH_TEAM(1, 2, 0, 16);
+            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 16); else EDS_LAUNCH_TEAM(0, 2, 0, 16); } else EDS_LAUNCH_BILINEAR(2, 16);
         }
         }
     } else if (stream) {
@@ -705,15 +739,16 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
     quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP && h->H < 8000;     // every point's patch has a cache line of its own; 13-bit row field (pack_origin)
     switch (ppt) {
-        case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_FUSED_T(1, 1, 0); break;
-        case 2: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_FUSED_T(1, 2, 0); break;
-        case 4: if (bicubic) { if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_FUSED_T(1, 4, 0); break;
-        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0, 0); else EDS_LAUNCH_FUSED_T(1, 0, 0); break;
+        case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_BILINEAR(1, 1); break;
+        case 2: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_BILINEAR(2, 1); break;
+        case 4: if (bicubic) { if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_BILINEAR(4, 1); break;
+        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0, 0); else EDS_LAUNCH_BILINEAR(0, 1); break;
     }
     }
 #undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED
 #undef EDS_LAUNCH_TEAM
+#undef EDS_LAUNCH_BILINEAR
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
@@ -803,3 +838,4 @@ int eds_fused_fetch_trace(eds_trk* h, int slot) {
     delete tmp;
     return EDS_OK;
 }
+#endif   // EDS_FUSED_BILINEAR_TU

@@ -76,6 +76,14 @@ int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);
 struct EdsArrays;
 // eds_stream6.hip (wide = 1: one 512-thread workgroup per CU; 0: two 256-thread workgroups per CU)
+// launch arguments of one eds_fused6_kernel launch, for the instantiations that live in the second translation unit
+// (eds_fused.hip, EDS_FUSED_BILINEAR_TU)
+struct EdsFused6Launch {
+    const EdsArrays* A; const EdsFusedIn* in; EdsFusedOut* out; void* sv;
+    int first, count, threads, iters, damped; double lambda0, tau; int nb;
+    unsigned long long* mail; int* ticket; unsigned ticket_base, epoch; hipStream_t st;
+};
+void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team);
 void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,
                         int count, int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
 
