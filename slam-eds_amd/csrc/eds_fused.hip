@@ -550,7 +550,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team) {
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(L.sv);
 #define EDS_BL(P, T, K)                                                                                                            \
-    hipLaunchKernelGGL((eds_fused6_kernel<1, P, T, 0, K>), dim3(L.count * K), dim3(L.threads), 0, L.st, *L.A, L.in, L.out, svp,      \
+    hipLaunchKernelGGL((eds_fused6_kernel<1, P, T, 0, K>), dim3(L.count * K - L.drop), dim3(L.threads), 0, L.st, *L.A, L.in, L.out, svp,      \
                        L.first, L.iters, L.damped, L.lambda0, L.tau, L.nb, L.mail, L.ticket, L.ticket_base, L.epoch)
     if (team > 1) {
         if (ppt == 1) { EDS_BL(1, 512, 4); }
@@ -671,16 +671,19 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #define EDS_LAUNCH_BILINEAR(P, K) do {                                                                                             \
         const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, first, count, (K) > 1 ? 512 : threads, iters, damped, h->cfg.lambda0, tau, nb, \
                                 (K) > 1 ? fb.d_mail : nullptr, (K) > 1 ? fb.d_ticket : nullptr, (K) > 1 ? ticket_base : 0u,         \
-                                (K) > 1 ? fb.epoch : 0u, h->st};                                                                   \
+                                (K) > 1 ? fb.epoch : 0u, (K) > 1 ? drop : 0, h->st};                                                                   \
         eds_fused6_launch_bilinear(L, P, K); } while (0)
 #define EDS_LAUNCH_TEAM(S, P, Q, K)                                                                                                \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
+    hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K - drop), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
                        iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch)
     // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
     // solves with register-resident points only.  Up to 2 048 points: 4 CUs (512 points each) up to 64 alignments, 2 CUs up to 128.
     // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
     // (16 000 points: 0.52 ms on one CU).
     int team = 1;
+    // test hook for the time-out path: a team launch goes out one workgroup short, so its last team never completes, reports a time-out
+    // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
+    const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;
     unsigned ticket_base = 0;          // (team launches shadow it with their own stretch of tickets)
     const bool team_ok = damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512;
     if (team_ok && maxN <= 2048) {

@@ -81,7 +81,7 @@ struct EdsArrays;
 struct EdsFused6Launch {
     const EdsArrays* A; const EdsFusedIn* in; EdsFusedOut* out; void* sv;
     int first, count, threads, iters, damped; double lambda0, tau; int nb;
-    unsigned long long* mail; int* ticket; unsigned ticket_base, epoch; hipStream_t st;
+    unsigned long long* mail; int* ticket; unsigned ticket_base, epoch; int drop; hipStream_t st;
 };
 void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team);
 void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,

@@ -547,10 +547,11 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     fb.pending_team = team; fb.pending_level = level;
     const unsigned ticket_base = fb.ticket_base;
     if (team > 1) fb.ticket_base += (unsigned)(count * team);
+    const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;     // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
 #define EDS_LAUNCH12_(S, T, C, NCM, K, Q)                                                                                             \
-    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
+    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K - ((K) > 1 ? drop : 0)), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
                        h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch)
 #define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)

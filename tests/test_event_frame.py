@@ -284,3 +284,31 @@ def test_build_event_frames_from_array_of_structs(gpu, capi, layout):
     with pytest.raises(capi.EdsError):                                 # an odd offset for a uint16 field
         capi._check(capi.lib().eds_trk_build_event_frames_aos(h._h, 0, 1, 10, ev.ctypes.data, 16, 9, 10, 12, sH, sW, 0.5, 1, None))
     h.close()
+
+
+@pytest.mark.gpu
+def test_event_slice_without_a_vote_gives_the_references_nan_frame(gpu, capi):
+    """Every event of a slice lands outside the image (undistortion map): the vote image stays zero, cv::norm is 0 and the reference
+    divides every pixel by it (EventFrame.cpp:359-378: double / double, 0 / 0) — an all-NaN frame with norm 0, not an error.  The single,
+    the all-levels and the batched builder do the same, and a non-empty neighbour in the same batch is not disturbed."""
+    import np_frame_oracle as fo
+    H, W = 60, 80
+    h = capi.Handle(capi.default_config(), 4, 64, H, W)
+    mapx = np.full((H, W), -7.0, np.float32); mapy = np.full((H, W), -7.0, np.float32)
+    mapx[:, W // 2:] = np.arange(W // 2, W, dtype=np.float32)[None, :]; mapy[:, W // 2:] = np.arange(H, dtype=np.float32)[:, None]   # right half: identity
+    h.set_undistort_map(mapx, mapy)
+    out = (np.array([3, 5, 9], np.uint16), np.array([4, 40, 59], np.uint16), np.array([1, 0, 1], np.uint8))      # left half: mapped outside
+    rng = np.random.default_rng(4)
+    inside = (rng.integers(W // 2 + 2, W - 2, 500).astype(np.uint16), rng.integers(2, H - 2, 500).astype(np.uint16), rng.integers(0, 2, 500).astype(np.uint8))
+    with np.errstate(invalid="ignore"):
+        ref, ref_norm = fo.event_frame(*out, H, W, mapx=mapx, mapy=mapy)
+    assert ref_norm == 0.0 and np.isnan(ref).all()
+    assert h.build_event_frame(0, *out) == 0.0
+    assert np.isnan(h.get_event_frame(0)).all()
+    norms = h.build_event_frame_batch(1, [inside, out, inside])
+    assert norms[1] == 0.0 and norms[0] > 0.0 and norms[0] == norms[2]
+    assert np.isnan(h.get_event_frame(2)).all()
+    good, good_norm = fo.event_frame(*inside, H, W, mapx=mapx, mapy=mapy)
+    assert norms[0] == pytest.approx(good_norm, rel=1e-11)
+    for s in (1, 3):
+        assert np.abs(h.get_event_frame(s) - good).max() <= 1e-6 * np.abs(good).max()

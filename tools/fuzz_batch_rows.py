@@ -24,13 +24,15 @@ for t in range(trials):
         slices.append((rng.integers(0, W, n).astype(np.uint16), rng.integers(0, H, n).astype(np.uint16), rng.integers(0, 2, n).astype(np.uint8)))
     norms = hb.build_event_frame_batch(0, slices, level=level, blur_sigma=sigma)
     ok = True
+    why = []
     for b in range(B):
         if len(slices[b][0]) == 0:
-            ok &= norms[b] == 0.0
+            if norms[b] != 0.0: ok = False; why.append(f"empty slice {b}: norm {norms[b]}")
             continue
         n1 = hs.build_event_frame(0, *slices[b], level=level, blur_sigma=sigma)
         f1, fb = hs.get_event_frame(0), hb.get_event_frame(b)
-        ok &= abs(n1 - norms[b]) <= 1e-11 * max(n1, 1e-300) and np.abs(f1 - fb).max() <= 1e-6 * max(np.abs(f1).max(), 1e-30)
+        good = abs(n1 - norms[b]) <= 1e-11 * max(n1, 1e-300) and (np.isnan(f1).all() and np.isnan(fb).all() if n1 == 0.0 else np.abs(f1 - fb).max() <= 1e-6 * max(np.abs(f1).max(), 1e-30))    # (no vote: 0 / 0 everywhere, as the reference)
+        if not good: ok = False; why.append(f"frame {b} ({len(slices[b][0])} events): norm {n1!r} vs {norms[b]!r}, max |df| {np.abs(f1 - fb).max():.3e} of {np.abs(f1).max():.3e}")
     # keyframes + real frames for the solves, then the batched scales and getCoord against single-slot calls
     for b in range(B):
         hb.set_alignment(b, als[b % 3])
@@ -38,7 +40,8 @@ for t in range(trials):
     for method in (capi.LP_MAD, capi.LP_STD):
         tb = hb.loss_param_batch(method, 0, B)
         for b in rng.choice(B, size=min(B, 6), replace=False):
-            ok &= abs(tb[b] - hb.loss_param(int(b), method)) <= 1e-12 * max(abs(tb[b]), 1e-300)
+            one = hb.loss_param(int(b), method)
+            if not abs(tb[b] - one) <= 1e-12 * max(abs(tb[b]), 1e-300): ok = False; why.append(f"loss scale method {method} slot {b}: {tb[b]!r} vs {one!r}")
     poses = []
     for b in range(B):
         a = als[b % 3]
@@ -50,9 +53,10 @@ for t in range(trials):
         a = als[int(b) % 3]
         hs.set_alignment(0, a); hs.set_state(0, poses[int(b)][0], poses[int(b)][1], a.v0)
         o1 = hs.update_points(0, delete)
-        ok &= np.array_equal(o1["kept"], outs[int(b)]["kept"]) and np.array_equal(o1["coord"], outs[int(b)]["coord"]) and o1["mean_sq_flow"] == outs[int(b)]["mean_sq_flow"]
+        good = np.array_equal(o1["kept"], outs[int(b)]["kept"]) and np.array_equal(o1["coord"], outs[int(b)]["coord"]) and o1["mean_sq_flow"] == outs[int(b)]["mean_sq_flow"]
+        if not good: ok = False; why.append(f"getCoord slot {b}: kept {len(o1['kept'])} vs {len(outs[int(b)]['kept'])}, flow {o1['mean_sq_flow']!r} vs {outs[int(b)]['mean_sq_flow']!r}")
     hb.close(); hs.close()
-    print(f"trial {t}: {H}x{W} B={B} level={level} sigma={sigma} map={use_map} N={N} delete={delete}  {'ok' if ok else 'DISAGREE'}", flush=True)
+    print(f"trial {t}: {H}x{W} B={B} level={level} sigma={sigma} map={use_map} N={N} delete={delete}  {'ok' if ok else 'DISAGREE: ' + '; '.join(why[:4])}", flush=True)
     bad += 0 if ok else 1
 print(f"{trials} trials, {bad} disagreements")
 sys.exit(1 if bad else 0)

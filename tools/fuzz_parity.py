@@ -21,7 +21,22 @@ import pyoracle as po
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+chaotic = 0
 stats = {"lm6": 0, "gn6": 0, "ref12": 0}
+
+
+def oracle_spread(al, kw, start, ref):
+    """How far the fp64 oracle's own answer moves when frame and start translation change at the level of fp32 rounding (6e-8): the yardstick
+    for a reported difference.  Large for near-ties in an accept decision and for Cauchy / Huber blocks whose s sits at the corrector's
+    square-root singularity s = a^2 (tools/replay_parity_case.py)."""
+    prng = np.random.default_rng(12345)
+    dmax, cmax = 0.0, 0.0
+    for _ in range(3):
+        alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + 6e-8 * prng.standard_normal(al.frame.shape))})
+        r = po.Oracle(alp, **kw).solve_lm(start[0] * (1 + 6e-8 * prng.standard_normal(3)), start[1], start[2])
+        dmax = max(dmax, po.se3_distance(r["p"], r["q"], ref["p"], ref["q"]))
+        cmax = max(cmax, abs(r["final_cost"] - ref["final_cost"]))
+    return dmax, cmax
 
 
 def solve(al, env, **cfg):
@@ -64,7 +79,9 @@ for c in range(cases):
         runs = {"host": solve(al, {"EDS_REF12_EXEC": "host"}, exec=capi.EXEC_DEVICE, **kw),
                 "wide": solve(al, {"EDS_REF12_KERNEL": "wide"}, exec=capi.EXEC_DEVICE, **kw),
                 "paired": solve(al, {"EDS_REF12_KERNEL": "paired"}, exec=capi.EXEC_DEVICE, **kw)}
-        ref = po.Oracle(al, sampling=sampling, num_blocks=nb, nc=nc, loss_type=loss, loss_param=lp, max_num_iterations=iters).solve_lm(*cfg_start)
+        okw = dict(sampling=sampling, num_blocks=nb, nc=nc, loss_type=loss, loss_param=lp, max_num_iterations=iters)
+        ref = po.Oracle(al, **okw).solve_lm(*cfg_start)
+        spread = None
         base = runs["host"]
         for name, r in runs.items():
             if isinstance(r[0], str) != (not ref["usable"]):
@@ -75,11 +92,20 @@ for c in range(cases):
             same_path = r[3]["num_iterations"] == ref["num_iterations"] and r[3]["termination"] == ref["termination"]
             if not same_path:
                 # legit only when a tolerance decision fell the other way: costs must then agree to the tolerance
-                if abs(r[3]["final_cost"] - ref["final_cost"]) > 2e-4 * max(ref["final_cost"], 1e-12):
-                    print(tag, f"nb={nb} loss={loss}: {name} path differs: it {r[3]['num_iterations']} vs {ref['num_iterations']}, cost {r[3]['final_cost']:.6e} vs {ref['final_cost']:.6e}"); bad += 1
+                dc = abs(r[3]["final_cost"] - ref["final_cost"])
+                if dc > 2e-4 * max(ref["final_cost"], 1e-12):
+                    spread = spread or oracle_spread(al, okw, cfg_start, ref)
+                    if spread[1] > 0.3 * dc:
+                        print(tag, f"nb={nb} loss={loss}: {name} path differs (it {r[3]['num_iterations']} vs {ref['num_iterations']}) — ill-conditioned: the oracle's own cost moves by {spread[1]:.1e} on inputs perturbed by 6e-8 (difference {dc:.1e})"); chaotic += 1
+                    else:
+                        print(tag, f"nb={nb} loss={loss}: {name} path differs: it {r[3]['num_iterations']} vs {ref['num_iterations']}, cost {r[3]['final_cost']:.6e} vs {ref['final_cost']:.6e}"); bad += 1
                 continue
             d = po.se3_distance(r[0], r[1], ref["p"], ref["q"])
             if d > 5e-4 and N >= 100 and not far and sampling == 0:   # bilinear: kinks make trajectories chaotic
+                spread = spread or oracle_spread(al, okw, cfg_start, ref)
+            if d > 5e-4 and N >= 100 and not far and sampling == 0 and spread[0] > 0.3 * d:
+                print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread[0]:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+            elif d > 5e-4 and N >= 100 and not far and sampling == 0:
                 print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e}"
                       f" (cost {r[3]['final_cost']:.9e} vs {ref['final_cost']:.9e}, ok steps {r[3]['num_successful_steps']} vs {ref['num_successful_steps']},"
                       f" initial cost {r[3]['initial_cost']:.9e} vs {ref['initial_cost']:.9e})"); bad += 1
@@ -115,4 +141,4 @@ for c in range(cases):
             from_dev = po.se3_distance(runs["default"][0], runs["default"][1], ref["p"], ref["q"])
             if from_dev > 5e-4:
                 print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
-print(f"{cases} cases ({stats}), {bad} disagreements")
+print(f"{cases} cases ({stats}), {bad} disagreements" + (f", {chaotic} differences on ill-conditioned cases (the oracle itself moves as much)" if chaotic else ""))
