@@ -87,20 +87,28 @@ __device__ __forceinline__ double blur_row_at(const double* __restrict__ row, in
 #define EDS_SUMSQ_WAYS 64
 // (SUMSQ: the blurred image IS level 0 — it goes straight to the level plane and its sum of squares is accumulated here, one launch
 // and one pass over the image less than blur -> k_levels; blockIdx.z: image of a batch, 0 otherwise)
-template <bool SUMSQ>
+// RPT rows per thread (batches: a column strip slides down RPT rows, every row filter is formed once instead of three times and a
+// workgroup adds one partial sum of squares for RPT rows; a single image keeps one row per workgroup, 1 440 of them, to fill the chip)
+template <bool SUMSQ, int RPT>
 __global__ void k_blur3(const double* __restrict__ src, double* __restrict__ dst, int H, int W, double k0, double k1, double* __restrict__ sumsq) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r0 = blockIdx.y * RPT;
     src += (size_t)blockIdx.z * H * W; dst += (size_t)blockIdx.z * H * W;
-    double v = 0.0;
+    double s = 0.0;
     if (c < W) {
-        const double a = blur_row_at(src + (size_t)reflect101(r - 1, H) * W, c, W, k0, k1);
-        const double b = blur_row_at(src + (size_t)r * W, c, W, k0, k1);
-        const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
-        v = k0 * a + k1 * b + k0 * d;
-        dst[(size_t)r * W + c] = v;
+        double a = blur_row_at(src + (size_t)reflect101(r0 - 1, H) * W, c, W, k0, k1);
+        double b = blur_row_at(src + (size_t)r0 * W, c, W, k0, k1);
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int r = r0 + k;
+            if (r >= H) break;
+            const double d = blur_row_at(src + (size_t)reflect101(r + 1, H) * W, c, W, k0, k1);
+            const double v = k0 * a + k1 * b + k0 * d;
+            dst[(size_t)r * W + c] = v;
+            s += v * v;
+            a = b; b = d;
+        }
     }
     if (SUMSQ) {                        // as k_levels
-        double s = v * v;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         __shared__ double sh[4];
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -194,6 +202,33 @@ __global__ void k_store_levels(const double* __restrict__ planes, const double* 
     const double inv = normalise ? 1.0 / sqrt(ss) : 1.0;         // PhotometricErrorNC wants the raw frame (EventFrame.cpp:278-281)
     const double v = planes[(size_t)blockIdx.z * H * W + (size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)] * inv;
     frames[(size_t)(first_slot + blockIdx.z) * Hp * Wp + eds_frame_index(r, c, Wp, tiled)] = (float)v;
+}
+
+// The same for the images of a batch in the tiled layout: one thread per (tile, row of the tile) — a 16-byte store, a quad of lanes
+// writes one whole 64-byte tile, a wavefront 1 KB of consecutive tiles — and a workgroup walks many tile groups, so the accumulators
+// are added up once per workgroup instead of once per 64 pixels (k_store_levels: 64 loads and adds, a square root and a division in
+// front of ONE pixel per lane).  Same arithmetic per pixel.
+__global__ void k_store_tiles_batch(const double* __restrict__ planes, const double* __restrict__ sumsq, float* __restrict__ frames, int first_slot,
+                                    int H, int W, int Hp, int Wp, int normalise, double* __restrict__ total_out) {
+    const int TW = Wp >> 2, ntiles = (Hp >> 2) * TW;
+    double ss = 0.0;
+    for (int k = 0; k < EDS_SUMSQ_WAYS; ++k) ss += sumsq[blockIdx.z * EDS_SUMSQ_WAYS + k];      // (k_store_levels' order)
+    if (blockIdx.x == 0 && threadIdx.x == 0) total_out[blockIdx.z] = ss;
+    const double inv = normalise ? 1.0 / sqrt(ss) : 1.0;
+    const double* __restrict__ pl = planes + (size_t)blockIdx.z * H * W;
+    float* __restrict__ fr = frames + (size_t)(first_slot + blockIdx.z) * Hp * Wp;
+    const int j = threadIdx.x & 3, per = blockDim.x >> 2;
+    for (int t = blockIdx.x * per + (threadIdx.x >> 2); t < ntiles; t += gridDim.x * per) {
+        const int ty = t / TW, tx = t - ty * TW;
+        const int r = min(max(ty * 4 + j - EDS_FRAME_MARGIN, 0), H - 1), c0 = tx * 4 - EDS_FRAME_MARGIN;
+        const double* __restrict__ row = pl + (size_t)r * W;
+        float4 o;
+        o.x = (float)(row[min(max(c0, 0), W - 1)] * inv);
+        o.y = (float)(row[min(max(c0 + 1, 0), W - 1)] * inv);
+        o.z = (float)(row[min(max(c0 + 2, 0), W - 1)] * inv);
+        o.w = (float)(row[min(max(c0 + 3, 0), W - 1)] * inv);
+        *reinterpret_cast<float4*>(fr + (size_t)t * 16 + j * 4) = o;
+    }
 }
 
 // row-major H x W fp32 image -> the handle's frame layout (tiles, padding and margin filled with the nearest border pixel): the
@@ -345,8 +380,8 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     const bool fused0 = blur_sigma > 0.0 && nlevels == 1 && level0 == 0 && sH == H && sW == W;
     if (blur_sigma > 0.0) {             // cv::getGaussianKernel(3, sigma): exp(-x^2 / (2 sigma^2)), normalised
         const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), s = 1.0 + 2.0 * t;
-        if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((sW + 255) / 256, sH), b2, 0, st, cur, fb.d_planes, sH, sW, t / s, 1.0 / s, norm_cur);
-        else hipLaunchKernelGGL(k_blur3<false>, dim3((sW + 255) / 256, sH), b2, 0, st, cur, other, sH, sW, t / s, 1.0 / s, (double*)nullptr);
+        if (fused0) hipLaunchKernelGGL((k_blur3<true, 1>), dim3((sW + 255) / 256, sH), b2, 0, st, cur, fb.d_planes, sH, sW, t / s, 1.0 / s, norm_cur);
+        else hipLaunchKernelGGL((k_blur3<false, 1>), dim3((sW + 255) / 256, sH), b2, 0, st, cur, other, sH, sW, t / s, 1.0 / s, (double*)nullptr);
         std::swap(cur, other);
     }
     if (sH != H || sW != W) {           // out_scale != 1 (EventFrame.cpp:342-346)
@@ -458,13 +493,19 @@ int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offs
             const bool fused0 = blur_sigma > 0.0 && level == 0;       // the blurred image is the level: blur + plane + sum of squares in one launch
             if (blur_sigma > 0.0) {
                 const double t = std::exp(-0.5 / (blur_sigma * blur_sigma)), sk = 1.0 + 2.0 * t;
-                if (fused0) hipLaunchKernelGGL(k_blur3<true>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, H, W, t / sk, 1.0 / sk, fb.b_norm);
-                else hipLaunchKernelGGL(k_blur3<false>, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk, (double*)nullptr);
+                if (fused0) hipLaunchKernelGGL((k_blur3<true, 4>), dim3((W + 255) / 256, (H + 3) / 4, cn), b2, 0, st, cur, fb.b_planes, H, W, t / sk, 1.0 / sk, fb.b_norm);
+                else hipLaunchKernelGGL((k_blur3<false, 4>), dim3((W + 255) / 256, (H + 3) / 4, cn), b2, 0, st, cur, fb.b_tmp, H, W, t / sk, 1.0 / sk, (double*)nullptr);
                 cur = fb.b_tmp;
             }
             if (!fused0) hipLaunchKernelGGL(k_levels, dim3((W + 255) / 256, H, cn), b2, 0, st, cur, fb.b_planes, fb.b_norm, H, W, level, (double*)nullptr, 1);
-            hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + g0 + c0, H, W,
-                               h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot + c0, (double*)nullptr);
+            if (h->tiled) {
+                const int ntiles = (h->Hp >> 2) * (h->Wp >> 2);
+                hipLaunchKernelGGL(k_store_tiles_batch, dim3(std::min((ntiles + 63) / 64, 64), 1, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe,
+                                   first_slot + g0 + c0, H, W, h->Hp, h->Wp, h->cfg.nc ? 0 : 1, d_tot + c0);
+            } else {
+                hipLaunchKernelGGL(k_store_levels, dim3((h->Wp + 255) / 256, h->Hp, cn), b2, 0, st, fb.b_planes, fb.b_norm, h->dframe, first_slot + g0 + c0, H, W,
+                                   h->Hp, h->Wp, h->tiled, h->cfg.nc ? 0 : 1, (double*)nullptr, d_tot + c0, (double*)nullptr);
+            }
         }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(st);
