@@ -22,6 +22,12 @@ for b in range(64): h.set_alignment(b, als[b % 8])
 for _ in range(5):
     h.optimize_batch(0, 0, 64); h.loss_param_batch(capi.LP_MAD)
 for b in range(64): h.update_points(b, True)
+# the batched forms (configs[4]: one event slice per tracker): 64 slices of 20 k events, getCoord of all 64
+sl = [(rng.integers(0, W, 20_000).astype(np.uint16), rng.integers(0, H, 20_000).astype(np.uint16), rng.integers(0, 2, 20_000).astype(np.uint8)) for _ in range(64)]
+for _ in range(6): h.build_event_frame_batch(0, sl)
+for b in range(64): h.set_alignment(b, als[b % 8])
+h.optimize_batch(0, 0, 64)
+for _ in range(6): h.update_points_batch(0, 64, False, want_points=False)
 h.close()
 img = rng.standard_normal((H, W))
 for _ in range(3): img = (img + np.roll(img, 1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 0) + np.roll(img, -1, 1)) / 5.0
