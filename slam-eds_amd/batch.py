@@ -39,6 +39,10 @@ def gather_results(local: np.ndarray, total: int, device=None, to_host: bool = T
     identity (single process).  Shards may be ragged; rows are padded to the common shard size for
     the collective and trimmed afterwards.
     """
+    from . import capi
+    if device is not None and capi.torch_loaded_first is False:
+        raise RuntimeError("a GPU collective needs torch.cuda, and PyTorch-ROCm only works on its own HIP runtime: import torch before the "
+                           "first slam-eds_amd call in this process (libeds_hip.so was loaded first and brought /opt/rocm's libamdhip64.so.7)")
     import torch
     import torch.distributed as dist
     local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, RESULT_WIDTH)
@@ -66,6 +70,8 @@ class BatchTracker:
     """Solves this rank's shard of `total` alignments on one GPU handle."""
 
     def __init__(self, cfg, total: int, max_points: int, H: int, W: int, rank: int = 0, world_size: int = 1):
+        if world_size > 1:
+            import torch  # noqa: F401  (before libeds_hip.so: see capi.torch_loaded_first)
         from . import capi
         self.capi = capi
         self.total, self.rank, self.world_size = total, rank, world_size

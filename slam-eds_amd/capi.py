@@ -96,6 +96,10 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+# PyTorch-ROCm ships its own libamdhip64.so.7 and libeds_hip.so is linked against /opt/rocm's: one process holds ONE copy of a SONAME,
+# whichever is loaded first.  torch works only on its own, libeds_hip on either — so a process that uses torch.cuda as well must
+# import torch before the first call into this module (bench.py and BatchTracker do; batch.gather_results checks).
+torch_loaded_first = None
 
 
 def lib():
@@ -104,6 +108,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise EdsError(ERR_NO_DEVICE, f"{LIB_PATH} is missing — run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+        global torch_loaded_first
+        import sys
+        torch_loaded_first = "torch" in sys.modules
         L = C.CDLL(LIB_PATH)
         L.eds_last_error.restype = C.c_char_p
         L.eds_trk_create.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
