@@ -546,7 +546,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 // instantiations (and 6 % on a lone alignment) but costs the bilinear ones 9 % (20.6 -> 18.7 M iterations/s at 4 096 alignments),
 // and the strategy is a per-TU compiler flag: eds_fused_bilinear.o (-DEDS_FUSED_BILINEAR_TU, register-pressure trackers only) holds
 // the SAMPLING = 1 instantiations behind eds_fused6_launch_bilinear(); eds_fused.o holds the rest and the host side.
-#ifdef EDS_FUSED_BILINEAR_TU
+#if defined(EDS_FUSED_BILINEAR_TU) || defined(EDS_FUSED_ONE_TU)      // (ONE_TU: the diagnostic builds, one command line for every source)
 void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team) {
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(L.sv);
 #define EDS_BL(P, T, K)                                                                                                            \
@@ -569,7 +569,8 @@ void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team) {
     }
 #undef EDS_BL
 }
-#else
+#endif
+#ifndef EDS_FUSED_BILINEAR_TU
 int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     fb->B = B;
     // start states and compact results live in pinned host memory that the kernels read / write directly (a solve moves ~100 bytes

@@ -524,6 +524,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     int team = 1;
     if (wide && !h->cfg.nc && !fb.team_disabled && maxN > 512 && count <= EDS_TEAM12_SLOTS) {
         team = (count <= 64 && maxN > 1024) ? 4 : 2;
+        if (count <= 16 && maxN > 1024) team = 8;                                   // a handful of alignments: 8 CUs each (2 000 points: 152 vs 159 us; equal from 32 alignments on)
         if (maxN > 8192 && count * 16 <= EDS_TEAM12_MEMBERS) team = 16;          // the finer pyramid levels (configs[2..3]): ~1 000 points per CU
         else if (maxN > 4096 && count * 8 <= EDS_TEAM12_MEMBERS) team = 8;
     }
