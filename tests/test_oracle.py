@@ -64,6 +64,44 @@ def test_bicubic_clamps_like_grid2d(po):
     assert f0 == pytest.approx(ref, abs=1e-13)
 
 
+def test_bicubic_matches_scipy_hermite_splines_with_catmull_rom_tangents(po):
+    """An implementation the oracle shares no code with: ceres::CubicHermiteSpline through (p1, p2) with the end slopes
+    (p2 - p0)/2 and (p3 - p1)/2 IS scipy.interpolate.CubicHermiteSpline with those dydx — along the columns of the four rows around the
+    sample, then once along the rows (values for f and d/drow, column derivatives for d/dcol), as BiCubicInterpolator::Evaluate does."""
+    from scipy.interpolate import CubicHermiteSpline
+    rng = np.random.default_rng(11)
+    fr = rng.standard_normal((18, 22))
+
+    def cr(p, x0, x):             # the Catmull-Rom piece between samples p[1] (at x0) and p[2] (at x0 + 1)
+        sp = CubicHermiteSpline([x0, x0 + 1.0], [p[1], p[2]], [(p[2] - p[0]) / 2.0, (p[3] - p[1]) / 2.0])
+        return float(sp(x)), float(sp.derivative()(x))
+
+    for _ in range(200):
+        r, c = rng.uniform(1.0, 15.999), rng.uniform(1.0, 19.999)        # interior: no clamping involved
+        r0, c0 = int(np.floor(r)), int(np.floor(c))
+        rows = [cr(fr[r0 - 1 + k, c0 - 1:c0 + 3], c0, c) for k in range(4)]
+        f, d_row = cr([v for v, _ in rows], r0, r)
+        d_col, _ = cr([d for _, d in rows], r0, r)
+        got = po.bicubic(fr, r, c)
+        assert got[0] == pytest.approx(f, abs=1e-13) and got[1] == pytest.approx(d_row, abs=1e-12) and got[2] == pytest.approx(d_col, abs=1e-12)
+
+
+def test_bicubic_is_the_spline_the_reference_restates_in_repo(po):
+    """The reference holds its own (float) copy of the spline Ceres' BiCubicInterpolator uses, for the DSO side
+    (/root/reference/src/utils/globalFuncs.h:192-195, 219-234: value at x past p[1] = p1 + x/2 (p2 - p0 + x (2 p0 - 5 p1 + 4 p2 - p3
+    + x (3 (p1 - p2) + p3 - p0))), first along x for the four rows, then along y).  That header needs Eigen and cannot be compiled here,
+    so the polynomial is written out in fp64 and the oracle must agree with it — the one piece of reference text that pins the sampler."""
+    def cub(p, x):
+        return p[1] + 0.5 * x * (p[2] - p[0] + x * (2.0 * p[0] - 5.0 * p[1] + 4.0 * p[2] - p[3] + x * (3.0 * (p[1] - p[2]) + p[3] - p[0])))
+    rng = np.random.default_rng(12)
+    fr = rng.standard_normal((16, 21))
+    for _ in range(200):
+        y, x = rng.uniform(1.0, 13.999), rng.uniform(1.0, 18.999)           # (row, col), interior
+        iy, ix = int(y), int(x)
+        val = [cub(fr[iy - 1 + k, ix - 1:ix + 3], x - ix) for k in range(4)]
+        assert po.bicubic(fr, y, x)[0] == pytest.approx(cub(val, y - iy), abs=1e-13)
+
+
 def test_bicubic_cpp_matches_numpy(po, npo):
     rng = np.random.default_rng(5)
     fr = rng.standard_normal((20, 24))
