@@ -136,6 +136,22 @@ def test_jacobians_autodiff_vs_closed_form(po, npo, al, nb, sampling):
     assert np.allclose(e6["b"], J6.T @ r, rtol=1e-10, atol=1e-14)
 
 
+def test_se3_row_is_the_row_the_reference_accumulates(po, npo, al):
+    """The pose-only view perturbs T <- exp(xi) T and differentiates with Jet<6>.  The reference's own 6-DoF tracker forms the same row in
+    closed form (/root/reference/src/tracking/CoarseTracker.cpp:304-321, the arguments of acc.updateSSE_eighted):
+        [id dx, id dy, -id (u dx + v dy), -(u v dx + (1 + v^2) dy), u v dy + (1 + u^2) dx, u dy - v dx]
+    with u = Px/Pz, v = Py/Pz, id = 1/Pz, dx = fx dE/dcol, dy = fy dE/drow.  Here the residual is w (mhat - E), hence the factor -w."""
+    tp, q = _pose(seed=9, ang=0.01, t=0.004)
+    ev = po.Oracle(al).pose6_eval(tp, q, al.v0)
+    _, P, ucol, vrow = npo.project(al, tp, q)
+    E, dE_drow, dE_dcol = npo.bicubic(al.frame, vrow, ucol)
+    u, v, idz = P[:, 0] / P[:, 2], P[:, 1] / P[:, 2], 1.0 / P[:, 2]
+    dx, dy = al.fx * dE_dcol, al.fy * dE_drow
+    row = np.stack([idz * dx, idz * dy, -idz * (u * dx + v * dy), -(u * v * dx + (1 + v * v) * dy), u * v * dy + (1 + u * u) * dx, u * dy - v * dx], axis=1)
+    ref = -al.weights[:, None] * row
+    assert np.abs(ev["J"] - ref).max() <= 1e-12 * max(np.abs(ref).max(), 1.0)
+
+
 def test_jacobians_vs_finite_differences(npo, al):
     # bicubic is C1 with a discontinuous second derivative at pixel borders, so a handful of points
     # whose +-h stencil straddles a border carry an O(h) error: compare with a robust statistic.
