@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic alignments (replicated to fill the batch)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-shared", dest="no_shared", action="store_true", help="skip the informational shared-frame measurement (it launches the "
+    ap.add_argument("--no-shared", dest="no_shared", action="store_true", help="skip the informational two-batches-in-flight and shared-frame measurements (the latter launches the "
                     "headline kernel on another workload: keep it out of profiler runs)")
     return ap.parse_args()
 
@@ -526,6 +526,35 @@ def main():
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device":
             out["latency"] = latency_block(capi, synth, als[0], a)
+        if world == 1 and a.exec_ == "device" and not a.no_shared:
+            # Informational: TWO batches in flight — a second handle (own stream, own copy of every frame) takes step k + 1 while step k
+            # runs.  The host's work per step and, more, the TAIL of a launch (its last workgroups end up to one alignment's duration
+            # apart: ~110 us of idle per CU in a 2.7 ms launch, 4-5 %) disappear under the other batch's kernel.  Not the headline: the
+            # contract's step is one batch on one stream, and two overlapping launches stretch each other's event-measured duration.
+            h2 = capi.Handle(cfg, B, N, H, W)
+            for b in range(B):
+                x = als[b % distinct]
+                h2.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy)
+                h2.set_event_frame(b, frames32[b % distinct])
+            hs = [h, h2]
+            for hh in hs:                                  # warm-up, one at a time
+                hh.set_states(0, p0, q0, v0); hh.optimize_batch(0, 0, B, sync=True)
+            nsteps = 8
+            t1 = time.perf_counter()
+            hs[0].set_states(0, p0, q0, v0); hs[0].optimize_batch(0, 0, B, sync=False)
+            same = True
+            for k in range(nsteps):
+                cur, nxt = hs[k % 2], hs[(k + 1) % 2]
+                if k + 1 < nsteps:
+                    nxt.set_states(0, p0, q0, v0); nxt.optimize_batch(0, 0, B, sync=False)
+                cur.sync()
+                tabk = cur.results(0, B)
+                same = same and (bool(np.array_equal(tabk, table)) if a.solver == "lm6" else True)
+            el = time.perf_counter() - t1
+            out["two_batches_in_flight"] = {"iterations_per_s": nsteps * B * float(np.mean(tabk[:, 14])) / el, "ms_per_step": 1e3 * el / nsteps,
+                                            "steps": nsteps, "identical_to_single_batch": same,
+                                            "note": "NOT the headline: two handles / streams alternate, step k + 1 is launched while step k runs"}
+            h2.close()
         if world == 1 and a.exec_ == "device" and not a.no_shared and B > distinct:
             # A DIFFERENT workload, informational: the same batch when the alignments that are replicas of one another also SHARE their
             # event frame (eds_trk_share_event_frame: slot b samples slot b % distinct's storage) — several keyframes / pose hypotheses
