@@ -18,10 +18,12 @@
 // run on different CUs, B >> 256 fills the chip.  No MFMA-shaped work exists on this path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
@@ -776,6 +778,20 @@ int eds_fused_collect(eds_trk* h) {
         dev_ms = t1 > t0 ? (float)((double)(t1 - t0) * 1e-5) : 0.f;        // 100 MHz ticks
     } else {
         hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
+    }
+    if (fb.pending_team == 1 && getenv("EDS_FUSED_REPORT")) {     // diagnostic: what the workgroups' own begin / end stamps say about the launch
+        std::vector<unsigned long long> te;
+        unsigned long long t0 = ~0ull, t1 = 0; double busy = 0.0;
+        for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) {
+            t0 = std::min(t0, fb.h_out[s].t_begin); t1 = std::max(t1, fb.h_out[s].t_end);
+            busy += (double)(fb.h_out[s].t_end - fb.h_out[s].t_begin); te.push_back(fb.h_out[s].t_end);
+        }
+        std::sort(te.begin(), te.end());
+        double tail = 0.0; const int nc = std::min(256, (int)te.size());
+        for (int i = 0; i < nc; ++i) tail += (double)(t1 - te[te.size() - 1 - i]);       // the last workgroup of each CU = the 256 latest ends
+        const double span = (double)(t1 - t0);
+        std::fprintf(stderr, "[eds_fused] %d alignments: span %.1f us, mean workgroup %.1f us, covered %.3f of 256 CUs x span, tail idle %.1f us per CU\n",
+                     fb.pending_count, span * 1e-2, busy / fb.pending_count * 1e-2, span > 0 ? busy / (256.0 * span) : 0.0, tail / nc * 1e-2);
     }
     if (fb.pending_team > 1) {                        // a team whose members did not all become resident within the bound
         bool timed_out = false;
