@@ -315,6 +315,16 @@ def main():
     backend = os.environ.get("EDS_BENCH_BACKEND", "nccl")
     if "EDS_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["EDS_BENCH_DEVICE"])
+    # EDS_BENCH_FORCE_DIST=1 (single-GPU boxes): a process group of ONE rank over RCCL and the sharded step below — the overlap of the
+    # torch stream's all-gather with the library stream's solve and all_gather_into_tensor on a device tensor run on the hardware
+    # before the multi-GPU node sees them.  Same workload, same metric; the JSON line says "forced_dist": true.
+    forced = world == 1 and os.environ.get("EDS_BENCH_FORCE_DIST") == "1"
+    if forced:
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port_))
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1:
         if backend == "nccl" and torch.cuda.device_count() < world:      # device_count() does not initialise the GPU
             raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
@@ -324,7 +334,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if world > 1:
+    if world > 1 or forced:
         world = dist.get_world_size()               # n_gpus is reported from the collective, not from the environment
         assert world == a.gpus, (world, a.gpus)
     capi = importlib.import_module("slam-eds_amd.capi")
@@ -353,7 +363,7 @@ def main():
     p0 = np.stack([als[b % distinct].p0 for b in range(B)])
     q0 = np.stack([als[b % distinct].q0 for b in range(B)])
     v0 = np.stack([als[b % distinct].v0 for b in range(B)])
-    dev = torch.device("cuda", local_rank) if (world > 1 and backend == "nccl") else None
+    dev = torch.device("cuda", local_rank) if ((world > 1 and backend == "nccl") or forced) else None
 
     def step():
         h.set_states(0, p0, q0, v0)                  # same start every step (host-side, 104 B per slot)
@@ -361,7 +371,7 @@ def main():
         return h.results(0, B)
 
     def gather(local):
-        return batchmod.gather_results(local, total, device=dev, to_host=(rank == 0))
+        return batchmod.gather_results(local, total, device=dev, to_host=(rank == 0), force=forced)
 
     def step_sharded(prev_local):
         """Several GPUs: the all-gather of step k-1 (RCCL on torch's stream) overlaps the solve of step k (library stream)."""
@@ -373,14 +383,14 @@ def main():
 
     for _ in range(a.warmup):
         table = step()
-        if world > 1:
+        if world > 1 or forced:
             table = gather(table)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
     torch.cuda.synchronize()
     dev_us = []
     t0 = time.perf_counter()
-    if world == 1:
+    if world == 1 and not forced:
         for _ in range(a.steps):
             table = step()
             dev_us.append(h.info(0)["device_time_us"])
@@ -395,10 +405,10 @@ def main():
         if t_last is not None:
             table = t_last
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or forced:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -469,6 +479,8 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj,
         }
+        if forced:
+            out["forced_dist"] = True
         if world == 1 and a.exec_ == "device" and a.sampling == "bicubic" and not a.no_ref12:
             # the sampler north_star names (bilinear, 2x2 taps; the reference itself samples bicubically): informational
             h.set_config(capi.default_config(device=0, sampling=capi.SAMPLE_BILINEAR, solver=cfg.solver, exec=capi.EXEC_DEVICE,
@@ -605,7 +617,7 @@ def main():
             if "reference_problem" in out:
                 out["reference_problem"]["speedup_vs_cpu_ref12_all_threads"] = \
                     out["reference_problem"]["lm_iterations_per_s"] / max(v["lm_iterations_per_s"] for k, v in out["cpu_baseline_ref12"].items() if k.startswith("T"))
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -31,12 +31,14 @@ def pack_result(p, q, v, cost, iterations, success) -> np.ndarray:
     return out
 
 
-def gather_results(local: np.ndarray, total: int, device=None, to_host: bool = True):
+def gather_results(local: np.ndarray, total: int, device=None, to_host: bool = True, force: bool = False):
     """All-gather the per-rank result rows into the global [total, 16] table (every rank gets it; with
     ``to_host=False`` a rank only takes part in the collective and returns None — e.g. every rank but 0 in bench.py).
 
     `local` is this rank's [count, 16] block.  Without an initialised process group this is the
-    identity (single process).  Shards may be ragged; rows are padded to the common shard size for
+    identity (single process); with a group of ONE rank too, unless ``force`` asks for the collective
+    all the same (the single-GPU box's only way to put RCCL's all-gather of a device tensor under
+    test: tests/test_rccl_gpu.py, ``EDS_BENCH_FORCE_DIST=1 python bench.py``).  Shards may be ragged; rows are padded to the common shard size for
     the collective and trimmed afterwards.
     """
     from . import capi
@@ -46,7 +48,7 @@ def gather_results(local: np.ndarray, total: int, device=None, to_host: bool = T
     import torch
     import torch.distributed as dist
     local = np.ascontiguousarray(local, dtype=np.float64).reshape(-1, RESULT_WIDTH)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local[:total].copy()
     world = dist.get_world_size()
     per = -(-total // world)

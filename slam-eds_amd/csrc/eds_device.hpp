@@ -140,6 +140,9 @@ __device__ __forceinline__ void load_patch_row(const float* __restrict__ tiles, 
     a = *reinterpret_cast<const float4*>(base + (row_b + (((cc - 1u) >> 2) << 6)));
     b = *reinterpret_cast<const float4*>(base + (row_b + (((cc + 2u) >> 2) << 6)));
 }
+// three registers whose content does not matter and that cost NO instruction: outputs of an empty asm (freeze(undef), below, is
+// materialised as v_mov 0 once it meets a phi)
+__device__ __forceinline__ void dont_care3(float4& b) { asm("" : "=v"(b.x), "=v"(b.y), "=v"(b.z)); b.w = b.z; }
 // a register whose content does not matter (no instruction emitted): the unselected arm of a bit_select
 __device__ __forceinline__ float4 dont_care4() {
     float x = 0.f;
@@ -166,6 +169,20 @@ __device__ __forceinline__ void shift_patch_row(const float4& a, const float4& b
                 t4 = bit_select(m2, b.z, b.x);
     t[0] = bit_select(m1, t1, t0); t[1] = bit_select(m1, t2, t1); t[2] = bit_select(m1, t3, t2); t[3] = bit_select(m1, t4, t3);
 }
+// The same barrel shift as ONE v_bitop3_b32 per select through the gfx950 builtin (round 3; truth table 0xCA = S0 ? S1 : S2 bit by
+// bit): no inline asm in the point loop, so the scheduler may move the selects and the register allocator may put their results
+// wherever the consumer wants them (the 16-byte cache store, the pairs of the packed row splines) — and, being a target intrinsic,
+// nothing the SLP vectoriser can turn into <2 x i32> logic plus shuffles (which it did to the same selects written as and / xor).
+__device__ __forceinline__ float mask_select(int m, float yes, float no) {
+    return __int_as_float(__builtin_amdgcn_bitop3_b32(m, __float_as_int(yes), __float_as_int(no), 0xCA));
+}
+__device__ __forceinline__ void shift_patch_row3(const float4& a, const float4& b, int origin, float (&t)[4]) {
+    const int m2 = __builtin_amdgcn_sbfe(origin, 30, 1), m1 = __builtin_amdgcn_sbfe(origin, 29, 1);
+    const float t0 = mask_select(m2, a.z, a.x), t1 = mask_select(m2, a.w, a.y), t2 = mask_select(m2, b.x, a.z), t3 = mask_select(m2, b.y, a.w),
+                t4 = mask_select(m2, b.z, b.x);
+    t[0] = mask_select(m1, t1, t0); t[1] = mask_select(m1, t2, t1); t[2] = mask_select(m1, t3, t2); t[3] = mask_select(m1, t4, t3);
+}
+
 // LDS patch cache of the quad path: [point][row][4 taps], one 16-byte unit per (point, row), units XOR-swizzled by the
 // quad index so that the 16 lanes one ds_read_b128 / ds_write_b128 services together hit 16 different bank groups.
 __device__ __forceinline__ int patch_unit(int point, int row) { return ((point << 2) + row) ^ (((point >> 2) & 3) << 2); }
@@ -237,6 +254,17 @@ __device__ __forceinline__ void load_pose_rt(const double* D, const double* t, c
     ps.fx = uniformf((float)pb[EDS_PB_K]);
     ps.fy = uniformf((float)pb[EDS_PB_K + 1]);
 }
+
+// The pose of the packed point phase travels as fourteen scalar VALUES (macro below: plain locals, never a struct).  From a struct
+// — array or named members alike — the vectoriser widened the loads of the scalars it had to splat for the packed multiplies into
+// overlapping <2 x float> loads of the stack object, the object could then no longer be promoted to registers, and the whole pose
+// went through scratch memory every pass.  rt: R - I then t (12 floats, narrowed once by the lane that made the pose), kf32 = {fx, fy}.
+#define EDS_LOAD_POSE_SCALARS(rt, kf32)                                                                                          \
+    const float ps_d0 = uniformf((rt)[0]), ps_d1 = uniformf((rt)[1]), ps_d2 = uniformf((rt)[2]), ps_d3 = uniformf((rt)[3]),    \
+                ps_d4 = uniformf((rt)[4]), ps_d5 = uniformf((rt)[5]), ps_d6 = uniformf((rt)[6]), ps_d7 = uniformf((rt)[7]),    \
+                ps_d8 = uniformf((rt)[8]), ps_t0 = uniformf((rt)[9]), ps_t1 = uniformf((rt)[10]), ps_t2 = uniformf((rt)[11]), \
+                ps_fx = uniformf((kf32)[0]), ps_fy = uniformf((kf32)[1])
+#define EDS_POSE_SCALARS ps_d0, ps_d1, ps_d2, ps_d3, ps_d4, ps_d5, ps_d6, ps_d7, ps_d8, ps_t0, ps_t1, ps_t2, ps_fx, ps_fy
 
 // 1 / x: v_rcp_f32 (1 ulp) + one Newton step = 3 instructions, against the ~10 of the IEEE division sequence; the point loop
 // divides twice per point and is instruction-bound when a launch holds few alignments
@@ -464,6 +492,122 @@ __device__ __forceinline__ float point_row6_sampled(const PoseF& ps, const Point
         ct = hw * r * r * (2.0f - hw);
     }
     accumulate_normal<6>(acc, J, r, hw, ct);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------
+// Round 3: the point phase of the pose-only persistent kernel on an instruction diet.  That phase is VALU-issue-bound (two
+// wavefronts per SIMD, one wave64 instruction per 4 clocks), and gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — two
+// fp32 operations per lane — at the same rate as their scalar forms.  So everything below works on PAIRS (ext_vector float2, which
+// the backend keeps in aligned register pairs): two points of a lane through the projection, two patch rows through the row spline,
+// {value, column-derivative} through the column spline, and the 28 running sums as 12 pairs + 4 scalars.  The arithmetic is the
+// same closed form as above, re-associated where that removes instructions (noted at each place); parity tolerances are unchanged.
+// ---------------------------------------------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+// Two independent Catmull-Rom splines at once (element k of every argument belongs to spline k).  With a2 = 2a, b2 = 2b, c2 = 2c of
+// hermite():  f = p1 + (x/2)(c2 + x(b2 + x a2)),  f' = c2/2 + (x/2)(2 b2 + 3x a2);  xh = x/2 and x3 = 3x are passed in because the
+// caller shares them between splines.  14 packed instructions for two values and two derivatives (hermite(): 17 scalar ones each).
+__device__ __forceinline__ void hermite_pair(f2 p0, f2 p1, f2 p2, f2 p3, f2 x, f2 xh, f2 x3, f2& f, f2& df) {
+    const f2 a2 = (p3 - p0) + 3.0f * (p1 - p2);
+    const f2 b2 = 4.0f * p2 + (-5.0f * p1 + (2.0f * p0 - p3));
+    const f2 c2 = p2 - p0;
+    f = p1 + xh * (c2 + x * (b2 + x * a2));
+    df = 0.5f * c2 + xh * (x3 * a2 + (b2 + b2));
+}
+
+// Geometry of two points of one lane that the sampler and the row need: the reference's P = R kp + t, u = fx Px/Pz + cx
+// (PhotometricError.hpp:157-168) in the small-displacement form of project_point — without P itself: the SE(3) row only needs
+// un = Px/Pz, vn = Py/Pz and iz = 1/Pz (row6_accumulate), so the second reciprocal and three products of project_point go.
+struct PairGeom { f2 iz, un, vn, ax, ay; };
+__device__ __forceinline__ void project_pair(float D0, float D1, float D2, float D3, float D4, float D5, float D6, float D7, float D8, float T0, float T1,
+                                             float T2, float fx, float fy, f2 x, f2 y, f2 rhop, f2 f0x, f2 f0y, int cell_a, int cell_b, PairGeom& g,
+                                             int (&r0)[2], int (&c0)[2]) {
+    // (one wave-uniform operand per instruction: VOP3P reads a single SGPR pair, a second scalar would be copied to a VGPR first)
+    const f2 d0 = (D0 * x + (D1 * y + T0 * rhop)) + D2;
+    const f2 d1 = (D3 * x + (D4 * y + T1 * rhop)) + D5;
+    const f2 d2 = (D6 * x + (D7 * y + T2 * rhop)) + D8;
+    const f2 s = 1.0f + d2;                      // Pz rho'
+    f2 is = {__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y)};
+    is = is * (2.0f - s * is);                   // one Newton step (fast_recip)
+    g.un = (x + d0) * is;
+    g.vn = (y + d1) * is;
+    g.iz = rhop * is;
+    const f2 du = fx * (d0 - x * d2) * is;       // u - u0   (column, PhotometricError.hpp:167)
+    const f2 dv = fy * (d1 - y * d2) * is;       // v - v0   (row,    PhotometricError.hpp:168)
+    // split_rel for both: a non-finite or huge coordinate lands 60 000 cells out with phase 0 (Grid2D then clamps: the reference has
+    // no in-bounds test) — the clamp of the COORDINATE gives exactly that (a NaN becomes -60 000: fmax / fmin return the number)
+    const f2 su = __builtin_elementwise_min(__builtin_elementwise_max(f0x + du, (f2)(-60000.0f)), (f2)(60000.0f));
+    const f2 sv = __builtin_elementwise_min(__builtin_elementwise_max(f0y + dv, (f2)(-60000.0f)), (f2)(60000.0f));
+    const f2 flu = __builtin_elementwise_floor(su), flv = __builtin_elementwise_floor(sv);
+    g.ax = su - flu;
+    g.ay = sv - flv;
+    const i2 cu = __builtin_convertvector(flu, i2), cv = __builtin_convertvector(flv, i2);
+    c0[0] = (int)(short)(cell_a & 0xffff) + cu.x; c0[1] = (int)(short)(cell_b & 0xffff) + cu.y;
+    r0[0] = (cell_a >> 16) + cv.x;                r0[1] = (cell_b >> 16) + cv.y;
+}
+
+// The 28 running sums of one lane (upper triangle of J^T J, J^T r, sum r^2) as pairs.  With the row in three pairs
+// P0 = (J0, J1), P1 = (J2, J3), P2 = (J4, J5):  dg[i] = Pi * Pi (two diagonal entries), x01/x02/x12 = Pi * splat(J_k) (the four
+// entries of an off-diagonal 2x2 block in two instructions), o = the entry inside each pair, b[i] = Pi * r: 12 packed + 4 scalar
+// fused multiply-adds per point instead of 28 (+ 6 pre-multiplications).
+struct Acc6 {
+    f2 dg[3], x01[2], x02[2], x12[2], b[3];
+    float o[3], cost;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dg[i] = (f2)(0.0f); b[i] = (f2)(0.0f); o[i] = 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { x01[i] = (f2)(0.0f); x02[i] = (f2)(0.0f); x12[i] = (f2)(0.0f); }
+        cost = 0.0f;
+    }
+    // the EDS_RED_* record order: row-major upper triangle, then J^T r, then the cost
+    __device__ __forceinline__ void unpack(float (&acc)[EDS_RED_K6]) const {
+        acc[0] = dg[0].x;  acc[1] = o[0];      acc[2] = x01[0].x;  acc[3] = x01[1].x;  acc[4] = x02[0].x;  acc[5] = x02[1].x;
+        acc[6] = dg[0].y;  acc[7] = x01[0].y;  acc[8] = x01[1].y;  acc[9] = x02[0].y;  acc[10] = x02[1].y;
+        acc[11] = dg[1].x; acc[12] = o[1];     acc[13] = x12[0].x; acc[14] = x12[1].x;
+        acc[15] = dg[1].y; acc[16] = x12[0].y; acc[17] = x12[1].y;
+        acc[18] = dg[2].x; acc[19] = o[2];     acc[20] = dg[2].y;
+        acc[21] = b[0].x;  acc[22] = b[0].y;   acc[23] = b[1].x;   acc[24] = b[1].y;   acc[25] = b[2].x;   acc[26] = b[2].y;
+        acc[27] = cost;
+#pragma unroll
+        for (int k = EDS_RED_N6; k < EDS_RED_K6; ++k) acc[k] = 0.0f;
+    }
+};
+
+// One point of a pose-only pass from its sampled value and derivatives: residual r = w (mhat - E) and the SE(3) left-perturbation
+// row J = -w [gradE_P, P x gradE_P] (= DSO's row, CoarseTracker.cpp:311-321), written WITHOUT P: with a = -w fx E_col,
+// b = -w fy E_row, t = a un + b vn (un = Px/Pz, vn = Py/Pz, iz = 1/Pz, and Pz iz = 1):
+//     J = [a iz, b iz, -t iz, -(vn t + b), a + un t, un b - vn a]
+// 13 instructions against the 30 of finish_point + jacobian6 + the P of project_point.  HUBER: per-point Huber weight
+// (extension, cf. reference CoarseTracker.cpp:445), a template parameter so that the plain path carries no branch per point.
+template <bool HUBER>
+__device__ __forceinline__ float row6_accumulate(float fx, float fy, float iz, float un, float vn, float E, float Er, float Ec, float w,
+                                                 float mhat, float tau, Acc6& A) {
+    const float nw = -w;
+    const float a = nw * (fx * Ec), b = nw * (fy * Er);
+    const float t = a * un + b * vn;
+    f2 P0 = {a * iz, b * iz};
+    f2 P1 = {-t * iz, -(vn * t) - b};
+    f2 P2 = {a + un * t, un * b - vn * a};
+    const float r = w * (mhat - E);
+    f2 Q0 = P0, Q1 = P1, Q2 = P2;                // the weighted row (hw J); the plain row when HUBER is off
+    float hr = r, ct = r * r;
+    if (HUBER) {
+        const float ar = fabsf(r);
+        const float hw = ar > tau ? tau / ar : 1.0f;
+        Q0 = hw * P0; Q1 = hw * P1; Q2 = hw * P2;
+        hr = hw * r;
+        ct = hw * r * r * (2.0f - hw);
+    }
+    A.dg[0] += Q0 * P0; A.dg[1] += Q1 * P1; A.dg[2] += Q2 * P2;
+    A.o[0] += Q0.x * P0.y; A.o[1] += Q1.x * P1.y; A.o[2] += Q2.x * P2.y;
+    A.x01[0] += Q0 * P1.x; A.x01[1] += Q0 * P1.y;
+    A.x02[0] += Q0 * P2.x; A.x02[1] += Q0 * P2.y;
+    A.x12[0] += Q1 * P2.x; A.x12[1] += Q1 * P2.y;
+    A.b[0] += P0 * hr; A.b[1] += P1 * hr; A.b[2] += P2 * hr;
+    A.cost += ct;
     return r;
 }
 

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     unsigned pass_no = 0;                         // exchanges so far (TEAM > 1)
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
+    __shared__ float s_posef[16];      // fp32 copies for the point phase: [0..11] R - I and t of the pose to evaluate (serial solver), [12..13] fx, fy
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
@@ -104,9 +105,12 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int N = TEAM > 1 ? (Nall - poff < 0 ? 0 : (Nall - poff > PPT * MAXT ? PPT * MAXT : Nall - poff)) : Nall;
     const size_t base = (size_t)slot * A.Np + poff;
     static_assert(TEAM == 1 || PPT > 0, "teams keep their points in registers");
-    const int fslot = (int)gpb[EDS_PB_FRAME];          // the slot whose frame storage is sampled (its own unless shared)
+    const int fslot = __builtin_amdgcn_readfirstlane((int)gpb[EDS_PB_FRAME]);   // the slot whose frame storage is sampled (its own unless shared);
+                                                                               // wave-uniform: the frame address then lives in SGPRs
     const FrameView frame = make_frame_view(A.frame, fslot, A.H, A.W, A.Hp, A.Wp, 1);    // persistent kernels: tiled frames only (eds_fused_solve)
-    const float* __restrict__ tiles = A.frame + (size_t)fslot * A.Hp * A.Wp;             // start of that allocation (quad gather)
+    // start of that allocation (quad gather); fslot is wave-uniform, so this is scalar arithmetic and the address lives in SGPRs
+    // (the product in a 32-bit scalar multiply: 64-bit it became VALU work whose result sat in VGPRs — two v_readfirstlane per load)
+    const float* __restrict__ tiles = A.frame + (size_t)((unsigned)fslot * (unsigned)(A.Hp * A.Wp / 16)) * 16;
     static_assert(!QUAD || (SAMPLING == 0 && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: bicubic, register-resident points, all cached");
 
     if (tid == 0) {
@@ -115,12 +119,17 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         edsm::fill_pose_block(I.p, I.q, I.v, A.G + (size_t)slot * EDS_MAX_BLOCKS * 36, nb, s_pose);
         sv.init(damped != 0, iters, lambda0, I.p, I.q, PPT > 0 ? 1 : 0);   // PPT > 0: residuals of the accepted pose stay in registers
         s_state = sv.final_pass ? 1 : 0;
+        for (int i = 0; i < 9; ++i) s_posef[i] = (float)s_pose[EDS_PB_D + i];
+        for (int i = 0; i < 3; ++i) s_posef[9 + i] = (float)s_pose[EDS_PB_T + i];
+        s_posef[12] = (float)s_pose[EDS_PB_K]; s_posef[13] = (float)s_pose[EDS_PB_K + 1];
         if (spec_mode) {                // candidate 0 of the first pass = the start pose
             edsp::Spec6& c0 = sp.spec[0];
             for (int i = 0; i < 3; ++i) { c0.p[i] = I.p[i]; c0.rt.t[i] = s_pose[EDS_PB_T + i]; }
             for (int i = 0; i < 4; ++i) c0.q[i] = I.q[i];
             for (int i = 0; i < 6; ++i) c0.xi[i] = 0.0;
             for (int i = 0; i < 9; ++i) c0.rt.D[i] = s_pose[EDS_PB_D + i];
+            for (int i = 0; i < 9; ++i) c0.rt.f[i] = (float)c0.rt.D[i];
+            for (int i = 0; i < 3; ++i) c0.rt.f[9 + i] = (float)c0.rt.t[i];
             c0.ok = 1;
             sp.k = 0; sp.mode = edsp::MODE_USE;
             for (int i = 0; i < EDS_RED_N6; ++i) sp.cur[i] = 0.0;
@@ -133,6 +142,11 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     // for the fixed velocity, mhat_i = a_i.v / n_block(i)
     PointKf kf[NREG];
     float kw[NREG], kmh[NREG];
+    // the same constants as PAIRS of points for the packed point phase (quad gather, even PPT): element e of pair g = point 2 g + e
+    constexpr bool PAIRS = QUAD != 0 && PPT > 0 && PPT % 2 == 0;
+    constexpr int NPAIR = PAIRS ? NREG / 2 : 1;
+    f2 k2x[NPAIR], k2y[NPAIR], k2rhop[NPAIR], k2f0x[NPAIR], k2f0y[NPAIR], k2w[NPAIR], k2mh[NPAIR];
+    int kcell[NREG];
     {
         float vf[6];
 #pragma unroll
@@ -159,6 +173,12 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                         kf[jj].f0x = A.f0x[o]; kf[jj].f0y = A.f0y[o]; kf[jj].cell0 = A.cell0[o];
                         kw[jj] = in_range ? A.w[o] : 0.0f;      // w = 0 silences out-of-range lanes
                         kmh[jj] = mh;
+                        if (PAIRS) {
+                            const int g = jj >> 1;
+                            if (jj & 1) { k2x[g].y = x; k2y[g].y = y; k2rhop[g].y = rho + 1e-5f; k2f0x[g].y = kf[jj].f0x; k2f0y[g].y = kf[jj].f0y; k2w[g].y = kw[jj]; k2mh[g].y = mh; }
+                            else { k2x[g].x = x; k2y[g].x = y; k2rhop[g].x = rho + 1e-5f; k2f0x[g].x = kf[jj].f0x; k2f0y[g].x = kf[jj].f0y; k2w[g].x = kw[jj]; k2mh[g].x = mh; }
+                            kcell[jj] = kf[jj].cell0;
+                        }
                     }
                 }
             } else if (in_range) {
@@ -200,7 +220,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         EDS_STAMP(0);
         const int state = s_state;
         PoseF ps;
-        if (spec_mode) load_pose_rt(sp.spec[sp.k].rt.D, sp.spec[sp.k].rt.t, s_pose, ps);
+        if (PAIRS) { }
+        else if (spec_mode) load_pose_rt(sp.spec[sp.k].rt.D, sp.spec[sp.k].rt.t, s_pose, ps);
         else load_pose(s_pose, ps);
         float acc[EDS_RED_K6];
 #pragma unroll
@@ -211,7 +232,77 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             if (PPT == 0 && state == 1 && i < N) A.r[base + i] = r;      // streaming variant: residuals stored by a final pass
             return r;
         };
-        if (QUAD) {
+        if constexpr (QUAD != 0 && PPT > 0 && PPT % 2 == 0) {
+            // ---- round 3: the quad-cooperative gather on pairs (eds_device.hpp, "instruction diet") --------------------------------
+            // phase A: the lane's points go through the projection two at a time (packed fp32); every point probes the cache and
+            // its packed origin goes round the quad: a MISSING patch has lane j put row j in flight from HBM, a CACHED one has lane j
+            // read its row of the cache into the SAME registers (origin 0: shift amount 0, so phase B's barrel shift passes it through
+            // unchanged — no select between "gathered" and "cached" any more)
+            const int jr = lane & 3;
+            float* __restrict__ cache = &s_patch[0][0] + 16 * (tid & ~3) + 4 * jr;
+            const int swz = (tid >> 2) & 3;
+            const int cq0 = 16 * (0 ^ swz), cq1 = 16 * (1 ^ swz), cq2 = 16 * (2 ^ swz), cq3 = 16 * (3 ^ swz);
+            const int cq[4] = {cq0, cq1, cq2, cq3};
+            const float* __restrict__ rtf = spec_mode ? sp.spec[sp.k].rt.f : s_posef;
+            EDS_LOAD_POSE_SCALARS(rtf, s_posef + 12);
+            PairGeom pg[NPAIR];
+            int org[NREG];
+            float4 ra[NREG][4], rb[NREG][4];
+#pragma unroll
+            for (int g = 0; g < NPAIR; ++g) {
+                int r0[2], c0[2];
+                project_pair(EDS_POSE_SCALARS, k2x[g], k2y[g], k2rhop[g], k2f0x[g], k2f0y[g], kcell[2 * g], kcell[2 * g + 1], pg[g], r0, c0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * g + e, i = tid + j * nthr;
+                    const int key = (r0[e] << 16) ^ (c0[e] & 0xffff);
+                    const bool miss = s_cell[i] != key;
+                    if (miss) s_cell[i] = key;
+                    org[j] = pack_origin(frame, r0[e], c0[e]) | (miss ? (int)0x80000000 : 0);
+                    const int o0 = quad_bcast_i<0>(org[j]), o1 = quad_bcast_i<1>(org[j]), o2 = quad_bcast_i<2>(org[j]), o3 = quad_bcast_i<3>(org[j]);
+                    const int oq[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ra[j][q] = dont_care4(); rb[j][q] = dont_care4();
+                        if (oq[q] < 0) load_patch_row(tiles, frame.TW, oq[q] & 0x7fffffff, jr, ra[j][q], rb[j][q]);
+                    }
+                }
+            }
+            // phase B (branch-free): barrel shift, the row back to the cache, the row splines of two patches per packed instruction,
+            // the transposes, the column spline of {value, column derivative} as one pair, the row and its 28 products
+            Acc6 A6;
+            A6.clear();
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int g = j >> 1;
+                const float ax_j = (j & 1) ? pg[g].ax.y : pg[g].ax.x, ay_j = (j & 1) ? pg[g].ay.y : pg[g].ay.x;
+                const int o0 = quad_bcast_i<0>(org[j]), o1 = quad_bcast_i<1>(org[j]), o2 = quad_bcast_i<2>(org[j]), o3 = quad_bcast_i<3>(org[j]);
+                const int oq[4] = {o0, o1, o2, o3};
+                const f2 x01 = {quad_bcast_f<0>(ax_j), quad_bcast_f<1>(ax_j)}, x23 = {quad_bcast_f<2>(ax_j), quad_bcast_f<3>(ax_j)};
+                float t[4][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 c = *reinterpret_cast<const float4*>(cache + cq[q] + 16 * j * nthr);
+                    shift_patch_row3(ra[j][q], rb[j][q], oq[q], t[q]);
+                    const bool m = oq[q] < 0;                    // gathered this pass
+                    t[q][0] = flag_select(m, t[q][0], c.x); t[q][1] = flag_select(m, t[q][1], c.y); t[q][2] = flag_select(m, t[q][2], c.z); t[q][3] = flag_select(m, t[q][3], c.w);
+                    *reinterpret_cast<float4*>(cache + cq[q] + 16 * j * nthr) = make_float4(t[q][0], t[q][1], t[q][2], t[q][3]);
+                }
+                f2 f01, d01, f23, d23;
+                hermite_pair((f2){t[0][0], t[1][0]}, (f2){t[0][1], t[1][1]}, (f2){t[0][2], t[1][2]}, (f2){t[0][3], t[1][3]}, x01, 0.5f * x01, 3.0f * x01, f01, d01);
+                hermite_pair((f2){t[2][0], t[3][0]}, (f2){t[2][1], t[3][1]}, (f2){t[2][2], t[3][2]}, (f2){t[2][3], t[3][3]}, x23, 0.5f * x23, 3.0f * x23, f23, d23);
+                float f[4] = {f01.x, f01.y, f23.x, f23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
+                quad_transpose(f, lane);
+                quad_transpose(d, lane);
+                f2 EEc, dE;
+                const f2 y2 = (f2)(ay_j);
+                hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
+                const float iz_j = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_j = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_j = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
+                const float w_j = (j & 1) ? k2w[g].y : k2w[g].x, mh_j = (j & 1) ? k2mh[g].y : k2mh[g].x;
+                rcand[j] = row6_accumulate<(QUAD == 2)>(ps_fx, ps_fy, iz_j, un_j, vn_j, EEc.x, dE.x, EEc.y, w_j, mh_j, tau, A6);
+            }
+            A6.unpack(acc);
+        } else if (QUAD) {
             // phase A: every lane projects its own points and probes the cache; the packed origins go round the quad and every
             // lane puts its ROW of each missing patch in flight
             const int jr = lane & 3;
@@ -495,6 +586,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 s_state = 2;
             } else {
                 edsm::fill_pose_rt(sv.cp, sv.cq, s_pose);
+                for (int i = 0; i < 9; ++i) s_posef[i] = (float)s_pose[EDS_PB_D + i];
+                for (int i = 0; i < 3; ++i) s_posef[9 + i] = (float)s_pose[EDS_PB_T + i];
                 s_state = sv.final_pass ? 1 : 0;
             }
         }
@@ -720,17 +813,21 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         }
         const unsigned ticket_base = fb.ticket_base;
         fb.ticket_base += (unsigned)(count * team);
+        // (QUAD = 2: the pair-packed point phase with the per-point Huber weight compiled in; points in pairs need an even PPT)
+#define EDS_TEAM_Q2(K) do { if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K); else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); \
+                            else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
         if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
             if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_BILINEAR(1, 4);
         } else if (team == 2) {                      // 1 024 points per member, two per lane
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 2); else EDS_LAUNCH_TEAM(0, 2, 0, 2); } else EDS_LAUNCH_BILINEAR(2, 2);
+            EDS_TEAM_Q2(2);
         } else if (team == 4) {                      // 1 024 points per member from here on
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 4); else EDS_LAUNCH_TEAM(0, 2, 0, 4); } else EDS_LAUNCH_BILINEAR(2, 4);
+            EDS_TEAM_Q2(4);
         } else if (team == 8) {
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 8); else EDS_LAUNCH_TEAM(0, 2, 0, 8); } else EDS_LAUNCH_BILINEAR(2, 8);
+            EDS_TEAM_Q2(8);
         } else {
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 2, 1, 16); else EDS_LAUNCH_TEAM(0, 2, 0, 16); } else EDS_LAUNCH_BILINEAR(2, 16);
+            EDS_TEAM_Q2(16);
         }
+#undef EDS_TEAM_Q2
         }
     } else if (stream) {
         eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
@@ -744,10 +841,11 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     bool quad = count >= 32;
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
     quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP && h->H < 8000;     // every point's patch has a cache line of its own; 13-bit row field (pack_origin)
+    const bool hub = tau > 0;                        // QUAD = 2: the per-point Huber weight compiled into the pair-packed point phase
     switch (ppt) {
         case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_BILINEAR(1, 1); break;
-        case 2: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_BILINEAR(2, 1); break;
-        case 4: if (bicubic) { if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_BILINEAR(4, 1); break;
+        case 2: if (bicubic) { if (quad && hub) EDS_LAUNCH_FUSED_T(0, 2, 2); else if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_BILINEAR(2, 1); break;
+        case 4: if (bicubic) { if (quad && hub) EDS_LAUNCH_FUSED(0, 4, 512, 2); else if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_BILINEAR(4, 1); break;
         default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0, 0); else EDS_LAUNCH_BILINEAR(0, 1); break;
     }
     }

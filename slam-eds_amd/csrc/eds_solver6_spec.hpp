@@ -24,7 +24,8 @@ namespace edsp {
 
 struct PoseRT {                 // the part of a pose block that changes from pass to pass (eds_layout.hpp EDS_PB_R / _D / _T)
     double D[9], t[3];
-};
+    float f[12];                // the same twelve numbers narrowed once by the lane that made them: every wavefront of every pass reads
+};                              // these (ds_read + v_readfirstlane) instead of converting twelve doubles itself
 struct Spec6 {                  // one prepared candidate
     double p[3], q[4], xi[6];
     PoseRT rt;
@@ -73,6 +74,10 @@ __device__ __noinline__ void propose(const double* __restrict__ cur, double lamb
 #pragma unroll
     for (int i = 0; i < 4; ++i) out.q[i] = tq[i];
     edsm::quat_to_RmI(tq, out.rt.D);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out.rt.f[i] = (float)out.rt.D[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out.rt.f[9 + i] = (float)tp[i];
     out.ok = ok ? 1 : 0;
 }
 
