@@ -102,7 +102,8 @@ typedef struct eds_trk_info {
     int32_t  num_iterations;        /* successful + unsuccessful steps (Tracker.cpp:211) */
     double   time_seconds;          /* solver-reported time (Tracker.cpp:212) */
     uint8_t  success;               /* IsSolutionUsable (Tracker.cpp:213) */
-    uint8_t  pad_[3];
+    uint8_t  flags;                 /* EDS_INFO_* bits below (diagnostics; 0 in the normal case) */
+    uint8_t  pad_[2];
     int32_t  termination;           /* 0 convergence, 1 no convergence (max iterations), 2 failure */
     int32_t  num_successful_steps;
     int32_t  num_unsuccessful_steps;
@@ -111,6 +112,11 @@ typedef struct eds_trk_info {
     double   device_time_us;        /* GPU time of the solve: between two stream events around the launch; for launches of up to 64
                                      * alignments, from the kernel's own 100 MHz time stamps (first workgroup in .. result out) */
 } eds_trk_info;
+
+#define EDS_INFO_TEAM_TIMEOUT 1      /* this solve was launched on several CUs per alignment, a team did not assemble within 50 ms (something
+                                     * else held the GPU), and the range was solved again with one CU per alignment: the result is valid, the
+                                     * call took >= 50 ms, and the handle forms no teams for its next launches (it re-arms by itself) */
+#define EDS_INFO_TEAMS_PAUSED 2     /* solved with one CU per alignment because an earlier time-out's cool-down is still running */
 
 typedef struct eds_trk eds_trk;     /* opaque */
 

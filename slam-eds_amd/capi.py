@@ -70,13 +70,17 @@ class Cfg(C.Structure):
 class Info(C.Structure):
     """``eds_trk_info`` — mirrors eds::tracking::TrackerInfo (reference tracking/Config.hpp:60-68)."""
     _fields_ = [("meas_time_us", C.c_double), ("num_points", C.c_uint32), ("num_iterations", C.c_int32),
-                ("time_seconds", C.c_double), ("success", C.c_uint8), ("pad_", C.c_uint8 * 3),
+                ("time_seconds", C.c_double), ("success", C.c_uint8), ("flags", C.c_uint8), ("pad_", C.c_uint8 * 2),
                 ("termination", C.c_int32), ("num_successful_steps", C.c_int32),
                 ("num_unsuccessful_steps", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
                 ("device_time_us", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
+INFO_TEAM_TIMEOUT, INFO_TEAMS_PAUSED = 1, 2       # eds_trk_info.flags (include/eds_hip.h)
+TEAM_COOLDOWN = 16                                # EDS_TEAM_COOLDOWN (csrc/eds_fused.hpp): solves without teams after a time-out
 
 
 class EdsError(RuntimeError):

@@ -77,6 +77,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     if (TEAM > 1) {
         if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
+        // a ticket outside this launch's stretch means host and device counters disagree (a launch that failed half-way): leave —
+        // the host pre-marks every slot of a team launch as timed out, so the range is solved again and the counter reset
+        if ((unsigned)s_ticket >= gridDim.x) return;
         team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
     }
     const int slot = first + team_slot;
@@ -690,6 +693,25 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     return 0;
 }
 
+bool eds_team_allowed(EdsFusedBuffers* fb) {
+    if (fb->team_cooldown <= 0) return true;
+    if (--fb->team_cooldown == 0) fb->team_clean = 0;      // re-armed: the next eligible solve forms teams again
+    return false;
+}
+void eds_team_timed_out(eds_trk* h) {
+    EdsFusedBuffers& fb = h->fused;
+    // a time-out soon after a re-arm doubles the pause; after EDS_TEAM_REARM_CLEAN clean team launches it counts as a first one
+    const int next = fb.team_backoff > 0 ? std::min(2 * fb.team_backoff, EDS_TEAM_COOLDOWN_MAX) : EDS_TEAM_COOLDOWN;
+    fb.team_cooldown = fb.team_backoff = next;
+    fb.team_clean = 0;
+    // workgroups of the short launch may have taken tickets the host never accounted for (or the reverse): start over
+    hipMemsetAsync(fb.d_ticket, 0, sizeof(int), h->st);
+    fb.ticket_base = 0;
+}
+void eds_team_clean(EdsFusedBuffers* fb) {
+    if (fb->team_backoff > 0 && ++fb->team_clean >= EDS_TEAM_REARM_CLEAN) { fb->team_backoff = 0; fb->team_clean = 0; }
+}
+
 void eds_fused_free(EdsFusedBuffers* fb) {
     if (fb->d_sv) hipFree(fb->d_sv);
     if (fb->h_in) hipHostFree(fb->h_in);
@@ -781,9 +803,14 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
     const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;
     unsigned ticket_base = 0;          // (team launches shadow it with their own stretch of tickets)
-    const bool team_ok = damped == 1 && iters > 0 && !fb.team_disabled && maxN > 512;
+    // (513 .. 1 024 points: a member's slice is PPT x 512 = 1 024 points, a team of two would leave its second member without a
+    // point — one CU per alignment there, as in round 1)
+    const bool team_eligible = damped == 1 && iters > 0 && maxN > 1024 && !fb.pending_retry;
+    const bool wants_team = team_eligible && (maxN > 2048 ? maxN <= 1024 * EDS_TEAM6_MAX : count <= EDS_TEAM_SLOTS);
+    const bool team_ok = wants_team && eds_team_allowed(&fb);
+    fb.pending_paused = wants_team && !team_ok && !fb.pending_retry;
     if (team_ok && maxN <= 2048) {
-        if (count <= 64 && maxN > 1024) team = 4;
+        if (count <= 64) team = 4;
         else if (count <= EDS_TEAM_SLOTS) team = 2;
     } else if (team_ok && maxN <= 1024 * EDS_TEAM6_MAX) {
         // at ANY batch size: the alternative is the streaming kernel (lane-per-patch gather, constants re-read, a quarter of the
@@ -792,7 +819,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
     if (const char* ev = getenv("EDS_LM6_TEAM")) {                    // tuning knob: 1 | 2 | 4 | 8 | 16
         const int v = atoi(ev);
-        const bool feasible = damped == 1 && iters > 0 && (v == 2 || v == 4 || v == 8 || v == 16) && maxN <= (v == 2 ? 2048 : 1024 * v);
+        const bool feasible = damped == 1 && iters > 0 && (v == 2 || v == 4 || v == 8 || v == 16) && maxN <= (v == 2 ? 2048 : 1024 * v) &&
+                              !fb.pending_retry && fb.team_cooldown <= 0;          // the override does not reach past the time-out policy
         if (v == 1 || feasible) team = v;
     }
     if (team > 1) { stream = false; wide = false; }
@@ -813,6 +841,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         }
         const unsigned ticket_base = fb.ticket_base;
         fb.ticket_base += (unsigned)(count * team);
+        for (int s = first; s < first + count; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
         // (QUAD = 2: the pair-packed point phase with the per-point Huber weight compiled in; points in pairs need an even PPT)
 #define EDS_TEAM_Q2(K) do { if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K); else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); \
                             else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
@@ -894,16 +923,18 @@ int eds_fused_collect(eds_trk* h) {
     if (fb.pending_team > 1) {                        // a team whose members did not all become resident within the bound
         bool timed_out = false;
         for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) timed_out |= fb.h_out[s].failed == 2;
-        if (timed_out) {                             // never again on this handle; solve the range once more, one CU per alignment
-            fb.team_disabled = true;
+        if (timed_out) {                             // solve the range once more, one CU per alignment; teams pause on this handle (eds_fused.hpp)
+            eds_team_timed_out(h);
             const int pf = fb.pending_first, pc = fb.pending_count;
             fb.pending_count = 0;
+            fb.pending_retry = true;
             int rc = eds_fused_solve(h, fb.pending_level, pf, pc);
-            if (rc != EDS_OK) return rc;
+            if (rc != EDS_OK) { fb.pending_retry = false; return rc; }
             hipError_t e = hipStreamSynchronize(h->st);
-            if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+            if (e != hipSuccess) { fb.pending_retry = false; return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e)); }
             return eds_fused_collect(h);
         }
+        eds_team_clean(&fb);
     }
     for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) {
         Slot& sl = h->slots[s];
@@ -922,6 +953,7 @@ int eds_fused_collect(eds_trk* h) {
         in.num_points = sl.N;
         in.num_iterations = O.iterations;
         in.success = ok;
+        in.flags = (fb.pending_retry ? EDS_INFO_TEAM_TIMEOUT : 0) | (fb.pending_paused ? EDS_INFO_TEAMS_PAUSED : 0);
         in.termination = ok ? edss::TERM_NO_CONVERGENCE : edss::TERM_FAILURE;
         in.num_successful_steps = O.naccepted;
         in.num_unsuccessful_steps = O.ntrace - O.naccepted;
@@ -939,6 +971,7 @@ int eds_fused_collect(eds_trk* h) {
     }
 #endif
     fb.pending_count = 0;
+    fb.pending_retry = false; fb.pending_paused = false;
     return EDS_OK;
 }
 

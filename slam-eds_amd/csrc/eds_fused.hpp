@@ -33,6 +33,9 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 // ---- teams: several workgroups (CUs) per alignment, partial sums exchanged as tagged 8-byte granules (eds_fused.hip) -----------
 #define EDS_TEAM_GRANULES 64                      // LM6, per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
 #define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
+#define EDS_TEAM_COOLDOWN 16                      // solves without teams after a time-out (doubling up to EDS_TEAM_COOLDOWN_MAX while they recur)
+#define EDS_TEAM_COOLDOWN_MAX 1024
+#define EDS_TEAM_REARM_CLEAN 64                   // clean team launches after which a new time-out counts as a first one again
 #define EDS_TEAM6_MAX 16                          // LM6: up to 16 CUs per alignment (16 384 points)
 #define EDS_TEAM_SLOTS 128                        // up to 2 048 points: teams of two up to this many alignments per launch
 #define EDS_TEAM_MEMBERS 4096                     // workgroups (alignments x team size) one team LAUNCH holds: the mailboxes' capacity; larger ranges go out in several launches
@@ -56,7 +59,15 @@ struct EdsFusedBuffers {
     int* d_ticket = nullptr;                // team launches: workgroup arrival counter (team = ticket / K, member = ticket % K)
     unsigned epoch = 0;                     // launch sequence number inside the granule tags
     unsigned ticket_base = 0;               // tickets handed out by earlier team launches (the device counter is never reset)
-    bool team_disabled = false;             // a team once timed out on this handle
+    // Time-out policy of the team launches: a time-out (eds_fused_collect / eds_fused12_collect) re-runs the range with one CU per
+    // alignment and PAUSES teams for `team_cooldown` further solves of this handle — 16 after the first time-out, doubled by every
+    // time-out that follows a re-arm without EDS_TEAM_REARM_CLEAN clean team launches in between (up to 1 024), back to 16 after that
+    // many.  One stall caused by something else on the GPU therefore costs the latency regime a few calls, not the handle's lifetime.
+    int team_cooldown = 0;                  // solves left without teams
+    int team_backoff = 0;                   // the cool-down the next time-out will impose (0: the default)
+    int team_clean = 0;                     // clean team launches since the last re-arm
+    bool pending_retry = false;             // the launch in flight is the one-CU re-run of a timed-out team launch
+    bool pending_paused = false;            // the launch in flight would have used teams but for the cool-down
     int pending_team = 1, pending_level = 0;
     bool pending_ticks = false;    // device time from the kernels' own time stamps (no event records around the launch)
     bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (eds_mirror_residuals)
@@ -66,6 +77,10 @@ struct EdsFusedBuffers {
 };
 
 int  eds_fused_alloc(EdsFusedBuffers* fb, int B);
+// time-out policy (eds_fused.hip): may this solve form teams?  (counts the cool-down down); a team launch timed out / ended clean
+bool eds_team_allowed(EdsFusedBuffers* fb);
+void eds_team_timed_out(eds_trk* h);
+void eds_team_clean(EdsFusedBuffers* fb);
 void eds_fused_free(EdsFusedBuffers* fb);
 int  eds_fused_solve(eds_trk* h, int level, int first, int count);   // asynchronous on h->st
 int  eds_fused_collect(eds_trk* h);                                  // after the stream is idle

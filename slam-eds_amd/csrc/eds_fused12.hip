@@ -60,6 +60,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     if (TEAM > 1) {
         if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
+        if ((unsigned)s_ticket >= gridDim.x) return;      // counters out of step: see eds_fused6_kernel
         team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
     }
     const int slot = first + team_slot;
@@ -522,7 +523,10 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     int maxN = 0;
     for (int s = first; s < first + count; ++s) maxN = std::max(maxN, h->slots[s].N);
     int team = 1;
-    if (wide && !h->cfg.nc && !fb.team_disabled && maxN > 512 && count <= EDS_TEAM12_SLOTS) {
+    const bool wants_team = wide && !h->cfg.nc && maxN > 512 && count <= EDS_TEAM12_SLOTS && !fb.pending_retry;
+    const bool team_ok = wants_team && eds_team_allowed(&fb);         // the time-out policy of eds_fused.hpp
+    fb.pending_paused = wants_team && !team_ok;
+    if (team_ok) {
         team = (count <= 64 && maxN > 1024) ? 4 : 2;
         if (count <= 16 && maxN > 1024) team = 8;                                   // a handful of alignments: 8 CUs each (2 000 points: 152 vs 159 us; equal from 32 alignments on)
         if (maxN > 8192 && count * 16 <= EDS_TEAM12_MEMBERS) team = 16;          // the finer pyramid levels (configs[2..3]): ~1 000 points per CU
@@ -530,7 +534,8 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     }
     if (const char* ev = getenv("EDS_REF12_TEAM")) {                  // tuning knob: 1 | 2 | 4 | 8 | 16
         const int v = atoi(ev);
-        if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS && count * v <= EDS_TEAM12_MEMBERS)) team = v;
+        if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS && count * v <= EDS_TEAM12_MEMBERS &&
+                       !fb.pending_retry && fb.team_cooldown <= 0)) team = v;
     }
     if (team > 1) {
         if (!fb.d_mail12) {
@@ -547,7 +552,10 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     }
     fb.pending_team = team; fb.pending_level = level;
     const unsigned ticket_base = fb.ticket_base;
-    if (team > 1) fb.ticket_base += (unsigned)(count * team);
+    if (team > 1) {
+        fb.ticket_base += (unsigned)(count * team);
+        for (int s = first; s < first + count; ++s) fb.h_out12[s].failed = 2;    // "no result yet" reads as a time-out (eds_fused_solve)
+    }
     const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;     // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
@@ -585,15 +593,17 @@ int eds_fused12_collect(eds_trk* h) {
         bool timed_out = false;
         for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) timed_out |= fb.h_out12[s].failed == 2;
         if (timed_out) {
-            fb.team_disabled = true;
+            eds_team_timed_out(h);
             const int pf = fb.pending_first, pc = fb.pending_count;
             fb.pending_count = 0;
+            fb.pending_retry = true;
             int rc = eds_fused12_solve(h, fb.pending_level, pf, pc);
-            if (rc != EDS_OK) return rc;
+            if (rc != EDS_OK) { fb.pending_retry = false; return rc; }
             hipError_t e = hipStreamSynchronize(h->st);
-            if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+            if (e != hipSuccess) { fb.pending_retry = false; return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e)); }
             return eds_fused12_collect(h);
         }
+        eds_team_clean(&fb);
     }
     const double now = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     float dev_ms = 0.f;
@@ -623,11 +633,13 @@ int eds_fused12_collect(eds_trk* h) {
         in.num_unsuccessful_steps = O.num_unsuccessful;
         in.num_iterations = O.num_successful + O.num_unsuccessful;       // Tracker.cpp:211
         in.success = ok;
+        in.flags = (fb.pending_retry ? EDS_INFO_TEAM_TIMEOUT : 0) | (fb.pending_paused ? EDS_INFO_TEAMS_PAUSED : 0);
         in.termination = O.termination;
         in.initial_cost = O.initial_cost;
         in.final_cost = O.final_cost;
     }
     fb.pending_count = 0;
     fb.pending_kind = 0;
+    fb.pending_retry = false; fb.pending_paused = false;
     return EDS_OK;
 }
