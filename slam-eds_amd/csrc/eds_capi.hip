@@ -320,6 +320,7 @@ void free_all(eds_trk* h) {
                      h->dmhat, h->dframe, h->dr, h->dJ};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
+    eds_strips_free(h);
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
     eds_keyframe_free(&h->kf_build);
@@ -369,6 +370,7 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
     EDS_HIP_TRY(hipEventRecord(h->ev_stage, h->st));
     h->stage_busy = true;
     h->slots[slot].has_frame = true;
+    ++h->slots[slot].frame_version;             // its strip copy (eds_strips.hip) is out of date
     return EDS_OK;
 }
 

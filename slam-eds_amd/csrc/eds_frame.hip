@@ -401,6 +401,7 @@ int eds_frame_build_levels(eds_trk* h, int first_slot, int level0, int nlevels, 
     for (int i = 0; i < nlevels; ++i) {
         if (norms_out) norms_out[i] = std::sqrt(fb.h_norm_out[i]);     // the accumulators added up in k_store_levels' order
         h->slots[first_slot + i].has_frame = true;
+        ++h->slots[first_slot + i].frame_version;
     }
     return EDS_OK;
 }
@@ -513,6 +514,7 @@ int eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* offs
         for (int b = 0; b < gn; ++b) {
             if (norms_out) norms_out[g0 + b] = std::sqrt(h_tot[b]);
             h->slots[first_slot + g0 + b].has_frame = true;
+            ++h->slots[first_slot + g0 + b].frame_version;
         }
         g0 = g1;
     }

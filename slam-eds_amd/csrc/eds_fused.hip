@@ -235,7 +235,77 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             if (PPT == 0 && state == 1 && i < N) A.r[base + i] = r;      // streaming variant: residuals stored by a final pass
             return r;
         };
-        if constexpr (QUAD != 0 && PPT > 0 && PPT % 2 == 0) {
+        if constexpr (QUAD >= 3) {
+            // ---- round 3, second step: the gather on STRIPS, landing in LDS (eds_layout.hpp; tools/ubench_gather_lds.hip) -------------
+            // Every patch row is ONE 16-byte read at a 4-byte-aligned address, issued as global_load_lds_dwordx4: lane L's 16 bytes go
+            // straight to  zone[wave][4 j + q][L]  in LDS — no VGPRs while in flight, no barrel shift, and the landing zone IS the patch
+            // cache: a point whose cell did not change simply does not issue its loads (its rows of the previous pass are still there).
+            // The owner of a point computes the byte offset of its patch's first row once; it goes round the quad by DPP with the
+            // "gather it" flag in bit 31, and lane j adds j rows (and clears the flag) with one add.
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            typedef const __attribute__((address_space(1))) void* glb_ptr;
+            const int jr = lane & 3;
+            const float* __restrict__ rtf = spec_mode ? sp.spec[sp.k].rt.f : s_posef;
+            EDS_LOAD_POSE_SCALARS(rtf, s_posef + 12);
+            PairGeom pg[NPAIR];
+            const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+            float* __restrict__ zone = &s_patch[0][0] + wave_u * (NREG * 4 * 256);
+            const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
+            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * (2u * (size_t)copy_bytes);
+            const unsigned row_add = 0x80000000u + 32u * (unsigned)jr;
+#pragma unroll
+            for (int g = 0; g < NPAIR; ++g) {
+                int r0[2], c0[2];
+                project_pair(EDS_POSE_SCALARS, k2x[g], k2y[g], k2rhop[g], k2f0x[g], k2f0y[g], kcell[2 * g], kcell[2 * g + 1], pg[g], r0, c0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * g + e, i = tid + j * nthr;
+                    const int key = (r0[e] << 16) ^ (c0[e] & 0xffff);
+                    const bool miss = s_cell[i] != key;
+                    if (miss) s_cell[i] = key;
+                    const int ra = clampi(r0[e], -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca = clampi(c0[e], -2, frame.W) + (EDS_FRAME_MARGIN - 1);
+                    const int off = (int)(eds_strips_row_offset(ra, ca, A.Hp, copy_bytes) | (miss ? 0x80000000u : 0u));
+                    const int o0 = quad_bcast_i<0>(off), o1 = quad_bcast_i<1>(off), o2 = quad_bcast_i<2>(off), o3 = quad_bcast_i<3>(off);
+                    const int oq[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (oq[q] < 0)
+                            __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * 256), 16, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every row has landed (each lane reads back only what it fetched itself)
+            asm volatile("" ::: "memory");
+            // phase B: the rows of two patches per packed instruction straight out of LDS (ds_read2st64_b32 pairs {q, q + 1}), the
+            // transposes, the column spline of {value, column derivative}, the row and its 28 products
+            Acc6 A6;
+            A6.clear();
+            const float* __restrict__ mine = zone + 4 * lane;
+#pragma unroll
+            for (int j = 0; j < NREG; ++j) {
+                const int g = j >> 1;
+                const float ax_j = (j & 1) ? pg[g].ax.y : pg[g].ax.x, ay_j = (j & 1) ? pg[g].ay.y : pg[g].ay.x;
+                const f2 x01 = {quad_bcast_f<0>(ax_j), quad_bcast_f<1>(ax_j)}, x23 = {quad_bcast_f<2>(ax_j), quad_bcast_f<3>(ax_j)};
+                f2 ta[4], tb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ta[k] = (f2){mine[(4 * j + 0) * 256 + k], mine[(4 * j + 1) * 256 + k]};
+                    tb[k] = (f2){mine[(4 * j + 2) * 256 + k], mine[(4 * j + 3) * 256 + k]};
+                }
+                f2 f01, d01, f23, d23;
+                hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
+                hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
+                float f[4] = {f01.x, f01.y, f23.x, f23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
+                quad_transpose(f, lane);
+                quad_transpose(d, lane);
+                f2 EEc, dE;
+                const f2 y2 = (f2)(ay_j);
+                hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
+                const float iz_j = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_j = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_j = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
+                const float w_j = (j & 1) ? k2w[g].y : k2w[g].x, mh_j = (j & 1) ? k2mh[g].y : k2mh[g].x;
+                rcand[j] = row6_accumulate<(QUAD == 4)>(ps_fx, ps_fy, iz_j, un_j, vn_j, EEc.x, dE.x, EEc.y, w_j, mh_j, tau, A6);
+            }
+            A6.unpack(acc);
+        } else if constexpr (QUAD != 0 && PPT > 0 && PPT % 2 == 0) {
             // ---- round 3: the quad-cooperative gather on pairs (eds_device.hpp, "instruction diet") --------------------------------
             // phase A: the lane's points go through the projection two at a time (packed fp32); every point probes the cache and
             // its packed origin goes round the quad: a MISSING patch has lane j put row j in flight from HBM, a CACHED one has lane j
@@ -751,7 +821,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
     hipError_t e = hipSuccess;
-    const EdsArrays A = h->arrays();
+    EdsArrays A = h->arrays();
     // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
     // the points-per-lane variant is picked from the largest N of the range
     // 8 wavefronts x 4 points per lane measured 12% faster than 16 x 2 at N = 2000 (fewer wavefronts to
@@ -799,6 +869,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
     // (16 000 points: 0.52 ms on one CU).
     int team = 1;
+    bool want_strips = true;
+    if (const char* ev = getenv("EDS_FUSED_LAYOUT")) want_strips = std::strcmp(ev, "tiles") != 0;          // tuning knob: "strips" | "tiles"
     // test hook for the time-out path: a team launch goes out one workgroup short, so its last team never completes, reports a time-out
     // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
     const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;
@@ -830,6 +902,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
         const bool q = bic && count * team >= 128 && h->H < 8000;   // enough gathers in flight for the quad-cooperative form to pay
+        // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member)
+        const bool strips = q && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_prepare(h, first, count);
+        A.strips = h->dstrips;
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
         const int per_launch = EDS_TEAM_MEMBERS / team, whole_first = first, whole_count = count;
@@ -843,8 +918,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         fb.ticket_base += (unsigned)(count * team);
         for (int s = first; s < first + count; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
         // (QUAD = 2: the pair-packed point phase with the per-point Huber weight compiled in; points in pairs need an even PPT)
-#define EDS_TEAM_Q2(K) do { if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K); else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); \
-                            else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
+#define EDS_TEAM_Q2(K) do { if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K);                           \
+                            else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 4, K); else EDS_LAUNCH_TEAM(0, 2, 3, K); }                 \
+                            else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
         if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
             if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_BILINEAR(1, 4);
         } else if (team == 2) {                      // 1 024 points per member, two per lane
@@ -870,7 +946,15 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     bool quad = count >= 32;
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
     quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP && h->H < 8000;     // every point's patch has a cache line of its own; 13-bit row field (pack_origin)
-    const bool hub = tau > 0;                        // QUAD = 2: the per-point Huber weight compiled into the pair-packed point phase
+    const bool hub = tau > 0;                        // QUAD = 2 / 4: the per-point Huber weight compiled into the pair-packed point phase
+    // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
+    // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
+    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);
+    A.strips = h->dstrips;
+    if (strips) {
+        if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }
+        else { if (hub) EDS_LAUNCH_FUSED(0, 4, 512, 4); else EDS_LAUNCH_FUSED(0, 4, 512, 3); }
+    } else
     switch (ppt) {
         case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_BILINEAR(1, 1); break;
         case 2: if (bicubic) { if (quad && hub) EDS_LAUNCH_FUSED_T(0, 2, 2); else if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_BILINEAR(2, 1); break;

@@ -86,6 +86,11 @@ int  eds_fused_solve(eds_trk* h, int level, int first, int count);   // asynchro
 int  eds_fused_collect(eds_trk* h);                                  // after the stream is idle
 int  eds_fused_fetch_trace(eds_trk* h, int slot);                    // D2H of one slot's trace
 
+// eds_strips.hip: makes the strip copies of the frames the slots [first, first + count) sample current (allocates them at the first call;
+// one conversion launch per run of stale slots, on h->st).  false: no memory for them — the caller uses the tiles.
+bool eds_strips_prepare(eds_trk* h, int first, int count);
+void eds_strips_free(eds_trk* h);
+
 bool eds_fused12_supported(const eds_trk* h, int first, int count);
 int  eds_fused12_solve(eds_trk* h, int level, int first, int count);
 int  eds_fused12_collect(eds_trk* h);

@@ -14,6 +14,8 @@ struct Slot {
     int N = 0;
     bool has_kf = false, has_frame = false;
     int frame_slot = -1;            // >= 0: this alignment samples THAT slot's frame storage (eds_trk_share_event_frame); -1: its own
+    unsigned frame_version = 0;     // bumped by everything that writes this slot's frame storage ...
+    unsigned strips_version = 0;    // ... and the version its strip copy (eds_layout.hpp) was made from; 0 = never
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[6];
     double K[4] = {0, 0, 0, 0};
     eds_trk_info info;
@@ -40,6 +42,7 @@ struct eds_trk {
     float *df0x = nullptr, *df0y = nullptr;
     int* dcell0 = nullptr;
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
+    float* dstrips = nullptr;           // strip layout of the frames, allocated by the first solve that uses it (eds_strips.hip)
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
     EdsPointBuffers point_ops;
@@ -63,7 +66,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.strips = dstrips; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

@@ -15,6 +15,7 @@ struct EdsArrays {
     float* mhat;                                            // normalised model (pose-only solvers)
     // frames [B][Hp*Wp]
     const float* frame;
+    const float* strips;   // [B][2][strips copy] or null: the strip layout of the same frames (eds_layout.hpp), valid for the slots a solve asked for
     // per-slot constants
     double* pose;        // [B][EDS_POSE_STRIDE]
     double* G;           // [B][EDS_MAX_BLOCKS][36]

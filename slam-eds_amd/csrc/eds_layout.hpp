@@ -81,3 +81,20 @@ EDS_LAYOUT_HD static inline size_t eds_frame_index(int r, int c, int Wp, int til
     const int rr = r + EDS_FRAME_MARGIN, cc = c + EDS_FRAME_MARGIN;
     return tiled ? ((size_t)((rr >> 2) * (Wp >> 2) + (cc >> 2)) * 16 + ((rr & 3) << 2) + (cc & 3)) : ((size_t)rr * Wp + cc);
 }
+
+// ---- strips: the second frame layout of the persistent pose-only kernel (round 3) ----------------------------------------
+// A bicubic patch row (4 taps) read out of 4x4 tiles is TWO aligned 16-byte pieces plus a barrel shift, and a patch touches
+// 3.06 sectors of 64 bytes.  Strips: the allocation (margins included) cut into 8-column-wide full-height strips — a strip row is
+// 32 bytes, rows follow one another — and stored TWICE, the second copy cut 4 columns later.  Any 4 consecutive columns then lie
+// inside one strip of one of the two copies: a patch row is ONE 16-byte read at a 4-byte-aligned address, the four rows of a patch
+// are 128 contiguous bytes (2.5 sectors on average), no shift.  Measured (tools/ubench_gather_lds.hip, 256 frames in flight):
+// 37.7 G patches/s against 32.0 for the tiles — the gather is what bounds the solve.  Costs 2 x the frame's bytes beside the
+// tiles, filled by one conversion launch when a solve finds a slot's strips out of date (eds_strips.hip).
+EDS_LAYOUT_HD static inline int eds_strips_count(int Wp) { return (Wp + 7) >> 3; }
+EDS_LAYOUT_HD static inline size_t eds_strips_copy_elems(int Hp, int Wp) { return (size_t)eds_strips_count(Wp) * Hp * 8; }
+// byte offset, from the start of a frame's strips, of the 4 taps at allocation row ra, allocation columns ca .. ca + 3
+EDS_LAYOUT_HD static inline unsigned eds_strips_row_offset(int ra, int ca, int Hp, unsigned copy_bytes) {
+    const int copy = ((ca & 7) + 3) >> 3;            // columns 5, 6, 7 (mod 8) would cross a strip of copy 0
+    const int cc = ca - 4 * copy;
+    return (unsigned)copy * copy_bytes + (unsigned)((((cc >> 3) * Hp + ra) << 5) + ((cc & 7) << 2));
+}

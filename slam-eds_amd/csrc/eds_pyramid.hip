@@ -109,6 +109,7 @@ static int build_levels(eds_pyr* p) {
         const dim3 b(32, 8), g((d->Wp + 31) / 32, (d->Hp + 7) / 8);
         hipLaunchKernelGGL(k_pyr_down, g, b, 0, st0, s->dframe, s->Wp, s->tiled, d->dframe, d->H, d->W, d->Hp, d->Wp, d->tiled);
         d->slots[0].has_frame = true;
+        ++d->slots[0].frame_version;
     }
     e = hipGetLastError();
     if (e == hipSuccess && p->levels > 1) {

@@ -1,0 +1,63 @@
+// Strip copies of the event frames (eds_layout.hpp): the layout the persistent pose-only kernel gathers from since round 3.
+//
+// The frame writers (set_event_frame, the event-frame builders, the pyramid) keep writing 4x4 tiles — every other kernel samples
+// those — and bump the slot's frame_version; a solve that wants strips calls eds_strips_prepare, which converts the slots whose
+// copy is out of date: one launch per run of stale slots, every thread moving one aligned 16-byte tile row into its place in a
+// strip (reads 2 x 1.26 MB, writes 2.5 MB per 640x480 frame: ~1 us per frame at the rates the batched image passes reach).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "eds_fused.hpp"
+#include "eds_handle.hpp"
+#include "eds_layout.hpp"
+
+// grid: (pieces of one frame's strips / 256, slots of the run)
+__global__ __launch_bounds__(256) void k_tiles_to_strips(const float* __restrict__ tiles, float* __restrict__ strips, int first, int Hp, int Wp) {
+    const int slot = first + blockIdx.y;
+    const int NS = eds_strips_count(Wp), TW = Wp >> 2;
+    const int per_copy = NS * Hp * 2;                       // 16-byte pieces per copy
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * per_copy) return;
+    const int copy = i >= per_copy, k = i - copy * per_copy;
+    const int half = k & 1, row = (k >> 1) % Hp, strip = (k >> 1) / Hp;
+    int col0 = 8 * strip + 4 * copy + 4 * half;             // allocation column of the piece's first pixel: a multiple of 4 = one tile row
+    if (col0 > Wp - 4) col0 = Wp - 4;                       // past the allocation (last strip of the shifted copy): never sampled, any finite filler
+    const float4 v = *reinterpret_cast<const float4*>(tiles + (size_t)slot * Hp * Wp + ((size_t)(row >> 2) * TW + (col0 >> 2)) * 16 + ((row & 3) << 2));
+    *reinterpret_cast<float4*>(strips + (size_t)slot * 2 * eds_strips_copy_elems(Hp, Wp) + (size_t)i * 4) = v;
+}
+
+bool eds_strips_prepare(eds_trk* h, int first, int count) {
+    if (!h->tiled) return false;
+    const size_t per_frame = 2 * eds_strips_copy_elems(h->Hp, h->Wp);
+    if (!h->dstrips) {
+        if (hipMalloc((void**)&h->dstrips, (size_t)h->B * per_frame * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); h->dstrips = nullptr; return false; }
+    }
+    // the slots whose storage is sampled: a slot's own, or the one it shares (eds_trk_share_event_frame)
+    std::vector<char> stale(h->B, 0);
+    bool any = false;
+    for (int s = first; s < first + count; ++s) {
+        const int fs = h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s;
+        Slot& src = h->slots[fs];
+        if (src.strips_version != src.frame_version || src.strips_version == 0) { stale[fs] = 1; any = true; }
+    }
+    if (!any) return true;
+    const int pieces = 2 * eds_strips_count(h->Wp) * h->Hp * 2;
+    for (int s = 0; s < h->B;) {
+        if (!stale[s]) { ++s; continue; }
+        int e = s;
+        while (e < h->B && stale[e] && e - s < 65535) ++e;
+        hipLaunchKernelGGL(k_tiles_to_strips, dim3((pieces + 255) / 256, e - s), dim3(256), 0, h->st, h->dframe, h->dstrips, s, h->Hp, h->Wp);
+        for (int k = s; k < e; ++k) {
+            if (h->slots[k].frame_version == 0) h->slots[k].frame_version = 1;       // (frames written before versions were kept)
+            h->slots[k].strips_version = h->slots[k].frame_version;
+        }
+        s = e;
+    }
+    return hipGetLastError() == hipSuccess;
+}
+
+void eds_strips_free(eds_trk* h) {
+    if (h->dstrips) hipFree(h->dstrips);
+    h->dstrips = nullptr;
+}
