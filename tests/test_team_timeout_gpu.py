@@ -93,12 +93,14 @@ def test_teams_pause_then_come_back(solver):
         assert w > 0.045 and info["flags"] & capi.INFO_TEAM_TIMEOUT and info["success"]
         np.testing.assert_allclose(tab, tab_team, rtol=1e-6, atol=1e-6)
         pause = capi.TEAM_COOLDOWN * (2 ** round_)             # a time-out right after a re-arm doubles the pause
-        dev_paused = []
+        dev_paused, w_paused = [], []
         for k in range(pause):
             w, tab, info = call()
             assert info["flags"] == capi.INFO_TEAMS_PAUSED, (round_, k, info["flags"])
-            assert w < 0.02 and info["success"]
-            dev_paused.append(info["device_time_us"])
+            assert info["success"]
+            dev_paused.append(info["device_time_us"]); w_paused.append(w)
+        # normal speed during the pause (the median: a shared box may stall any single call), and no 50 ms wait inside the kernels
+        assert np.median(w_paused) < 0.005 and max(dev_paused) < 5000.0, (round_, sorted(w_paused)[-3:], max(dev_paused))
         w, tab, info = call()                                  # re-armed
         assert info["flags"] == 0 and info["success"], (round_, info["flags"])
         np.testing.assert_allclose(tab, tab_team, rtol=1e-6, atol=1e-6)
