@@ -46,7 +46,9 @@ typedef double acc4d __attribute__((ext_vector_type(4)));
 // points, the members exchange their per-block sums (157 doubles per residual block) as tagged granules after every evaluation,
 // add them in member order, and all run the LM state machine on the identical totals.
 // QUAD (bicubic): the quad-cooperative gather of eds_device.hpp / eds_fused.hip — lane j of a quad loads row j of each of the quad's
-// four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane.
+// four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane.  QUAD = 2 (round 3):
+// the same on the STRIP copies of the frames (eds_layout.hpp) — one 16-byte read per patch row at a 4-byte-aligned address instead of
+// two aligned pieces and a barrel shift, 2.5 instead of 3.06 sectors per patch.
 template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
@@ -168,6 +170,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             float4 ra[2][4], rb[2][4];                                  // QUAD: this lane's row of the quad's four patches
             const int jr = lane & 3;
             const float* __restrict__ tiles = A.frame + (size_t)fslot * A.Hp * A.Wp;
+            const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
+            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * (2u * (size_t)copy_bytes);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
@@ -188,6 +192,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 miss[jj] = !(cached && s_cell[li] == key);
                 if (QUAD) {
                     if (miss[jj] && cached) s_cell[li] = key;
+                    if (QUAD == 2) {            // strips: the byte offset of the patch's first row (cached: offset 0, as below)
+                        const int ra_ = clampi(pg[jj].r0, -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca_ = clampi(pg[jj].c0, -2, frame.W) + (EDS_FRAME_MARGIN - 1);
+                        org[jj] = miss[jj] ? (int)(eds_strips_row_offset(ra_, ca_, A.Hp, copy_bytes) | 0x80000000u) : 0;
+                        continue;
+                    }
                     org[jj] = miss[jj] ? (pack_origin(frame, pg[jj].r0, pg[jj].c0) | (int)0x80000000) : 0;     // cached: origin 0 — its (unused) row loads fall on the first line of the allocation: no branch around the loads (+3 %)
                     continue;
                 }
@@ -207,7 +216,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     const int oq[4] = {o0, o1, o2, o3};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        load_patch_row(tiles, frame.TW, oq[q], jr, ra[jj][q], rb[jj][q]);
+                        if (QUAD == 2) {
+                            const float4u v = *reinterpret_cast<const float4u*>(sbase + (((unsigned)oq[q] & 0x7fffffffu) + 32u * (unsigned)jr));
+                            ra[jj][q] = make_float4(v.x, v.y, v.z, v.w);
+                        } else {
+                            load_patch_row(tiles, frame.TW, oq[q], jr, ra[jj][q], rb[jj][q]);
+                        }
                     }
                 }
             }
@@ -256,7 +270,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                             float* unit = cache + 4 * patch_unit(qcached ? qli + q : q, jr);
                             const float4 c = *reinterpret_cast<const float4*>(unit);
                             float t[4];
-                            shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
+                            if (QUAD == 2) { t[0] = ra[jj][q].x; t[1] = ra[jj][q].y; t[2] = ra[jj][q].z; t[3] = ra[jj][q].w; }
+                            else shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
                             const int m = oq[q] >> 31;               // all ones: gathered this pass
                             t[0] = flag_select(m != 0, t[0], c.x); t[1] = flag_select(m != 0, t[1], c.y); t[2] = flag_select(m != 0, t[2], c.z); t[3] = flag_select(m != 0, t[3], c.w);
                             if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
@@ -508,7 +523,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         std::memcpy(I.p, sl.p, sizeof(I.p)); std::memcpy(I.q, sl.q, sizeof(I.q)); std::memcpy(I.v, sl.v, sizeof(I.v));
     }
     hipError_t e = hipSuccess;           // (start states and results: pinned host memory the kernel accesses directly, eds_fused_alloc)
-    const EdsArrays A = h->arrays();
+    EdsArrays A = h->arrays();
     // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads,
     // 96 KB patch cache — the lower latency (0.28 ms for one 2 000-point alignment, 7.0 M LM iterations/s at 256).
     // Beyond that, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase
@@ -565,15 +580,23 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
                        h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch)
 #define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
-    bool quad = bicubic && count >= 1024;          // measured: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below
+    // on the tiles: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below; on the strips (one load per row, no shift) it wins
+    // from 64 alignments on: 3.61 vs 3.47 M LM iterations/s at 64, 9.97 vs 9.18 at 256, 11.06 vs 9.60 at 1 024, 13.30 vs 10.76 at 4 096
+    bool want_strips = !h->cfg.nc;
+    if (const char* ev = getenv("EDS_FUSED_LAYOUT")) want_strips = want_strips && std::strcmp(ev, "tiles") != 0;
+    bool quad = bicubic && count >= (want_strips ? 64 : 1024);
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
     quad = quad && h->H < 8000;                   // 13-bit row field of the packed origins (pack_origin)
+    // QUAD = 2: the same gather on the strip copies of the frames (EDS_FUSED_LAYOUT=tiles keeps the tiles; so does a failed allocation)
+    const bool strips = quad && want_strips && eds_strips_prepare(h, first, count);
+    if (want_strips && !strips && count < 1024) quad = false;         // (no room for the copies: the tiles' rule)
+    A.strips = h->dstrips;
     if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }
     else if (team == 8) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 8, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 8, 0); }
-    else if (team == 4) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
-    else if (team == 2) { if (bicubic) { if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 2, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 2, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 2, 0); }
-    else if (wide) { if (bicubic) { if (quad) EDS_LAUNCH12(0, 512, 1408, 1); else EDS_LAUNCH12(0, 512, 1408, 0); } else EDS_LAUNCH12(1, 512, 1408, 0); }
-    else { if (bicubic) { if (quad) EDS_LAUNCH12(0, 256, 320, 1); else EDS_LAUNCH12(0, 256, 320, 0); } else EDS_LAUNCH12(1, 256, 320, 0); }
+    else if (team == 4) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 4, 2); else if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
+    else if (team == 2) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 2, 2); else if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 2, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 2, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 2, 0); }
+    else if (wide) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 1, 2); else if (quad) EDS_LAUNCH12(0, 512, 1408, 1); else EDS_LAUNCH12(0, 512, 1408, 0); } else EDS_LAUNCH12(1, 512, 1408, 0); }
+    else { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 256, 320, false, 1, 2); else if (quad) EDS_LAUNCH12(0, 256, 320, 1); else EDS_LAUNCH12(0, 256, 320, 0); } else EDS_LAUNCH12(1, 256, 320, 0); }
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
