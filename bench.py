@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--no-ref12", dest="no_ref12", action="store_true", help="skip the informational REF12 measurement")
     ap.add_argument("--lambda0", type=float, default=0.01, help="initial LM6 damping (DSO template: 0.01)")
     ap.add_argument("--exec", dest="exec_", choices=["device", "host"], default="device")
-    ap.add_argument("--distinct", type=int, default=32, help="distinct synthetic alignments (replicated to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic alignments (replicated to fill the batch)")
+    ap.add_argument("--no-configs", dest="no_configs", action="store_true", help="skip the block of the other BASELINE.json configs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-shared", dest="no_shared", action="store_true", help="skip the informational two-batches-in-flight and shared-frame measurements (the latter launches the "
@@ -283,6 +284,114 @@ def latency_block(capi, synth, al, a):
     return out
 
 
+def configs_block(capi, synth, a):
+    """The other BASELINE.json configs as throughput + roofline + parity in the same record (each outside the headline's timed region):
+    configs[2] batched (256 x 1280x720 / 8 000 points, per-point Huber at 1.345 MAD), configs[3] batched (64 four-level pyramids,
+    2 000 .. 16 000 points, one launch per level for all of them), configs[4] (64 alignments of configs[1], one launch).  LM6,
+    `--iters` iterations (per level), bicubic; >= 8 result rows of each against the CPU oracle (the checker: never inside a timing)."""
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    import np_pyramid_oracle as pyo
+    per_pt, mm = BYTES_RESJAC["bicubic"] + BYTES_REDUCE, BYTES_MUST_MOVE["bicubic"]
+    pool = ThreadPoolExecutor(min(16, os.cpu_count() or 1))
+    out = {}
+
+    def rounded(x):            # the alignment with its frame as the library holds it (fp32)
+        return synth.Alignment(**{**x.__dict__, "frame": np.ascontiguousarray(x.frame, dtype=np.float32).astype(np.float64)})
+
+    def timed(f, reps=5):
+        f()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); r = f(); t.append(time.perf_counter() - t0)
+        return float(np.median(t)), r
+
+    def roof(points_passes, k_ms):          # points_passes = sum over launches of alignments x points x passes
+        return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
+                "achieved": points_passes * per_pt / (k_ms * 1e-3) / 1e9, "frac": points_passes * per_pt / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "achieved_must_move": points_passes * mm / (k_ms * 1e-3) / 1e9, "frac_must_move": points_passes * mm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    # ---- configs[2] ------------------------------------------------------------------------------------------------------------
+    B2, N2, H2, W2, D2 = 256, 8000, 720, 1280, 8
+    als = list(pool.map(lambda i: synth.make_alignment(2234 + i, H=H2, W=W2, N=N2), range(D2)))
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0), B2, N2, H2, W2)
+    fr = [np.ascontiguousarray(x.frame, dtype=np.float32) for x in als]
+    for b in range(B2):
+        x = als[b % D2]
+        h.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy); h.set_event_frame(b, fr[b % D2])
+    r0 = h.eval(0, als[0].p0, als[0].q0, als[0].v0, ncols=6, want_jacobian=False)["r"]
+    tau = float(1.345 * 1.4826 * np.median(np.abs(r0 - np.median(r0))))            # 1.345 MAD of the start residuals of alignment 0
+    h.set_config(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0, huber_tau=tau))
+    P0 = np.stack([als[b % D2].p0 for b in range(B2)]); Q0 = np.stack([als[b % D2].q0 for b in range(B2)]); V0 = np.stack([als[b % D2].v0 for b in range(B2)])
+
+    def step2():
+        h.set_states(0, P0, Q0, V0); h.optimize_batch(0, 0, B2, sync=True)
+    wall, _ = timed(step2)
+    tab = h.results(0, B2); launch = h.last_launch(); k_ms = h.info(0)["device_time_us"] * 1e-3
+    its = float(np.mean(tab[:, 14])); passes = a.iters + 1
+    worst, mism = 0.0, 0
+    for d in range(D2):
+        ref = po.Oracle(rounded(als[d])).pose6_lm(als[d].p0, als[d].q0, als[d].v0, iters=a.iters, lambda0=a.lambda0, huber_tau=tau)
+        worst = max(worst, po.se3_distance(tab[d, 0:3], tab[d, 3:7], ref["p"], ref["q"])); mism += int(tab[d, 14] != ref["iterations"])
+    out["config2"] = {"workload": f"{B2} alignments x {N2} points on {W2}x{H2}, {a.iters} LM6 iterations, per-point Huber tau = 1.345 MAD = {tau:.4g}",
+                      "iterations_per_s": B2 * its / wall, "ms_per_step": 1e3 * wall, "kernel": launch["kernel"], "cus_per_alignment": launch["cus_per_alignment"],
+                      "roofline": roof(B2 * N2 * passes, k_ms), "success_fraction": float(np.mean(tab[:, 15])),
+                      "parity": {"rows_checked": D2, "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
+    h.close()
+
+    # ---- configs[3] ------------------------------------------------------------------------------------------------------------
+    counts, B3, D3 = [16000, 8000, 4000, 2000], 64, 8
+    als = list(pool.map(lambda i: synth.make_alignment(3234 + i, H=480, W=640, N=16000, rot_deg=0.6, trans_norm=0.012, blur_ksize=15, blur_sigma=4.0), range(D3)))
+    pyr = capi.Pyramid(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0), counts, 480, 640, batch=B3)
+    for b in range(B3):
+        x = als[b % D3]
+        for l, n in enumerate(counts):
+            pyr.set_keyframe_slot(b, l, x.norm_coord[:n], x.grad[:n], x.idp[:n], x.weights[:n], x.fx, x.fy, x.cx, x.cy)
+        pyr.set_event_frame_slot(b, x.frame)
+    P0 = np.stack([als[b % D3].p0 for b in range(B3)]); Q0 = np.stack([als[b % D3].q0 for b in range(B3)]); V0 = np.stack([als[b % D3].v0 for b in range(B3)])
+    wall, (P, Q, V, infos) = timed(lambda: pyr.optimize_batch(P0, Q0, V0))
+    its_l = [float(np.mean([infos[l][k]["num_iterations"] for k in range(B3)])) for l in range(len(counts))]
+    k_ms = sum(infos[l][0]["device_time_us"] for l in range(len(counts))) * 1e-3
+    worst, mism = 0.0, 0
+    for d in range(D3):
+        rp, rq, rv, per_level = pyo.track(po, synth, als[d], counts, [a.iters] * len(counts), solver="lm6")
+        worst = max(worst, po.se3_distance(P[d], Q[d], rp, rq))
+        mism += sum(int(infos[l][d]["num_iterations"] != per_level[l]["iterations"]) for l in range(len(counts)))
+    out["config3"] = {"workload": f"{B3} coarse-to-fine pyramids, levels 80x60 .. 640x480 with {counts[::-1]} points, {a.iters} LM6 iterations per level, "
+                                  f"one launch per level for all pyramids",
+                      "iterations_per_s": B3 * sum(its_l) / wall, "pyramids_per_s": B3 / wall, "ms_per_step": 1e3 * wall,
+                      "iterations_per_level_finest_first": its_l, "kernel": "eds_fused6_kernel, teams of 1 024 points per CU above 2 048 points (one launch per level)",
+                      "roofline": roof(sum(B3 * n * (a.iters + 1) for n in counts), k_ms),
+                      "parity": {"rows_checked": D3, "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
+    pyr.close()
+
+    # ---- configs[4] on one GPU -------------------------------------------------------------------------------------------------
+    B4 = 64
+    als = list(pool.map(lambda b: synth.make_alignment(5000 + b, H=a.height, W=a.width, N=a.points), range(B4)))
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0), B4, a.points, a.height, a.width)
+    for b in range(B4):
+        h.set_alignment(b, als[b])
+    P0 = np.stack([x.p0 for x in als]); Q0 = np.stack([x.q0 for x in als]); V0 = np.stack([x.v0 for x in als])
+
+    def step4():
+        h.set_states(0, P0, Q0, V0); h.optimize_batch(0, 0, B4, sync=True)
+    wall, _ = timed(step4, reps=20)
+    tab = h.results(0, B4); launch = h.last_launch(); k_ms = h.info(0)["device_time_us"] * 1e-3
+    worst, mism = 0.0, 0
+    for d in range(0, B4, 8):
+        ref = po.Oracle(rounded(als[d])).pose6_lm(als[d].p0, als[d].q0, als[d].v0, iters=a.iters, lambda0=a.lambda0)
+        worst = max(worst, po.se3_distance(tab[d, 0:3], tab[d, 3:7], ref["p"], ref["q"])); mism += int(tab[d, 14] != ref["iterations"])
+    out["config4_one_gpu"] = {"workload": f"{B4} alignments (seeds 5000..5063) x {a.points} points on {a.width}x{a.height}, {a.iters} LM6 iterations, ONE launch "
+                                          f"(the 8-GPU config shards them 8 per GPU; this is all 64 on one)",
+                              "iterations_per_s": B4 * float(np.mean(tab[:, 14])) / wall, "ms_per_step": 1e3 * wall, "kernel": launch["kernel"],
+                              "cus_per_alignment": launch["cus_per_alignment"], "roofline": roof(B4 * a.points * (a.iters + 1), k_ms),
+                              "parity": {"rows_checked": len(range(0, B4, 8)), "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
+    h.close()
+    pool.shutdown()
+    return out
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (torch.distributed.run) before this
     process has made any HIP / torch.cuda call — a process that has initialised the GPU must never exec or be re-used as a
@@ -348,7 +457,9 @@ def main():
     # BASELINE.json configs[4] seeds: 5000 + b for alignment b; `distinct` of them, replicated
     first_global = rank * B
     distinct = min(a.distinct, B)
-    als = [synth.make_alignment(5000 + ((first_global + i) % max(distinct * world, 1)), H=H, W=W, N=N) for i in range(distinct)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:        # numpy releases the GIL in the heavy parts (splat, blur, noise)
+        als = list(ex.map(lambda i: synth.make_alignment(5000 + ((first_global + i) % max(distinct * world, 1)), H=H, W=W, N=N), range(distinct)))
     cfg = capi.default_config(device=local_rank if world > 1 else 0,
                               sampling=capi.SAMPLE_BICUBIC if a.sampling == "bicubic" else capi.SAMPLE_BILINEAR,
                               solver=capi.SOLVER_LM6 if a.solver == "lm6" else capi.SOLVER_GN6,
@@ -418,40 +529,34 @@ def main():
 
     out = None
     if rank == 0:
-        # residual/Jacobian passes per solve: LM6 = initial linearisation + one per iteration (the persistent kernel keeps
-        # the accepted pose's residuals in registers; the host-driven loop and N > 2048 add a final residual pass);
-        # GN6 = one per iteration + the final residual pass
-        in_regs = a.exec_ == "device" and (N <= 2048 or not (N > 4096 and B < 16))
+        # residual/Jacobian passes per solve: LM6 = initial linearisation + one per iteration when the kernel keeps the accepted pose's
+        # residuals in registers (eds_fused6_kernel with register-resident points: second template argument > 0); the streaming
+        # kernels and the host-driven loop add a final residual pass; GN6 = one per iteration + the final residual pass.  Which
+        # kernel ran is what the LIBRARY says it launched (eds_trk_last_launch), not a copy of its selection rule.
+        launch = h.last_launch() if a.exec_ == "device" else None
+        in_regs = False
+        if launch and launch["kernel"].startswith("eds_fused6_kernel<"):
+            in_regs = int(launch["kernel"].split("<")[1].split(",")[1]) > 0
         passes = a.iters + (1 if (a.solver == "lm6" and in_regs) else (2 if a.solver == "lm6" else 1))
         per_pt = BYTES_RESJAC[a.sampling] + BYTES_REDUCE
         roof = None
         if a.exec_ == "device":
             k_ms = float(np.mean(dev_us)) * 1e-3
             ach = B * N * passes * per_pt / (k_ms * 1e-3) / 1e9
-            kname = "eds_fused6_kernel" if (N <= 2048 or (N > 4096 and B < 16)) else "eds_stream6_kernel"   # eds_fused_solve's rule
             mm = BYTES_MUST_MOVE[a.sampling]
             ach_mm = B * N * passes * mm / (k_ms * 1e-3) / 1e9
-            roof = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"kernel": launch["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": B * N * passes * per_pt,
                     "achieved_must_move": ach_mm, "frac_must_move": ach_mm / HBM_PEAK_GBS, "must_move_bytes_per_launch": B * N * passes * mm,
+                    "frame_layout": {0: "row-major", 1: "4x4 tiles", 2: "strips"}.get(launch["layout"], "?"),
                     "note": f"achieved/frac: SURVEY 8d credit, {per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch "
                             f"(a fused kernel is credited the J bytes it never moves); *_must_move: {mm} B per point-evaluation "
                             f"(point constants + taps only)"}
-            # the instantiation eds_fused_solve launches for this shape: <sampler, points per lane, threads, quad gather, team>
-            if kname == "eds_fused6_kernel":
-                thr = 512 if N <= 2048 else 1024
-                while thr > 64 and thr // 2 >= N:
-                    thr //= 2
-                ppt = -(-N // thr); ppt = 1 if ppt <= 1 else (2 if ppt <= 2 else (4 if ppt <= 4 else 0))
-                smp = 0 if a.sampling == "bicubic" else 1
-                inst = f"<{smp}, {ppt}, {thr}, {1 if (smp == 0 and B >= 32 and ppt > 0) else 0}, 1>"
-            else:
-                inst = "<0" if a.sampling == "bicubic" else "<1"
-            roof["kernel"] = kname + (inst if inst.endswith(">") else "")
-            t = pmc_traffic(kname + inst, a)
+            t = pmc_traffic(launch["kernel"], a)
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
+            launch_digest = {k: launch[k] for k in ("workgroups", "span_us", "mean_workgroup_us", "covered", "tail_idle_us")}
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
         both_ms = h.bench_eval(0, B, ncols=6, with_reduction=True, reps=20)
         ach_rj = B * N * BYTES_RESJAC[a.sampling] / (rj_ms * 1e-3) / 1e9
@@ -479,6 +584,10 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj,
         }
+        if a.exec_ == "device":
+            out["launch_digest"] = dict(launch_digest, note="the timed kernel's last launch, from its workgroups' own begin / end stamps: covered = sum of "
+                                        "workgroup durations / (256 CUs x span); tail_idle_us = mean idle time of a CU behind its last workgroup")
+        out["config"]["distinct_alignments"] = distinct
         if forced:
             out["forced_dist"] = True
         if world == 1 and a.exec_ == "device" and a.sampling == "bicubic" and not a.no_ref12:
@@ -528,16 +637,17 @@ def main():
                                                      "traffic": None, "kernel_ms": rk_ms,
                                                      "note": f"{r_cred} B credited / {r_mm} B must-move per point-evaluation x {B}x{N} points x "
                                                              f"{r_evals:.2f} evaluations per solve"}}
-            smp = 0 if a.sampling == "bicubic" else 1
-            inst12 = (f"<{smp}, 512, 1408, false, 1, 0>" if B <= 256 else f"<{smp}, 256, 320, false, 1, {1 if (smp == 0 and B >= 1024) else 0}>")
-            out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = "eds_fused12_kernel" + inst12
-            t = pmc_traffic("eds_fused12_kernel" + inst12, a)
+            k12 = h.last_launch()["kernel"]
+            out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = k12
+            t = pmc_traffic(k12, a)
             if t:
                 out["reference_problem"]["roofline"]["traffic"] = t["bytes"]
                 out["reference_problem"]["roofline"]["traffic_source"] = t["source"]
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device":
             out["latency"] = latency_block(capi, synth, als[0], a)
+        if world == 1 and a.exec_ == "device" and a.sampling == "bicubic" and a.solver == "lm6" and not a.no_configs:
+            out["configs"] = configs_block(capi, synth, a)
         if world == 1 and a.exec_ == "device" and not a.no_shared:
             # Informational: TWO batches in flight — a second handle (own stream, own copy of every frame) takes step k + 1 while step k
             # runs.  The host's work per step and, more, the TAIL of a launch (its last workgroups end up to one alignment's duration
@@ -567,26 +677,33 @@ def main():
                                             "steps": nsteps, "identical_to_single_batch": same,
                                             "note": "NOT the headline: two handles / streams alternate, step k + 1 is launched while step k runs"}
             h2.close()
-        if world == 1 and a.exec_ == "device" and not a.no_shared and B > distinct:
-            # A DIFFERENT workload, informational: the same batch when the alignments that are replicas of one another also SHARE their
-            # event frame (eds_trk_share_event_frame: slot b samples slot b % distinct's storage) — several keyframes / pose hypotheses
-            # against one frame.  The frames in flight then fit the L2s (TCC hit 0.97 against 0.08, profiles/r02_shared_frames_l2.txt)
-            # and the same kernel runs without the fabric-bound gather.  Last leg: the handle is not used afterwards.
-            for b in range(distinct, B):
-                h.share_event_frame(b, b % distinct)
+        if world == 1 and a.exec_ == "device" and not a.no_shared and B > 32:
+            # A DIFFERENT workload, informational: the batch shape with 32 distinct alignments whose replicas SHARE their event frame
+            # (eds_trk_share_event_frame: slot b holds alignment b % 32 and samples slot b % 32's storage) — several keyframes / pose
+            # hypotheses against one frame.  The frames in flight then fit the L2s (TCC hit 0.97 against 0.08, profiles/r02_shared_frames_l2.txt)
+            # and the same kernel runs without the fabric-bound gather: what is left is its instruction stream.  Last leg on this handle.
+            nsh = min(32, distinct)
+            for b in range(B):
+                x = als[b % nsh]
+                h.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy)
+                if b < nsh:
+                    h.set_event_frame(b, frames32[b])
+                else:
+                    h.share_event_frame(b, b % nsh)
+            ps, qs, vs = (np.stack([getattr(als[b % nsh], k) for b in range(B)]) for k in ("p0", "q0", "v0"))
             s_ms, s_dev = [], []
             for k in range(5):
-                h.set_states(0, p0, q0, v0)
+                h.set_states(0, ps, qs, vs)
                 t1 = time.perf_counter()
                 h.optimize_batch(0, 0, B, sync=True)
                 s_ms.append(1e3 * (time.perf_counter() - t1))
                 s_dev.append(h.info(0)["device_time_us"] * 1e-3)
             stab = h.results(0, B)
             out["shared_frames"] = {"iterations_per_s": B * float(np.mean(stab[:, 14])) / (float(np.median(s_ms[1:])) * 1e-3),
-                                    "kernel_ms": float(np.median(s_dev[1:])), "distinct_frames": distinct,
-                                    "identical_to_own_copies": bool(np.array_equal(stab, table)) if a.solver == "lm6" else None,
+                                    "kernel_ms": float(np.median(s_dev[1:])), "distinct_frames": nsh, "kernel": h.last_launch()["kernel"],
+                                    "replicas_bit_identical": bool(all(np.array_equal(stab[b], stab[b % nsh]) for b in range(nsh, B, 97))),
                                     "roofline_frac": B * N * passes * per_pt / (float(np.median(s_dev[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "note": "NOT the headline workload: replicas of an alignment sample one shared frame instead of a copy each"}
+                                    "note": "NOT the headline workload: 32 distinct alignments, replicas of an alignment sample one shared frame instead of a copy each"}
     h.close()
     if rank == 0:
         # ---- parity of the timed batch against the CPU oracle (the checker, outside every timed region) ---------------------------

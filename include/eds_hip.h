@@ -330,6 +330,14 @@ int  eds_pyr_get_level_frame(eds_pyr* p, int level, double* frame);     /* (H >>
  * infos (optional) receives one eds_trk_info per level.  Returns the status of the finest level. */
 int  eds_pyr_optimize(eds_pyr* p, double pose_p[3], double q_xyzw[4], double v[6], eds_trk_info* infos);
 int  eds_pyr_get_residuals(eds_pyr* p, int level, double* r);
+/* `batch` independent pyramids in one object (level l of all of them = one handle of `batch` slots = one launch per level):
+ * the calls above address pyramid 0; these take the pyramid (slot).  eds_pyr_optimize_batch: P, Q, V are count x 3 / 4 / 6, in and
+ * out; infos (optional) levels x count, level-major. */
+int  eds_pyr_create_batch(const eds_trk_cfg* cfg, int batch, int levels, const int* max_points, int H, int W, eds_pyr** out);
+int  eds_pyr_set_keyframe_slot(eds_pyr* p, int slot, int level, int N, const double* norm_xy, const double* grad_xy, const double* idp,
+                               const double* w, double fx0, double fy0, double cx0, double cy0);
+int  eds_pyr_set_event_frame_slot(eds_pyr* p, int slot, const double* frame);
+int  eds_pyr_optimize_batch(eds_pyr* p, int first, int count, double* P, double* Q, double* V, eds_trk_info* infos);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP events on the handle's own stream (torch.cuda.Event cannot see it). */
@@ -339,6 +347,24 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the 
  * [first, first+count) `reps` times back-to-back at the stored states and reports the mean
  * duration per launch in ms, measured with HIP events on the handle's stream. */
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
+/* What the last on-device solve (eds_trk_optimize / _optimize_batch with exec = device) actually launched — so that a benchmark
+ * prices the kernel that ran instead of mirroring the library's selection rule. */
+typedef struct eds_trk_launch_info {
+    char    kernel[96];             /* e.g. "eds_fused6_kernel<0, 4, 512, 3, 1>": name and template arguments as rocprofv3 prints them */
+    int32_t workgroups;             /* of the last launch of the call (a range may go out in several team launches) */
+    int32_t cus_per_alignment;      /* > 1: a team launch */
+    int32_t first, count;           /* the range solved */
+    int32_t layout;                 /* frame layout the kernel sampled: 0 row-major, 1 4x4 tiles, 2 strips (csrc/eds_layout.hpp) */
+    int32_t timing_source;          /* device_time_us of eds_trk_info: 0 = two stream events around the launch(es), 1 = the workgroups' own
+                                     * 100 MHz stamps (launches of <= 64 alignments: member 0 of each team stamps when IT starts, so the value
+                                     * excludes dispatch latency and is not comparable with source 0 to better than a few microseconds) */
+    /* digest of the workgroups' begin / end stamps (one CU per alignment only; zeros otherwise): */
+    double  span_us;                /* first workgroup in .. last workgroup out */
+    double  mean_workgroup_us;
+    double  covered;                /* sum of workgroup durations / (256 CUs x span): what the launch tail and dispatch gaps leave */
+    double  tail_idle_us;           /* mean idle time of a CU between its last workgroup's end and the end of the launch */
+} eds_trk_launch_info;
+int eds_trk_last_launch(eds_trk* h, eds_trk_launch_info* out);
 
 #ifdef __cplusplus
 }

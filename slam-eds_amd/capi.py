@@ -40,10 +40,10 @@ EXPORTS = (
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
-    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval",
+    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_last_launch",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
-    "eds_pyr_get_residuals",
+    "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -77,6 +77,13 @@ class Info(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
+class LaunchInfo(C.Structure):
+    """``eds_trk_launch_info`` — what the last on-device solve launched (include/eds_hip.h)."""
+    _fields_ = [("kernel", C.c_char * 96), ("workgroups", C.c_int32), ("cus_per_alignment", C.c_int32), ("first", C.c_int32),
+                ("count", C.c_int32), ("layout", C.c_int32), ("timing_source", C.c_int32), ("span_us", C.c_double),
+                ("mean_workgroup_us", C.c_double), ("covered", C.c_double), ("tail_idle_us", C.c_double)]
 
 
 INFO_TEAM_TIMEOUT, INFO_TEAMS_PAUSED = 1, 2       # eds_trk_info.flags (include/eds_hip.h)
@@ -180,6 +187,11 @@ def lib():
         L.eds_pyr_level_size.argtypes = [C.c_void_p, C.c_int, _ip, _ip]
         L.eds_pyr_get_level_frame.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_pyr_optimize.argtypes = [C.c_void_p, _dp, _dp, _dp, C.POINTER(Info)]
+        L.eds_pyr_create_batch.argtypes = [C.POINTER(Cfg), C.c_int, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.eds_pyr_set_keyframe_slot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.eds_pyr_set_event_frame_slot.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.eds_pyr_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Info)]
+        L.eds_trk_last_launch.argtypes = [C.c_void_p, C.POINTER(LaunchInfo)]
         L.eds_pyr_get_residuals.argtypes = [C.c_void_p, C.c_int, _dp]
         if L.eds_trk_cfg_size() != C.sizeof(Cfg) or L.eds_trk_info_size() != C.sizeof(Info):
             raise EdsError(ERR_INVALID, "ctypes struct layout disagrees with include/eds_hip.h")
@@ -521,6 +533,13 @@ class Handle:
         _check(lib().eds_trk_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    def last_launch(self) -> dict:
+        li = LaunchInfo()
+        _check(lib().eds_trk_last_launch(self._h, C.byref(li)))
+        d = {k: getattr(li, k) for k, _ in li._fields_}
+        d["kernel"] = li.kernel.decode()
+        return d
+
     def bench_eval(self, first, count, ncols=6, with_reduction=False, reps=20) -> float:
         ms = C.c_float(0.0)
         _check(lib().eds_trk_bench_eval(self._h, first, count, ncols, int(with_reduction), reps, C.byref(ms)))
@@ -530,13 +549,33 @@ class Handle:
 class Pyramid:
     """RAII wrapper of ``eds_pyr*``: coarse-to-fine tracking of one alignment on an image pyramid (BASELINE.json configs[3])."""
 
-    def __init__(self, cfg: Cfg, max_points, H: int, W: int):
+    def __init__(self, cfg: Cfg, max_points, H: int, W: int, batch: int = 1):
         self.levels = len(max_points)
-        self.H, self.W = int(H), int(W)
+        self.H, self.W, self.batch = int(H), int(W), int(batch)
         mp = np.ascontiguousarray(max_points, dtype=np.int32)
         self._h = C.c_void_p()
         self._N = [0] * self.levels
-        _check(lib().eds_pyr_create(C.byref(cfg), self.levels, mp.ctypes.data_as(_ip), self.H, self.W, C.byref(self._h)))
+        _check(lib().eds_pyr_create_batch(C.byref(cfg), self.batch, self.levels, mp.ctypes.data_as(_ip), self.H, self.W, C.byref(self._h)))
+
+    # -- batched pyramids (batch > 1): the same calls per pyramid (slot), one launch per level for all of them ----------------
+    def set_keyframe_slot(self, slot, level, norm_coord, grad, idp, weights, fx, fy, cx, cy):
+        nc, g, d, w = _f64(norm_coord), _f64(grad), _f64(idp), _f64(weights)
+        self._N[level] = max(self._N[level], int(d.shape[0]))
+        _check(lib().eds_pyr_set_keyframe_slot(self._h, int(slot), int(level), int(d.shape[0]), _p(nc), _p(g), _p(d), _p(w), fx, fy, cx, cy))
+
+    def set_event_frame_slot(self, slot, frame):
+        f = _f64(frame)
+        assert f.size == self.H * self.W
+        _check(lib().eds_pyr_set_event_frame_slot(self._h, int(slot), _p(f)))
+
+    def optimize_batch(self, P, Q, V, first=0, want_infos=True):
+        """P, Q, V: count x 3 / 4 / 6 start states of pyramids [first, first + count).  Returns (P, Q, V, infos[level][k])."""
+        P, Q, V = _f64(P).copy(), _f64(Q).copy(), _f64(V).copy()
+        count = P.shape[0]
+        infos = (Info * (self.levels * count))() if want_infos else None
+        _check(lib().eds_pyr_optimize_batch(self._h, int(first), count, _p(P), _p(Q), _p(V), infos))
+        out = [[infos[l * count + k].as_dict() for k in range(count)] for l in range(self.levels)] if want_infos else None
+        return P, Q, V, out
 
     def close(self):
         if self._h:

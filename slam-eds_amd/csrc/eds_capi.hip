@@ -993,6 +993,11 @@ int eds_trk_timer_start(eds_trk* h) {
     return EDS_OK;
 }
 
+int eds_trk_last_launch(eds_trk* h, eds_trk_launch_info* out) {
+    if (!h || !out) return fail(EDS_ERR_INVALID, "null argument");
+    return eds_fused_last_launch(h, out);
+}
+
 int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms) {
     if (!h || !elapsed_ms) return fail(EDS_ERR_INVALID, "null argument");
     EDS_HIP_TRY(hipSetDevice(h->dev));

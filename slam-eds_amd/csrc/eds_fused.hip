@@ -853,17 +853,22 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         stream = std::strcmp(ev, "paired") == 0 || std::strcmp(ev, "wide") == 0 || std::strcmp(ev, "stream") == 0;
         wide = std::strcmp(ev, "wide") == 0;
     }
-#define EDS_LAUNCH_FUSED(S, P, T, Q)                                                                                              \
+#define EDS_NOTE_LAUNCH(S, P, T, Q, K, WG) do { std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d>", S, P, T, Q, K); \
+        fb.last_workgroups = (WG); fb.last_team = (K); fb.last_layout = (Q) >= 3 ? 2 : 1; } while (0)
+#define EDS_LAUNCH_FUSED(S, P, T, Q) do {                                                                                         \
+    EDS_NOTE_LAUNCH(S, P, T, Q, 1, count);                                                                                        \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q, 1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u, 0u)
+                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u, 0u); } while (0)
 #define EDS_LAUNCH_BILINEAR(P, K) do {                                                                                             \
+        EDS_NOTE_LAUNCH(1, P, (K) > 1 ? 512 : threads, 0, K, count * (K) - ((K) > 1 ? drop : 0));                                 \
         const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, first, count, (K) > 1 ? 512 : threads, iters, damped, h->cfg.lambda0, tau, nb, \
                                 (K) > 1 ? fb.d_mail : nullptr, (K) > 1 ? fb.d_ticket : nullptr, (K) > 1 ? ticket_base : 0u,         \
                                 (K) > 1 ? fb.epoch : 0u, (K) > 1 ? drop : 0, h->st};                                                                   \
         eds_fused6_launch_bilinear(L, P, K); } while (0)
-#define EDS_LAUNCH_TEAM(S, P, Q, K)                                                                                                \
+#define EDS_LAUNCH_TEAM(S, P, Q, K) do {                                                                                           \
+    EDS_NOTE_LAUNCH(S, P, 512, Q, K, count * K - drop);                                                                            \
     hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K - drop), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch)
+                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch); } while (0)
     // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
     // solves with register-resident points only.  Up to 2 048 points: 4 CUs (512 points each) up to 64 alignments, 2 CUs up to 128.
     // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
@@ -935,6 +940,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_TEAM_Q2
         }
     } else if (stream) {
+        std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_stream6_kernel<%d, %d, %d>", h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 0 : 1, wide ? 512 : 256, wide ? 2048 : 1024);
+        fb.last_workgroups = count; fb.last_team = 1; fb.last_layout = 1;
         eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
     } else {
     // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
@@ -964,6 +971,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
 #undef EDS_LAUNCH_FUSED_T
 #undef EDS_LAUNCH_FUSED
+#undef EDS_NOTE_LAUNCH
 #undef EDS_LAUNCH_TEAM
 #undef EDS_LAUNCH_BILINEAR
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
@@ -973,6 +981,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     fb.pending_first = first;
     fb.pending_count = count;
     fb.pending_kind = 6;
+    fb.last_first = first; fb.last_count = count; fb.last_kind = 6; fb.last_ticks = fb.pending_ticks;
     fb.launch_wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return EDS_OK;
 }
@@ -1056,6 +1065,35 @@ int eds_fused_collect(eds_trk* h) {
 #endif
     fb.pending_count = 0;
     fb.pending_retry = false; fb.pending_paused = false;
+    return EDS_OK;
+}
+
+// eds_trk_last_launch: what the last on-device solve launched, and (one CU per alignment) the digest of its workgroups' stamps
+int eds_fused_last_launch(eds_trk* h, eds_trk_launch_info* out) {
+    EdsFusedBuffers& fb = h->fused;
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->kernel, sizeof(out->kernel), "%s", fb.last_kernel);
+    out->workgroups = fb.last_workgroups; out->cus_per_alignment = fb.last_team;
+    out->first = fb.last_first; out->count = fb.last_count;
+    out->layout = h->tiled ? fb.last_layout : 0;
+    out->timing_source = fb.last_ticks ? 1 : 0;
+    if (fb.last_count <= 0 || fb.last_team != 1 || fb.pending_count > 0) return EDS_OK;
+    std::vector<unsigned long long> te;
+    te.reserve(fb.last_count);
+    unsigned long long t0 = ~0ull, t1 = 0; double busy = 0.0;
+    for (int s = fb.last_first; s < fb.last_first + fb.last_count; ++s) {
+        const unsigned long long b = fb.last_kind == 12 ? fb.h_out12[s].t_begin : fb.h_out[s].t_begin, e = fb.last_kind == 12 ? fb.h_out12[s].t_end : fb.h_out[s].t_end;
+        if (e <= b) continue;
+        t0 = std::min(t0, b); t1 = std::max(t1, e); busy += (double)(e - b); te.push_back(e);
+    }
+    if (te.empty() || t1 <= t0) return EDS_OK;
+    std::sort(te.begin(), te.end());
+    const int nc = std::min(256, (int)te.size());
+    double tail = 0.0;
+    for (int i = 0; i < nc; ++i) tail += (double)(t1 - te[te.size() - 1 - i]);          // the last workgroup of each CU = the 256 latest ends
+    const double span = (double)(t1 - t0);
+    out->span_us = span * 1e-2; out->mean_workgroup_us = busy / (double)te.size() * 1e-2;
+    out->covered = busy / (256.0 * span); out->tail_idle_us = tail / nc * 1e-2;
     return EDS_OK;
 }
 

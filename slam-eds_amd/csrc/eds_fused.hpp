@@ -71,6 +71,9 @@ struct EdsFusedBuffers {
     int pending_team = 1, pending_level = 0;
     bool pending_ticks = false;    // device time from the kernels' own time stamps (no event records around the launch)
     bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (eds_mirror_residuals)
+    char last_kernel[96] = {0};    // what the last solve launched (eds_trk_last_launch)
+    int last_workgroups = 0, last_team = 1, last_first = 0, last_count = 0, last_layout = 1, last_kind = 0;
+    bool last_ticks = false;
     int B = 0;
     int pending_first = 0, pending_count = 0, pending_kind = 0;   // range launched but not yet collected (kind 6 | 12)
     double launch_wall_us = 0.0;
@@ -85,6 +88,8 @@ void eds_fused_free(EdsFusedBuffers* fb);
 int  eds_fused_solve(eds_trk* h, int level, int first, int count);   // asynchronous on h->st
 int  eds_fused_collect(eds_trk* h);                                  // after the stream is idle
 int  eds_fused_fetch_trace(eds_trk* h, int slot);                    // D2H of one slot's trace
+struct eds_trk_launch_info;
+int  eds_fused_last_launch(eds_trk* h, eds_trk_launch_info* out);
 
 // eds_strips.hip: makes the strip copies of the frames the slots [first, first + count) sample current (allocates them at the first call;
 // one conversion launch per run of stale slots, on h->st).  false: no memory for them — the caller uses the tiles.

@@ -574,10 +574,12 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;     // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH12_(S, T, C, NCM, K, Q)                                                                                             \
+#define EDS_LAUNCH12_(S, T, C, NCM, K, Q) do {                                                                                        \
+    std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", S, T, C, (NCM) ? "true" : "false", K, Q);   \
+    fb.last_workgroups = count * K - ((K) > 1 ? drop : 0); fb.last_team = (K); fb.last_layout = (Q) == 2 ? 2 : 1;                     \
     hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K - ((K) > 1 ? drop : 0)), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
                        h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
-                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch)
+                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch); } while (0)
 #define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
     // on the tiles: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below; on the strips (one load per row, no shift) it wins
@@ -606,6 +608,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     fb.pending_first = first;
     fb.pending_count = count;
     fb.pending_kind = 12;
+    fb.last_first = first; fb.last_count = count; fb.last_kind = 12; fb.last_ticks = fb.pending_ticks;
     fb.launch_wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return EDS_OK;
 }

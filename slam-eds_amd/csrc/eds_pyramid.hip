@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "../../include/eds_hip.h"
 #include "eds_handle.hpp"
@@ -21,10 +22,12 @@ namespace {
 
 // dst(r, c) = 0.25f * (src(2r, 2c) + src(2r, 2c+1) + src(2r+1, 2c) + src(2r+1, 2c+1)), in that order, in fp32 — for every element
 // of the destination ALLOCATION: margin elements take the value of the nearest image pixel (Grid2D's clamp, eds_layout.hpp).
-__global__ void k_pyr_down(const float* __restrict__ src, int sWp, int s_tiled, float* __restrict__ dst, int dH, int dW, int dHp, int dWp,
-                           int d_tiled) {
+__global__ void k_pyr_down(const float* __restrict__ src, int sHp, int sWp, int s_tiled, float* __restrict__ dst, int dH, int dW, int dHp, int dWp,
+                           int d_tiled, int first_slot) {
     const int cc = blockIdx.x * blockDim.x + threadIdx.x, rr = blockIdx.y * blockDim.y + threadIdx.y;     // allocation coordinates
     if (rr >= dHp || cc >= dWp) return;
+    src += (size_t)(first_slot + blockIdx.z) * sHp * sWp;          // blockIdx.z: the pyramid (slot) of a batched eds_pyr
+    dst += (size_t)(first_slot + blockIdx.z) * dHp * dWp;
     const int r = min(max(rr - EDS_FRAME_MARGIN, 0), dH - 1), c = min(max(cc - EDS_FRAME_MARGIN, 0), dW - 1);
     const float a = src[eds_frame_index(2 * r, 2 * c, sWp, s_tiled)], b = src[eds_frame_index(2 * r, 2 * c + 1, sWp, s_tiled)];
     const float cpix = src[eds_frame_index(2 * r + 1, 2 * c, sWp, s_tiled)], d = src[eds_frame_index(2 * r + 1, 2 * c + 1, sWp, s_tiled)];
@@ -34,25 +37,33 @@ __global__ void k_pyr_down(const float* __restrict__ src, int sWp, int s_tiled, 
 }  // namespace
 
 struct eds_pyr {
-    int levels = 0;
+    int levels = 0, batch = 1;
     eds_trk* lv[EDS_MAX_LEVELS] = {nullptr};
     double K0[4] = {0, 0, 0, 0};
     bool has_frame = false;
+    std::vector<char> slot_has_frame;   // batched pyramids: per slot
     hipEvent_t ev_levels = nullptr;     // recorded behind the last down-sampling launch
 };
 
 extern "C" {
 
 int eds_pyr_create(const eds_trk_cfg* cfg, int levels, const int* max_points, int H, int W, eds_pyr** out) {
+    return eds_pyr_create_batch(cfg, 1, levels, max_points, H, W, out);
+}
+
+// `batch` independent pyramids in one object: level l is ONE handle of `batch` slots, so that a level of all pyramids is one launch
+int eds_pyr_create_batch(const eds_trk_cfg* cfg, int batch, int levels, const int* max_points, int H, int W, eds_pyr** out) {
     if (!cfg || !out || !max_points) return eds_internal_fail(EDS_ERR_INVALID, "null argument");
     *out = nullptr;
+    if (batch < 1) return eds_internal_fail(EDS_ERR_INVALID, "batch out of range");
     if (levels < 1 || levels > EDS_MAX_LEVELS) return eds_internal_fail(EDS_ERR_INVALID, "levels out of range");
     if ((H >> (levels - 1)) < 4 || (W >> (levels - 1)) < 4) return eds_internal_fail(EDS_ERR_INVALID, "coarsest level smaller than 4x4");
     eds_pyr* p = new (std::nothrow) eds_pyr();
     if (!p) return eds_internal_fail(EDS_ERR_INVALID, "out of memory");
-    p->levels = levels;
+    p->levels = levels; p->batch = batch;
+    p->slot_has_frame.assign(batch, 0);
     for (int l = 0; l < levels; ++l) {
-        int rc = eds_trk_create(cfg, 1, max_points[l], H >> l, W >> l, &p->lv[l]);
+        int rc = eds_trk_create(cfg, batch, max_points[l], H >> l, W >> l, &p->lv[l]);
         if (rc != EDS_OK) { for (int k = 0; k < l; ++k) eds_trk_destroy(p->lv[k]); delete p; return rc; }
     }
     if (hipEventCreateWithFlags(&p->ev_levels, hipEventDisableTiming) != hipSuccess) {
@@ -89,27 +100,31 @@ int eds_pyr_level_intrinsics(int level, double fx0, double fy0, double cx0, doub
 
 int eds_pyr_set_keyframe(eds_pyr* p, int level, int N, const double* norm_xy, const double* grad_xy, const double* idp, const double* w,
                          double fx0, double fy0, double cx0, double cy0) {
+    return eds_pyr_set_keyframe_slot(p, 0, level, N, norm_xy, grad_xy, idp, w, fx0, fy0, cx0, cy0);
+}
+int eds_pyr_set_keyframe_slot(eds_pyr* p, int slot, int level, int N, const double* norm_xy, const double* grad_xy, const double* idp, const double* w,
+                              double fx0, double fy0, double cx0, double cy0) {
     if (!p) return eds_internal_fail(EDS_ERR_INVALID, "null handle");
     if (level < 0 || level >= p->levels) return eds_internal_fail(EDS_ERR_INVALID, "level out of range");
+    if (slot < 0 || slot >= p->batch) return eds_internal_fail(EDS_ERR_INVALID, "slot out of range");
     double K[4];
     eds_pyr_level_intrinsics(level, fx0, fy0, cx0, cy0, K);
-    return eds_trk_set_keyframe(p->lv[level], 0, N, norm_xy, grad_xy, idp, w, K[0], K[1], K[2], K[3]);
+    return eds_trk_set_keyframe(p->lv[level], slot, N, norm_xy, grad_xy, idp, w, K[0], K[1], K[2], K[3]);
 }
 
 // Levels 1 .. L-1 from level 0, all on level 0's stream (whatever wrote level 0 — set_event_frame's band launches, the event-frame
 // builder — is on that stream too), one launch behind the other; the other levels' streams then wait for ONE event.  The host
 // waits for nothing: a level's solve is ordered behind its frame on the level's own stream.
-static int build_levels(eds_pyr* p) {
+static int build_levels(eds_pyr* p, int first = 0, int count = 1) {
     hipStream_t st0 = p->lv[0]->st;
     hipError_t e = hipSetDevice(p->lv[0]->dev);
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     for (int l = 1; l < p->levels; ++l) {
         eds_trk* s = p->lv[l - 1];
         eds_trk* d = p->lv[l];
-        const dim3 b(32, 8), g((d->Wp + 31) / 32, (d->Hp + 7) / 8);
-        hipLaunchKernelGGL(k_pyr_down, g, b, 0, st0, s->dframe, s->Wp, s->tiled, d->dframe, d->H, d->W, d->Hp, d->Wp, d->tiled);
-        d->slots[0].has_frame = true;
-        ++d->slots[0].frame_version;
+        const dim3 b(32, 8), g((d->Wp + 31) / 32, (d->Hp + 7) / 8, count);
+        hipLaunchKernelGGL(k_pyr_down, g, b, 0, st0, s->dframe, s->Hp, s->Wp, s->tiled, d->dframe, d->H, d->W, d->Hp, d->Wp, d->tiled, first);
+        for (int k = first; k < first + count; ++k) { d->slots[k].has_frame = true; ++d->slots[k].frame_version; }
     }
     e = hipGetLastError();
     if (e == hipSuccess && p->levels > 1) {
@@ -117,15 +132,18 @@ static int build_levels(eds_pyr* p) {
         for (int l = 1; l < p->levels && e == hipSuccess; ++l) e = hipStreamWaitEvent(p->lv[l]->st, p->ev_levels, 0);
     }
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
+    for (int k = first; k < first + count; ++k) p->slot_has_frame[k] = 1;
     p->has_frame = true;
     return EDS_OK;
 }
 
-int eds_pyr_set_event_frame(eds_pyr* p, const double* frame) {
+int eds_pyr_set_event_frame(eds_pyr* p, const double* frame) { return eds_pyr_set_event_frame_slot(p, 0, frame); }
+int eds_pyr_set_event_frame_slot(eds_pyr* p, int slot, const double* frame) {
     if (!p || !frame) return eds_internal_fail(EDS_ERR_INVALID, "null argument");
-    int rc = eds_trk_set_event_frame(p->lv[0], 0, frame);
+    if (slot < 0 || slot >= p->batch) return eds_internal_fail(EDS_ERR_INVALID, "slot out of range");
+    int rc = eds_trk_set_event_frame(p->lv[0], slot, frame);
     if (rc) return rc;
-    return build_levels(p);
+    return build_levels(p, slot, 1);
 }
 
 int eds_pyr_build_event_frame(eds_pyr* p, int n_events, const uint16_t* x, const uint16_t* y, const uint8_t* polarity, double blur_sigma,
@@ -165,6 +183,28 @@ int eds_pyr_optimize(eds_pyr* p, double pp[3], double q[4], double v[6], eds_trk
     }
     if (last_rc == EDS_OK) { std::memcpy(pp, cp, sizeof(cp)); std::memcpy(q, cq, sizeof(cq)); std::memcpy(v, cv, sizeof(cv)); }
     return last_rc;
+}
+
+// The same for pyramids [first, first + count) of a batched object: P, Q, V are count x 3 / 4 / 6 in and out; every level of all
+// of them is one eds_trk_optimize_batch launch, the states carried on the host between the levels (104 B per pyramid).
+// infos (optional): levels x count, level-major.  A pyramid whose level fails keeps its last good pose for the next level.
+int eds_pyr_optimize_batch(eds_pyr* p, int first, int count, double* P, double* Q, double* V, eds_trk_info* infos) {
+    if (!p || !P || !Q || !V) return eds_internal_fail(EDS_ERR_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > p->batch) return eds_internal_fail(EDS_ERR_INVALID, "range out of bounds");
+    for (int k = first; k < first + count; ++k)
+        if (!p->slot_has_frame[k]) return eds_internal_fail(EDS_ERR_STATE, "event frame not set");
+    for (int l = p->levels - 1; l >= 0; --l) {
+        eds_trk* h = p->lv[l];
+        int rc = eds_trk_set_states(h, first, count, P, Q, V);
+        if (rc) return rc;
+        rc = eds_trk_optimize_batch(h, l, first, count);
+        if (rc) return rc;
+        if ((rc = eds_trk_sync(h))) return rc;
+        if ((rc = eds_trk_get_states(h, first, count, P, Q, V))) return rc;     // a failed slot still holds the state it was given
+        if (infos)
+            for (int k = 0; k < count; ++k) eds_trk_get_info(h, first + k, &infos[(size_t)l * count + k]);
+    }
+    return EDS_OK;
 }
 
 int eds_pyr_get_residuals(eds_pyr* p, int level, double* r) {

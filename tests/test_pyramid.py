@@ -79,3 +79,37 @@ def test_config3_coarse_to_fine_single_call(gpu, capi, synth, po, solver):
     r0 = pyr.residuals(0)
     assert r0.shape == (16000,)
     pyr.close()
+
+
+@pytest.mark.gpu
+def test_batched_pyramids_match_single_ones_and_the_oracle(gpu, capi, synth, po):
+    """eds_pyr_create_batch: B pyramids in one object, one launch per level for all of them (bench.py's configs[3] leg).  Every pyramid
+    of the batch must end where the same pyramid ends when it is solved alone (eds_pyr_optimize), and the first one where the
+    oracle's level-by-level solve ends."""
+    import np_pyramid_oracle as pyo
+    counts, iters, H, W = [6000, 3000, 1500], [6, 6, 6], 240, 320
+    als = [synth.make_alignment(3300 + b, H=H, W=W, N=counts[0], rot_deg=0.6, trans_norm=0.012, blur_ksize=9, blur_sigma=2.5) for b in range(3)]
+    cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=6)
+    pb = capi.Pyramid(cfg, counts, H, W, batch=len(als))
+    singles = []
+    for b, al in enumerate(als):
+        one = capi.Pyramid(cfg, counts, H, W)
+        for l, n in enumerate(counts):
+            pb.set_keyframe_slot(b, l, al.norm_coord[:n], al.grad[:n], al.idp[:n], al.weights[:n], al.fx, al.fy, al.cx, al.cy)
+            one.set_keyframe(l, al.norm_coord[:n], al.grad[:n], al.idp[:n], al.weights[:n], al.fx, al.fy, al.cx, al.cy)
+        pb.set_event_frame_slot(b, al.frame)
+        one.set_event_frame(al.frame)
+        singles.append(one.optimize(al.p0, al.q0, al.v0))
+        one.close()
+    P, Q, V, infos = pb.optimize_batch(np.stack([a.p0 for a in als]), np.stack([a.q0 for a in als]), np.stack([a.v0 for a in als]))
+    for b, al in enumerate(als):
+        sp, sq, sv, sinfo = singles[b]
+        assert po.se3_distance(P[b], Q[b], sp, sq) <= 1e-9, b
+        for l in range(len(counts)):
+            assert infos[l][b]["num_iterations"] == sinfo[l]["num_iterations"] and infos[l][b]["num_points"] == counts[l]
+    rp, rq, rv, per_level = pyo.track(po, synth, als[0], counts, iters, solver="lm6")
+    assert po.se3_distance(P[0], Q[0], rp, rq) <= 1e-4
+    # a second call on the same object starts from what it is given, not from where the first ended
+    P2, Q2, V2, _ = pb.optimize_batch(np.stack([a.p0 for a in als]), np.stack([a.q0 for a in als]), np.stack([a.v0 for a in als]), want_infos=False)
+    assert np.array_equal(P2, P) and np.array_equal(Q2, Q)
+    pb.close()

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-$PWD}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_${1:-r02}
 rm -rf "$OUT"; mkdir -p "$OUT"
-ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu --no-shared}"
+ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu --no-shared --no-configs}"
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"

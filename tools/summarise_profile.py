@@ -53,7 +53,7 @@ bench = json.loads(open(os.path.join(src, "bench_plain.json")).read().strip().sp
 cfg = bench["config"]
 out = {"tag": tag, "bench_config": cfg, "bench_value": bench["value"], "kernels": {}}
 lines = [f"# rocprofv3 digest {tag}", "",
-         f"command: `python3 bench.py {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-cpu --no-shared')}` "
+         f"command: `python3 bench.py {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-cpu --no-shared --no-configs')}` "
          f"({cfg['alignments_per_gpu']} alignments x {cfg['points']} points, {cfg['iterations']} {cfg['solver']} iterations, {cfg['sampling']})",
          f"bench value (un-profiled run): {bench['value']:.4g} {bench['unit']}", "",
          "| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | raw HBM bytes/launch | raw GB/s |",
