@@ -216,6 +216,13 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #else
 #define EDS_STAMP2(k) do { } while (0)
 #endif
+#if defined(EDS_FUSED_STAMPS) && EDS_FUSED_STAMPS == 3
+    __shared__ unsigned s_miss_total, s_pass_total;      // diagnostic build 3: patches gathered / passes run (cache hit rate)
+    if (tid == 0) { s_miss_total = 0; s_pass_total = 0; }
+#define EDS_COUNT_MISS(m) do { const unsigned long long bal_ = __ballot(m); if (lane == 0) atomicAdd(&s_miss_total, (unsigned)__popcll(bal_)); } while (0)
+#else
+#define EDS_COUNT_MISS(m) do { } while (0)
+#endif
     float rcand[NREG], racc[NREG];      // residuals of the pass in flight / of the accepted pose (PPT > 0)
 #pragma unroll
     for (int j = 0; j < NREG; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
             float* __restrict__ zone = &s_patch[0][0] + wave_u * (NREG * 4 * 256);
             const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
-            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * (2u * (size_t)copy_bytes);
+            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
             const unsigned row_add = 0x80000000u + 32u * (unsigned)jr;
 #pragma unroll
             for (int g = 0; g < NPAIR; ++g) {
@@ -262,9 +269,10 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     const int j = 2 * g + e, i = tid + j * nthr;
                     const int key = (r0[e] << 16) ^ (c0[e] & 0xffff);
                     const bool miss = s_cell[i] != key;
+                    EDS_COUNT_MISS(miss && i < N);
                     if (miss) s_cell[i] = key;
                     const int ra = clampi(r0[e], -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca = clampi(c0[e], -2, frame.W) + (EDS_FRAME_MARGIN - 1);
-                    const int off = (int)(eds_strips_row_offset(ra, ca, A.Hp, copy_bytes) | (miss ? 0x80000000u : 0u));
+                    const int off = (int)(eds_strips_row_offset(ra, ca, A.Hp, copy_bytes, A.strip_phases) | (miss ? 0x80000000u : 0u));
                     const int o0 = quad_bcast_i<0>(off), o1 = quad_bcast_i<1>(off), o2 = quad_bcast_i<2>(off), o3 = quad_bcast_i<3>(off);
                     const int oq[4] = {o0, o1, o2, o3};
 #pragma unroll
@@ -494,6 +502,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             }
         }
         EDS_STAMP(1);
+#if defined(EDS_FUSED_STAMPS) && EDS_FUSED_STAMPS == 3
+        if (tid == 0) ++s_pass_total;
+#endif
         wave_reduce_scatter<EDS_RED_K6>(acc, lane);
         if (lane < 32) s_red[wave][wave_red_index<EDS_RED_K6>(lane, 0)] = acc[0];
         EDS_STAMP2(1);
@@ -684,6 +695,10 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
 #if EDS_FUSED_STAMPS == 2
     if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
+#endif
+#if EDS_FUSED_STAMPS == 3
+    __syncthreads();
+    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)s_miss_total; out[slot].pad[1] = (double)s_pass_total; out[slot].pad[2] = (double)N; }
 #endif
 #endif
 
@@ -909,7 +924,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         const bool q = bic && count * team >= 128 && h->H < 8000;   // enough gathers in flight for the quad-cooperative form to pay
         // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member)
         const bool strips = q && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_prepare(h, first, count);
-        A.strips = h->dstrips;
+        A.strips = h->dstrips; A.strip_phases = h->strip_phases;
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
         const int per_launch = EDS_TEAM_MEMBERS / team, whole_first = first, whole_count = count;
@@ -957,7 +972,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
     // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
     const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);
-    A.strips = h->dstrips;
+    A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     if (strips) {
         if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }
         else { if (hub) EDS_LAUNCH_FUSED(0, 4, 512, 4); else EDS_LAUNCH_FUSED(0, 4, 512, 3); }
@@ -1059,8 +1074,13 @@ int eds_fused_collect(eds_trk* h) {
         for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s)
             for (int k = 0; k < 3; ++k) a[k] += fb.h_out[s].pad[k];
         const double n = fb.pending_count, passes = fb.h_out[fb.pending_first].iterations + 2.0;
+#if EDS_FUSED_STAMPS == 3
+        fprintf(stderr, "[stamps3] patches gathered %.0f of %.0f point-passes (%.1f passes per alignment): miss rate %.3f (mean over %d slots)\n",
+                a[0] / n, a[1] / n * a[2] / n, a[1] / n, a[0] / (a[1] * a[2] / n), fb.pending_count);
+#else
         fprintf(stderr, "[stamps] lane-0 cycles per pass: points %.0f  reduce %.0f  solver %.0f  (mean over %d slots, %g passes)\n",
                 a[0] / n / passes, a[1] / n / passes, a[2] / n / passes, fb.pending_count, passes);
+#endif
     }
 #endif
     fb.pending_count = 0;

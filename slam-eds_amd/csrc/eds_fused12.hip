@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             const int jr = lane & 3;
             const float* __restrict__ tiles = A.frame + (size_t)fslot * A.Hp * A.Wp;
             const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
-            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * (2u * (size_t)copy_bytes);
+            const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     if (miss[jj] && cached) s_cell[li] = key;
                     if (QUAD == 2) {            // strips: the byte offset of the patch's first row (cached: offset 0, as below)
                         const int ra_ = clampi(pg[jj].r0, -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca_ = clampi(pg[jj].c0, -2, frame.W) + (EDS_FRAME_MARGIN - 1);
-                        org[jj] = miss[jj] ? (int)(eds_strips_row_offset(ra_, ca_, A.Hp, copy_bytes) | 0x80000000u) : 0;
+                        org[jj] = miss[jj] ? (int)(eds_strips_row_offset(ra_, ca_, A.Hp, copy_bytes, A.strip_phases) | 0x80000000u) : 0;
                         continue;
                     }
                     org[jj] = miss[jj] ? (pack_origin(frame, pg[jj].r0, pg[jj].c0) | (int)0x80000000) : 0;     // cached: origin 0 — its (unused) row loads fall on the first line of the allocation: no branch around the loads (+3 %)
@@ -592,7 +592,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     // QUAD = 2: the same gather on the strip copies of the frames (EDS_FUSED_LAYOUT=tiles keeps the tiles; so does a failed allocation)
     const bool strips = quad && want_strips && eds_strips_prepare(h, first, count);
     if (want_strips && !strips && count < 1024) quad = false;         // (no room for the copies: the tiles' rule)
-    A.strips = h->dstrips;
+    A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }
     else if (team == 8) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 8, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 8, 0); }
     else if (team == 4) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 4, 2); else if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }

@@ -43,6 +43,7 @@ struct eds_trk {
     int* dcell0 = nullptr;
     float *dmhat = nullptr, *dframe = nullptr, *dr = nullptr, *dJ = nullptr;
     float* dstrips = nullptr;           // strip layout of the frames, allocated by the first solve that uses it (eds_strips.hip)
+    int strip_phases = 1;               // its row phases (eds_layout.hpp), fixed when it is allocated
     EdsFusedBuffers fused;
     EdsFrameBuffers frame_build;
     EdsPointBuffers point_ops;
@@ -66,7 +67,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.strips = dstrips; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.strips = dstrips; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

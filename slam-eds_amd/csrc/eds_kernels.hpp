@@ -15,7 +15,8 @@ struct EdsArrays {
     float* mhat;                                            // normalised model (pose-only solvers)
     // frames [B][Hp*Wp]
     const float* frame;
-    const float* strips;   // [B][2][strips copy] or null: the strip layout of the same frames (eds_layout.hpp), valid for the slots a solve asked for
+    const float* strips;   // [B][2 * strip_phases][strips copy] or null: the strip layout of the same frames (eds_layout.hpp), valid for the slots a solve asked for
+    int strip_phases;      // row phases of the strip copies: 1, 2 or 4
     // per-slot constants
     double* pose;        // [B][EDS_POSE_STRIDE]
     double* G;           // [B][EDS_MAX_BLOCKS][36]

@@ -92,9 +92,18 @@ EDS_LAYOUT_HD static inline size_t eds_frame_index(int r, int c, int Wp, int til
 // tiles, filled by one conversion launch when a solve finds a slot's strips out of date (eds_strips.hip).
 EDS_LAYOUT_HD static inline int eds_strips_count(int Wp) { return (Wp + 7) >> 3; }
 EDS_LAYOUT_HD static inline size_t eds_strips_copy_elems(int Hp, int Wp) { return (size_t)eds_strips_count(Wp) * Hp * 8; }
-// byte offset, from the start of a frame's strips, of the 4 taps at allocation row ra, allocation columns ca .. ca + 3
-EDS_LAYOUT_HD static inline unsigned eds_strips_row_offset(int ra, int ca, int Hp, unsigned copy_bytes) {
-    const int copy = ((ca & 7) + 3) >> 3;            // columns 5, 6, 7 (mod 8) would cross a strip of copy 0
+// ROW PHASES.  The L2 fills whole 128-byte lines from the fabric, and the gather is bound by exactly those fills
+// (profiles/r03_summary.md: 1.64 fabric requests per gathered patch on plain strips, where the 128 bytes of a patch start at
+// any multiple of 32).  With `phases` = 2 or 4 every (column) copy exists `phases` times, copy p holding allocation row r at position
+// r - p: a patch whose first row is ra reads copy p = ra mod phases, where its 128 bytes start at a multiple of 64 / 128 bytes —
+// with 4 phases a patch is exactly ONE line.  Measured (tools/ubench_gather_lds.hip, 256 frames in flight): 36.9 / 40.5 / 58.0 G
+// patches/s for 1 / 2 / 4 phases.  A frame then costs 2 x phases x its bytes (8 copies: 10 MB per 640x480 frame — memory a
+// 288 GB part has; the conversion writes them once per frame, eds_strips.hip).
+// byte offset, from the start of a frame's strips, of the 4 taps at allocation row ra + k (k = 0 .. 3 rows: add 32 k), allocation
+// columns ca .. ca + 3; copy_bytes = bytes of one copy, phases in {1, 2, 4}
+EDS_LAYOUT_HD static inline unsigned eds_strips_row_offset(int ra, int ca, int Hp, unsigned copy_bytes, int phases = 1) {
+    const int copy = ((ca & 7) + 3) >> 3;            // columns 5, 6, 7 (mod 8) would cross a strip of column copy 0
     const int cc = ca - 4 * copy;
-    return (unsigned)copy * copy_bytes + (unsigned)((((cc >> 3) * Hp + ra) << 5) + ((cc & 7) << 2));
+    const int p = ra & (phases - 1);
+    return (unsigned)(2 * p + copy) * copy_bytes + (unsigned)((((cc >> 3) * Hp + (ra - p)) << 5) + ((cc & 7) << 2));
 }

@@ -6,32 +6,46 @@
 // strip (reads 2 x 1.26 MB, writes 2.5 MB per 640x480 frame: ~1 us per frame at the rates the batched image passes reach).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "eds_fused.hpp"
 #include "eds_handle.hpp"
 #include "eds_layout.hpp"
 
-// grid: (pieces of one frame's strips / 256, slots of the run)
-__global__ __launch_bounds__(256) void k_tiles_to_strips(const float* __restrict__ tiles, float* __restrict__ strips, int first, int Hp, int Wp) {
+// grid: (pieces of one frame's strips / 256, slots of the run); copy index = 2 * row phase + column copy
+__global__ __launch_bounds__(256) void k_tiles_to_strips(const float* __restrict__ tiles, float* __restrict__ strips, int first, int Hp, int Wp, int phases) {
     const int slot = first + blockIdx.y;
     const int NS = eds_strips_count(Wp), TW = Wp >> 2;
     const int per_copy = NS * Hp * 2;                       // 16-byte pieces per copy
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * per_copy) return;
-    const int copy = i >= per_copy, k = i - copy * per_copy;
-    const int half = k & 1, row = (k >> 1) % Hp, strip = (k >> 1) / Hp;
+    if (i >= 2 * phases * per_copy) return;
+    const int cidx = i / per_copy, k = i - cidx * per_copy;
+    const int copy = cidx & 1, p = cidx >> 1;
+    const int half = k & 1, pos = (k >> 1) % Hp, strip = (k >> 1) / Hp;
+    int row = pos + p;                                      // copy p holds allocation row r at position r - p
+    if (row > Hp - 1) row = Hp - 1;                         // (its last p positions are never sampled)
     int col0 = 8 * strip + 4 * copy + 4 * half;             // allocation column of the piece's first pixel: a multiple of 4 = one tile row
     if (col0 > Wp - 4) col0 = Wp - 4;                       // past the allocation (last strip of the shifted copy): never sampled, any finite filler
     const float4 v = *reinterpret_cast<const float4*>(tiles + (size_t)slot * Hp * Wp + ((size_t)(row >> 2) * TW + (col0 >> 2)) * 16 + ((row & 3) << 2));
-    *reinterpret_cast<float4*>(strips + (size_t)slot * 2 * eds_strips_copy_elems(Hp, Wp) + (size_t)i * 4) = v;
+    *reinterpret_cast<float4*>(strips + (size_t)slot * 2 * phases * eds_strips_copy_elems(Hp, Wp) + (size_t)i * 4) = v;
 }
 
 bool eds_strips_prepare(eds_trk* h, int first, int count) {
     if (!h->tiled) return false;
-    const size_t per_frame = 2 * eds_strips_copy_elems(h->Hp, h->Wp);
     if (!h->dstrips) {
-        if (hipMalloc((void**)&h->dstrips, (size_t)h->B * per_frame * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); h->dstrips = nullptr; return false; }
+        // row phases (eds_layout.hpp): 4 — one 128-byte line per patch — for handles that hold batches, whose solves are bound by the
+        // fabric's line fills; 1 for the handles of the latency regime (a lone alignment is not bandwidth-bound, and its frame changes
+        // with every call: 2.5 MB of copies to write instead of 10).  EDS_STRIPS_PHASES=1|2|4 overrides; less memory -> fewer phases.
+        int phases = h->B >= 32 ? 4 : 1;
+        if (const char* ev = getenv("EDS_STRIPS_PHASES")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) phases = v; }
+        for (; phases >= 1; phases >>= 1) {
+            const size_t bytes = (size_t)h->B * 2 * phases * eds_strips_copy_elems(h->Hp, h->Wp) * sizeof(float);
+            if (hipMalloc((void**)&h->dstrips, bytes) == hipSuccess) break;
+            (void)hipGetLastError(); h->dstrips = nullptr;
+        }
+        if (!h->dstrips) return false;
+        h->strip_phases = phases;
     }
     // the slots whose storage is sampled: a slot's own, or the one it shares (eds_trk_share_event_frame)
     std::vector<char> stale(h->B, 0);
@@ -42,12 +56,12 @@ bool eds_strips_prepare(eds_trk* h, int first, int count) {
         if (src.strips_version != src.frame_version || src.strips_version == 0) { stale[fs] = 1; any = true; }
     }
     if (!any) return true;
-    const int pieces = 2 * eds_strips_count(h->Wp) * h->Hp * 2;
+    const int pieces = 2 * h->strip_phases * eds_strips_count(h->Wp) * h->Hp * 2;
     for (int s = 0; s < h->B;) {
         if (!stale[s]) { ++s; continue; }
         int e = s;
         while (e < h->B && stale[e] && e - s < 65535) ++e;
-        hipLaunchKernelGGL(k_tiles_to_strips, dim3((pieces + 255) / 256, e - s), dim3(256), 0, h->st, h->dframe, h->dstrips, s, h->Hp, h->Wp);
+        hipLaunchKernelGGL(k_tiles_to_strips, dim3((pieces + 255) / 256, e - s), dim3(256), 0, h->st, h->dframe, h->dstrips, s, h->Hp, h->Wp, h->strip_phases);
         for (int k = s; k < e; ++k) {
             if (h->slots[k].frame_version == 0) h->slots[k].frame_version = 1;       // (frames written before versions were kept)
             h->slots[k].strips_version = h->slots[k].frame_version;

@@ -16,3 +16,10 @@ rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" --output-format csv -- python3 be
 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum -d "$OUT/pmc_l2" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_l2.json" 2> "$OUT/l2.err"
 find "$OUT" -name "*.csv" | head -40
 du -sh "$OUT"
+# gpurun copies back at most 64 MiB: summarise here, keep the digests (they go to profiles/ by hand afterwards), drop the per-dispatch tables
+python3 tools/summarise_profile.py "${1:-r02}" > "$OUT/summarise.log" 2>&1
+mkdir -p "gpurun_out/profiles_${1:-r02}"
+cp profiles/${1:-r02}_* profiles/traffic_${1:-r02}.json "gpurun_out/profiles_${1:-r02}/" 2>/dev/null
+find "$OUT" -name "*_kernel_trace.csv" -delete
+find "$OUT" -name "*_counter_collection.csv" -size +4M -delete
+du -sh "$OUT"

@@ -10,6 +10,10 @@
 //   W0  quad rows, 64-B tiles  -> VGPRs  (two aligned 16-B loads per row: what eds_fused6_kernel does today)
 //   W1  quad rows, strips      -> VGPRs  (one unaligned 16-B load per row)
 //   W2  quad rows, strips      -> LDS    (global_load_lds_dwordx4, rows read back with ds_read_b128)
+//   W3  as W2 with every strip copy stored twice more, the second one row later: a patch whose first row is odd reads the shifted copy,
+//       so its 128 contiguous bytes always start on a 64-byte boundary — exactly 2 sectors per patch instead of 2.5 (4 copies in all)
+//   W4  four row phases (8 copies in all): the 128 bytes of a patch always start on a 128-byte boundary = ONE L2 line per patch
+//       (the L2 fills whole 128-byte lines from the fabric: profiles/r03_summary.md — 1.64 fabric requests per gathered patch on 2 copies)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -54,8 +58,8 @@ template <int MODE>
 __global__ __launch_bounds__(512) void gather(const float* __restrict__ buf, float* out, int passes, size_t frame_stride, int amp) {
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Hp = 488, TWt = 162;
-    const float* __restrict__ frame = buf + (size_t)b * 2 * frame_stride;
-    __shared__ __attribute__((aligned(16))) float land[MODE == 2 ? 8 : 1][MODE == 2 ? 16 : 1][64 * 4];      // [wave][j * 4 + q][lane * 4]: 128 KB
+    const float* __restrict__ frame = buf + (size_t)b * 8 * frame_stride;
+    __shared__ __attribute__((aligned(16))) float land[MODE >= 2 ? 8 : 1][MODE >= 2 ? 16 : 1][64 * 4];      // [wave][j * 4 + q][lane * 4]: 128 KB
     float acc = 0.f;
     const int row = tid & 3;
     for (int r = 0; r < passes; ++r) {
@@ -93,7 +97,12 @@ __global__ __launch_bounds__(512) void gather(const float* __restrict__ buf, flo
                 for (int q = 0; q < 4; ++q) {
                     int r0, c0;
                     point_pos(b, j * 512 + (tid & ~3) + q, sh, sv, r0, c0);
-                    __builtin_amdgcn_global_load_lds((glb_ptr)strip_row(frame, frame_stride, Hp, r0 - 1 + row, c0 - 1), (lds_ptr)&land[wave][4 * j + q][0], 16, 0, 0);
+                    const float* src = strip_row(frame, frame_stride, Hp, r0 - 1 + row, c0 - 1);
+                    if (MODE >= 3) {                     // row-phase copy: rows stored rp positions earlier, behind the two plain copies
+                        const int rp = (r0 - 1) & (MODE == 3 ? 1 : 3);
+                        src = strip_row(frame + rp * 2 * frame_stride, frame_stride, Hp, r0 - 1 + row - rp, c0 - 1);
+                    }
+                    __builtin_amdgcn_global_load_lds((glb_ptr)src, (lds_ptr)&land[wave][4 * j + q][0], 16, 0, 0);
                 }
             __builtin_amdgcn_s_waitcnt(0);                // vmcnt(0): the rows have landed (each lane reads back only what it wrote)
 #pragma unroll
@@ -133,7 +142,7 @@ int main(int argc, char** argv) {
     const int Gmax = 512;
     const int amp = argc > 1 ? atoi(argv[1]) : 5;
     printf("shift amplitude %d px, 512-thread workgroups (one per CU up to 256), 16 row loads per lane per pass\n", amp);
-    (void)hipMalloc(&buf, 2 * Gmax * frame_stride * 4); (void)hipMemset(buf, 0, 2 * Gmax * frame_stride * 4);
+    (void)hipMalloc(&buf, 8 * Gmax * frame_stride * 4); (void)hipMemset(buf, 0, 8 * Gmax * frame_stride * 4);
     (void)hipMalloc(&out, (size_t)Gmax * 512 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int Gs[] = {64, 128, 256, 512};
@@ -149,6 +158,8 @@ int main(int argc, char** argv) {
         RUN(0, "W0 quad rows, tiles  -> VGPR");
         RUN(1, "W1 quad rows, strips -> VGPR");
         RUN(2, "W2 quad rows, strips -> LDS ");
+        RUN(3, "W3 W2 + 2 row phases (x4)   ");
+        RUN(4, "W4 W2 + 4 row phases (x8)   ");
     }
     return 0;
 }
