@@ -100,8 +100,23 @@ void reduce_geometry(int N, int nb_red, int* cpb, int* nseg) {
 
 // One residual/Jacobian pass + reduction over slots [first, first+count) at the poses currently
 // in h_pose; brings the partial sums back to h_part.
+// The streaming residual/Jacobian kernel samples the strip copies of the frames (eds_layout.hpp) when they are worth making: batches
+// (every frame is touched by every pass of a host-driven solve or of a benchmark loop), or whenever a solve has made them already.
+// Returns the arrays with `strips` set only if the copies of this range are current.
+static EdsArrays arrays_for_pass(eds_trk* h, int first, int count) {
+    EdsArrays A = h->arrays();
+    bool ok = false;
+    if (h->tiled && h->cfg.sampling == EDS_SAMPLE_BICUBIC && h->H < 8000) {
+        const char* ev = getenv("EDS_FUSED_LAYOUT");
+        if (!(ev && std::strcmp(ev, "tiles") == 0) && (count >= 32 || h->dstrips)) ok = eds_strips_prepare(h, first, count);
+    }
+    A.strips = ok ? h->dstrips : nullptr;
+    A.strip_phases = h->strip_phases;
+    return A;
+}
+
 int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bool with_reduction, bool fetch) {
-    const EdsArrays A = h->arrays();
+    const EdsArrays A = arrays_for_pass(h, first, count);
     const int N = max_points(h, first, count);
     if (N <= 0) return fail(EDS_ERR_STATE, "no keyframe set");
     const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
@@ -1021,7 +1036,7 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     int rc = run_pass(h, first, count, ncols, true, with_reduction != 0, false);   // warm-up + model
     if (rc) return rc;
     EDS_HIP_TRY(hipStreamSynchronize(h->st));
-    const EdsArrays A = h->arrays();
+    const EdsArrays A = arrays_for_pass(h, first, count);
     const int N = max_points(h, first, count);
     const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
     const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;

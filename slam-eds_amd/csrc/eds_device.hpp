@@ -376,6 +376,35 @@ __device__ __forceinline__ void project_sample_quad(const FrameView& frame, cons
     finish_point(ps, g, E, Er, Ec, o);
 }
 
+// The same on the STRIP copies of the frame (eds_layout.hpp; round 3): the owner of a point computes the byte offset of its patch's
+// first row once, it goes round the quad, and lane j reads row j of each of the quad's four patches with ONE 16-byte load at a
+// 4-byte-aligned address (no second piece, no barrel shift).  `sbase`: start of the frame's strips; Hp: allocated rows;
+// copy_bytes / phases: the strip geometry.  Same arithmetic after the loads as project_sample_quad.
+__device__ __forceinline__ void project_sample_quad_strips(const FrameView& frame, const char* __restrict__ sbase, int Hp, unsigned copy_bytes, int phases,
+                                                           const PoseF& ps, const PointKf& k, bool valid, int lane, PointProj& o) {
+    PointGeom g;
+    project_point(ps, k, g);
+    const int ra = clampi(g.r0, -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca = clampi(g.c0, -2, frame.W) + (EDS_FRAME_MARGIN - 1);
+    const int off = valid ? (int)eds_strips_row_offset(ra, ca, Hp, copy_bytes, phases) : 0;
+    const int o0 = quad_bcast_i<0>(off), o1 = quad_bcast_i<1>(off), o2 = quad_bcast_i<2>(off), o3 = quad_bcast_i<3>(off);
+    const int oq[4] = {o0, o1, o2, o3};
+    const float x0 = quad_bcast_f<0>(g.ax), x1 = quad_bcast_f<1>(g.ax), x2 = quad_bcast_f<2>(g.ax), x3 = quad_bcast_f<3>(g.ax);
+    const float xq[4] = {x0, x1, x2, x3};
+    const unsigned jr32 = 32u * (unsigned)(lane & 3);
+    float4u t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4u*>(sbase + ((unsigned)oq[q] + jr32));
+    float f[4], d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hermite(t[q].x, t[q].y, t[q].z, t[q].w, xq[q], f[q], d[q]);
+    quad_transpose(f, lane);
+    quad_transpose(d, lane);
+    float E, Er, Ec, unused;
+    hermite(f[0], f[1], f[2], f[3], g.ay, E, Er);
+    hermite(d[0], d[1], d[2], d[3], g.ay, Ec, unused);
+    finish_point(ps, g, E, Er, Ec, o);
+}
+
 // SE(3) left-perturbation row: J = -w [gradE_P, P x gradE_P]  (= DSO's row, CoarseTracker.cpp:311-321)
 __device__ __forceinline__ void jacobian6(const PointProj& pp, float w, float (&J)[6]) {
     J[0] = -w * pp.g0;

@@ -67,7 +67,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.strips = dstrips; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.strips = nullptr /* set by the launch sites that made sure the copies are current */; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

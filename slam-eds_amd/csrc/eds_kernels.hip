@@ -114,8 +114,14 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
     kf.f0x = A.f0x[o]; kf.f0y = A.f0y[o]; kf.cell0 = A.cell0[o];
     PointProj pp;
     if (quad) {
-        const int fslot = (int)pb[EDS_PB_FRAME];
-        project_sample_quad(frame, A.frame + (size_t)fslot * A.Hp * A.Wp, ps, kf, i < N, threadIdx.x & 63, pp);
+        const int fslot = __builtin_amdgcn_readfirstlane((int)pb[EDS_PB_FRAME]);
+        if (A.strips) {                  // the strip copies of the frames are current for this range (the host checked): one load per patch row
+            const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
+            const char* sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
+            project_sample_quad_strips(frame, sbase, A.Hp, copy_bytes, A.strip_phases, ps, kf, i < N, threadIdx.x & 63, pp);
+        } else {
+            project_sample_quad(frame, A.frame + (size_t)fslot * A.Hp * A.Wp, ps, kf, i < N, threadIdx.x & 63, pp);
+        }
         if (i >= N) return;
     } else {
         project_sample<SAMPLING>(frame, ps, kf, pp);
