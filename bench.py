@@ -584,6 +584,12 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj,
         }
+        if a.exec_ == "device" and a.sampling == "bicubic":
+            # what the frame layout of the timed kernel costs to make: the strip copies of all B frames converted again (HIP events)
+            prep_ms = h.prepare_frames(0, B, force=True)
+            out["frame_layout_prep"] = {"ms_for_batch": prep_ms, "us_per_frame": 1e3 * prep_ms / B,
+                                        "note": "outside the timed region (inputs resident): one conversion launch per new frame set, tiles -> strip copies "
+                                                "(csrc/eds_layout.hpp); it is paid once per event frame, not per solve"}
         if a.exec_ == "device":
             out["launch_digest"] = dict(launch_digest, note="the timed kernel's last launch, from its workgroups' own begin / end stamps: covered = sum of "
                                         "workgroup durations / (256 CUs x span); tail_idle_us = mean idle time of a CU behind its last workgroup")

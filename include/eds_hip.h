@@ -181,6 +181,22 @@ int eds_trk_build_event_frame(eds_trk* h, int slot, int n_events, const uint16_t
 int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, int n_events, const void* events, int stride, int off_x,
                                    int off_y, int off_polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights,
                                    double* norms);
+/* The time bookkeeping EventFrame::create does on the same container before it draws the frame (EventFrame.cpp:313-335): first_time =
+ * events[0].ts, last_time = events[n-1].ts (set in the `else if` branch of the loop: a single event leaves it where clear() put it —
+ * reported here as `last_valid` = 0), time = events[n/2].ts (the "median" is the middle ELEMENT of the time-ordered slice), delta_time =
+ * last - first; all in the unit of the records' ts field (base::Time: int64 microseconds at byte offset off_ts).  A slice whose first
+ * time stamp is later than its last is the reference's `throw std::runtime_error("[EVENT_FRAME] FATAL ERROR Event time[0] > event
+ * time [N-1]")`: EDS_ERR_INVALID, and nothing is built. */
+typedef struct eds_event_times {
+    int64_t first_time, last_time, time, delta_time;
+    int32_t last_valid, reserved;
+} eds_event_times;
+int eds_event_times_aos(int n_events, const void* events, int stride, int off_ts, eds_event_times* out);
+/* eds_trk_build_event_frames_aos preceded by that bookkeeping, in the reference's order: the time check first (on failure no frame is
+ * touched), then the frames.  off_ts: byte offset of the int64 time stamp inside a record (8-byte aligned). */
+int eds_trk_build_event_frames_aos_timed(eds_trk* h, int first_slot, int num_levels, int n_events, const void* events, int stride, int off_x,
+                                         int off_y, int off_polarity, int off_ts, int sensor_H, int sensor_W, double blur_sigma,
+                                         int use_exp_weights, double* norms, eds_event_times* times);
 /* The batched tracker's counterpart (BASELINE.json configs[4]: one event frame per alignment): `count` independent event slices into
  * slots first_slot .. first_slot + count - 1 in one pass over the device per 32 slices — slice b's events are elements
  * offsets[b] .. offsets[b + 1] - 1 of x / y / polarity (offsets: count + 1 non-decreasing ints), each slice in time order, all at the
@@ -275,7 +291,8 @@ typedef struct eds_kf_select {
                                      * pixel above its cell's median (KeyFrame::candidatePoints, KeyFrame.cpp:740-823) */
     int32_t cell;                   /* cell edge in pixels; the reference uses cv::Size(20, 20) (KeyFrame.cpp:408); <= 32 */
     int32_t num_points;             /* MAX only: the reference passes rows*cols*percent_points/100 (KeyFrame.cpp:406-409) */
-    int32_t reserved;
+    int32_t sobel_ksize;            /* aperture of cv::Sobel: 3 (KeyFrame::create, KeyFrame.cpp:384-385; 0 means 3) or 7 (the KeyFrame constructor,
+                                     * KeyFrame.cpp:239-240: kernels [1 6 15 20 15 6 1] x [-1 -4 -5 0 5 4 1], un-normalised — gradients 256 times larger) */
     double  min_depth, max_depth;   /* without a depth map every point starts at idp = 1/((max-min)/2) (KeyFrame.cpp:1186-1192) */
     double  weight_threshold;       /* KeyFrame::cleanPoints(0.7) (KeyFrame.cpp:451,1566-1587) */
 } eds_kf_select;
@@ -349,6 +366,14 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the 
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
 /* What the last on-device solve (eds_trk_optimize / _optimize_batch with exec = device) actually launched — so that a benchmark
  * prices the kernel that ran instead of mirroring the library's selection rule. */
+/* The persistent kernels (and the streaming residual/Jacobian kernel on batches) gather from STRIP COPIES of the event frames
+ * (csrc/eds_layout.hpp): 8-column-wide strips stored 2 x `phases` times so that every bicubic 4x4 patch is ONE 128-byte L2 line.
+ * The frame writers keep writing the 4x4 tiles; a solve converts the slots whose copy is out of date before it launches.  This call
+ * does that conversion NOW for slots [first, first + count) — to take it off a latency-critical optimize, or (force != 0: convert
+ * even what is current) to measure it: elapsed_ms (optional) = HIP events around the conversion launches.  No-op for handles that
+ * never use the copies (bilinear sampling, row-major layout). */
+int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* elapsed_ms);
+
 typedef struct eds_trk_launch_info {
     char    kernel[96];             /* e.g. "eds_fused6_kernel<0, 4, 512, 3, 1>": name and template arguments as rocprofv3 prints them */
     int32_t workgroups;             /* of the last launch of the call (a range may go out in several team launches) */

@@ -105,6 +105,23 @@ def sobel3(L):
     return gx, gy
 
 
+def sobel7(L):
+    """cv::Sobel(L, CV_64F, 1, 0, 7) and (0, 1, 7) — the KeyFrame constructor's aperture (reference KeyFrame.cpp:239-240): separable
+    kernels smooth [1 6 15 20 15 6 1] and derivative [-1 -4 -5 0 5 4 1] (cv::getSobelKernels), border reflect-101, no scale; row pass
+    then column pass, centre term first and the symmetric pairs outwards (the order the device code reproduces bit for bit)."""
+    p = np.pad(L, 3, mode="reflect")
+    H, W = L.shape
+    def col(j):                                 # column c + j - 3 of every padded row
+        return p[:, j:j + W]
+    rs = ((20.0 * col(3) + 15.0 * (col(4) + col(2))) + 6.0 * (col(5) + col(1))) + (col(6) + col(0))
+    rd = (5.0 * (col(4) - col(2)) + 4.0 * (col(5) - col(1))) + (col(6) - col(0))
+    def row(a, k):
+        return a[k:k + H]
+    gx = ((20.0 * row(rd, 3) + 15.0 * (row(rd, 4) + row(rd, 2))) + 6.0 * (row(rd, 5) + row(rd, 1))) + (row(rd, 6) + row(rd, 0))
+    gy = (5.0 * (row(rs, 4) - row(rs, 2)) + 4.0 * (row(rs, 5) - row(rs, 1))) + (row(rs, 6) - row(rs, 0))
+    return gx, gy
+
+
 def magnitude(gx, gy):
     return np.sqrt(gx * gx + gy * gy)
 
@@ -156,11 +173,11 @@ def set_depth_map(coord, depth_xy, depth_idp, min_depth, max_depth):
 
 
 def keyframe(img, K, method=MEDIAN, num_points=0, cell=20, depth_xy=None, depth_idp=None, min_depth=1.0, max_depth=3.0,
-             weight_threshold=0.7):
+             weight_threshold=0.7, sobel_ksize=3):
     """The arrays KeyFrame::create leaves behind for the tracker (index-aligned, after cleanPoints)."""
     fx, fy, cx, cy = K
     L = normalise_log(img)
-    gx, gy = sobel3(L)
+    gx, gy = sobel7(L) if sobel_ksize == 7 else sobel3(L)
     mag = magnitude(gx, gy)
     pts = candidate_points(mag, cell, method, num_points)
     coord = pts.astype(np.float64)

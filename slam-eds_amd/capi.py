@@ -33,14 +33,14 @@ EXPORTS = (
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
     "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_idepth_strided", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
-    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos",
+    "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos", "eds_trk_build_event_frames_aos_timed", "eds_event_times_aos",
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
-    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_last_launch",
+    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_last_launch", "eds_trk_prepare_frames",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
     "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
@@ -53,7 +53,7 @@ _ip = C.POINTER(C.c_int32)
 
 class KfSelect(C.Structure):
     """``eds_kf_select`` — the arguments of KeyFrame::create that steer the point set-up (KeyFrame.cpp:333-341)."""
-    _fields_ = [("method", C.c_int32), ("cell", C.c_int32), ("num_points", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("method", C.c_int32), ("cell", C.c_int32), ("num_points", C.c_int32), ("sobel_ksize", C.c_int32),
                 ("min_depth", C.c_double), ("max_depth", C.c_double), ("weight_threshold", C.c_double)]
 
 
@@ -77,6 +77,21 @@ class Info(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "pad_"}
+
+
+class EventTimes(C.Structure):
+    """``eds_event_times`` — EventFrame::create's time bookkeeping (EventFrame.cpp:313-335)."""
+    _fields_ = [("first_time", C.c_int64), ("last_time", C.c_int64), ("time", C.c_int64), ("delta_time", C.c_int64),
+                ("last_valid", C.c_int32), ("reserved", C.c_int32)]
+
+
+def event_times(events) -> dict:
+    """first / last / middle-element time stamp and their difference of a structured event array with an int64 field `ts`;
+    raises EdsError(ERR_INVALID) when events[0].ts > events[-1].ts, like the reference's throw."""
+    ev = np.ascontiguousarray(events)
+    t = EventTimes()
+    _check(lib().eds_event_times_aos(int(ev.shape[0]), ev.ctypes.data_as(C.c_void_p), int(ev.dtype.itemsize), int(ev.dtype.fields["ts"][1]), C.byref(t)))
+    return {k: getattr(t, k) for k, _ in t._fields_ if k != "reserved"}
 
 
 class LaunchInfo(C.Structure):
@@ -148,6 +163,9 @@ def lib():
                                                  C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_build_event_frames_aos.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                      C.c_int, C.c_int, C.c_double, C.c_int, _dp]
+        L.eds_trk_build_event_frames_aos_timed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                           C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _dp, C.POINTER(EventTimes)]
+        L.eds_event_times_aos.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(EventTimes)]
         L.eds_trk_build_event_frame_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
                                                       C.POINTER(C.c_uint8), C.c_int, C.c_double, C.c_int, _dp]
         L.eds_trk_share_event_frame.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -338,6 +356,18 @@ class Handle:
                                                     float(blur_sigma), int(bool(use_exp_weights)), _p(norms)))
         return norms
 
+    def build_event_frames_aos_timed(self, first_slot, num_levels, events, sensor_size=None, blur_sigma=0.5, use_exp_weights=True):
+        """As build_event_frames_aos on records that also carry `ts` (int64): returns (norms, times dict); the time check comes first."""
+        ev = np.ascontiguousarray(events)
+        f = ev.dtype.fields
+        sH, sW = sensor_size if sensor_size is not None else (0, 0)
+        norms = np.zeros(num_levels)
+        t = EventTimes()
+        _check(lib().eds_trk_build_event_frames_aos_timed(self._h, int(first_slot), int(num_levels), int(ev.shape[0]), ev.ctypes.data_as(C.c_void_p),
+                                                          int(ev.dtype.itemsize), int(f["x"][1]), int(f["y"][1]), int(f["polarity"][1]), int(f["ts"][1]),
+                                                          int(sH), int(sW), float(blur_sigma), int(bool(use_exp_weights)), _p(norms), C.byref(t)))
+        return norms, {k: getattr(t, k) for k, _ in t._fields_ if k != "reserved"}
+
     def build_event_frame_batch(self, first_slot, slices, level=0, blur_sigma=0.5, use_exp_weights=True):
         """`slices`: one (x, y, polarity) triple per slot, first_slot onwards; returns the norms."""
         offs = np.zeros(len(slices) + 1, dtype=np.int32)
@@ -487,7 +517,7 @@ class Handle:
 
     # -- keyframe set-up on the device ------------------------------------------------------
     def build_keyframe(self, slot, img, K, method=KF_MEDIAN, num_points=0, cell=20, depth_xy=None, depth_idp=None,
-                       min_depth=1.0, max_depth=3.0, weight_threshold=0.7):
+                       min_depth=1.0, max_depth=3.0, weight_threshold=0.7, sobel_ksize=3):
         """KeyFrame::create's tracker-facing part on the device; returns dict(coord, norm_coord, grad, idp, weights)."""
         img = np.ascontiguousarray(img)
         if img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] not in (1, 3)):
@@ -502,7 +532,7 @@ class Handle:
             ty, img = IMG_F64, np.ascontiguousarray(img, dtype=np.float64)
         sel = KfSelect()
         lib().eds_kf_select_default(C.byref(sel))
-        sel.method, sel.cell, sel.num_points = int(method), int(cell), int(num_points)
+        sel.method, sel.cell, sel.num_points, sel.sobel_ksize = int(method), int(cell), int(num_points), int(sobel_ksize)
         sel.min_depth, sel.max_depth, sel.weight_threshold = float(min_depth), float(max_depth), float(weight_threshold)
         nd = 0 if depth_xy is None else len(depth_xy)
         dxy = _f64(depth_xy) if nd else None
@@ -531,6 +561,13 @@ class Handle:
     def timer_stop(self) -> float:
         ms = C.c_float(0.0)
         _check(lib().eds_trk_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def prepare_frames(self, first=0, count=None, force=False) -> float:
+        """Converts the (stale, or with force all) frames of the range to the strip layout now; returns the device time in ms."""
+        count = self.batch - first if count is None else count
+        ms = C.c_float(0.0)
+        _check(lib().eds_trk_prepare_frames(self._h, int(first), int(count), int(bool(force)), C.byref(ms)))
         return ms.value
 
     def last_launch(self) -> dict:

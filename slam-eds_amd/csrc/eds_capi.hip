@@ -712,6 +712,33 @@ int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, i
                                   norms, &aos);
 }
 
+// EventFrame::create's time bookkeeping (EventFrame.cpp:313-335), host only
+int eds_event_times_aos(int n_events, const void* events, int stride, int off_ts, eds_event_times* out) {
+    if (!out) return fail(EDS_ERR_INVALID, "null output");
+    std::memset(out, 0, sizeof(*out));
+    if (n_events < 0 || (n_events > 0 && !events)) return fail(EDS_ERR_INVALID, "bad event array");
+    if (stride < 8 || off_ts < 0 || off_ts + 8 > stride) return fail(EDS_ERR_INVALID, "bad event layout (ts: int64 field inside the stride)");
+    if (n_events == 0) return EDS_OK;                       // (the reference's loop does not run; everything stays where clear() put it)
+    auto ts = [&](int i) { int64_t t; std::memcpy(&t, static_cast<const char*>(events) + (size_t)i * stride + off_ts, 8); return t; };
+    out->first_time = ts(0);
+    if (n_events > 1) { out->last_time = ts(n_events - 1); out->last_valid = 1; }     // `else if ((it + 1) == events.end())`: never for a single event
+    if (out->last_valid && out->first_time > out->last_time)
+        return fail(EDS_ERR_INVALID, "[EVENT_FRAME] Event time[0] > event time [N-1] (EventFrame.cpp:325-329)");
+    out->time = ts(n_events / 2);
+    out->delta_time = out->last_time - out->first_time;
+    return EDS_OK;
+}
+
+int eds_trk_build_event_frames_aos_timed(eds_trk* h, int first_slot, int num_levels, int n_events, const void* events, int stride, int off_x,
+                                         int off_y, int off_polarity, int off_ts, int sensor_H, int sensor_W, double blur_sigma,
+                                         int use_exp_weights, double* norms, eds_event_times* times) {
+    eds_event_times local;
+    int rc = eds_event_times_aos(n_events, events, stride, off_ts, times ? times : &local);
+    if (rc) return rc;
+    return eds_trk_build_event_frames_aos(h, first_slot, num_levels, n_events, events, stride, off_x, off_y, off_polarity, sensor_H, sensor_W,
+                                          blur_sigma, use_exp_weights, norms);
+}
+
 int eds_trk_build_event_frame_batch(eds_trk* h, int first_slot, int count, const int* offsets, const uint16_t* x, const uint16_t* y,
                                     const uint8_t* polarity, int level, double blur_sigma, int use_exp_weights, double* norms) {
     if (!h) return fail(EDS_ERR_INVALID, "null handle");
@@ -1008,6 +1035,24 @@ int eds_trk_timer_start(eds_trk* h) {
     return EDS_OK;
 }
 
+int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* elapsed_ms) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    if (elapsed_ms) *elapsed_ms = 0.f;
+    if (!h->tiled || h->cfg.sampling != EDS_SAMPLE_BICUBIC) return EDS_OK;
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    if (force)
+        for (int s = first; s < first + count; ++s) h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s].strips_version = 0;
+    if (elapsed_ms) EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
+    if (!eds_strips_prepare(h, first, count)) return fail(EDS_ERR_HIP, "no memory for the strip copies of the frames");
+    if (elapsed_ms) {
+        EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
+        EDS_HIP_TRY(hipEventSynchronize(h->ev1));
+        EDS_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    }
+    return EDS_OK;
+}
+
 int eds_trk_last_launch(eds_trk* h, eds_trk_launch_info* out) {
     if (!h || !out) return fail(EDS_ERR_INVALID, "null argument");
     return eds_fused_last_launch(h, out);
@@ -1128,6 +1173,7 @@ void eds_kf_select_default(eds_kf_select* sel) {
     sel->method = EDS_KF_MEDIAN;            // KeyFrame::create falls back to MEDIAN without a point target (KeyFrame.cpp:410-411)
     sel->cell = 20;                          // cv::Size(20, 20)  (KeyFrame.cpp:408)
     sel->num_points = 0;
+    sel->sobel_ksize = 3;                    // KeyFrame::create (KeyFrame.cpp:384-385); 7: the constructor's (KeyFrame.cpp:239-240)
     sel->min_depth = 1.0; sel->max_depth = 3.0;
     sel->weight_threshold = 0.7;             // cleanPoints(0.7)  (KeyFrame.cpp:451)
 }

@@ -175,6 +175,29 @@ __global__ __launch_bounds__(KF_T) void k_sobel(const double* __restrict__ L, in
     gx[o] = x; gy[o] = y; mag[o] = sqrt(x * x + y * y);
 }
 
+// cv::Sobel with aperture 7 (the KeyFrame constructor's, reference KeyFrame.cpp:239-240): separable kernels smooth = [1 6 15 20 15 6 1],
+// derivative = [-1 -4 -5 0 5 4 1] (cv::getSobelKernels), no scale, reflect-101 border, CV_64F — the row pass first, then the column
+// pass, each in the order OpenCV's symmetric / anti-symmetric filters add: centre term, then the pairs outwards.
+__global__ __launch_bounds__(KF_T) void k_sobel7(const double* __restrict__ L, int H, int W, double* __restrict__ gx,
+                                                 double* __restrict__ gy, double* __restrict__ mag) {
+    const int c = blockIdx.x * KF_T + threadIdx.x, r = blockIdx.y;
+    if (c >= W) return;
+    int cc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) cc[j] = reflect101(c + j - 3, W);
+    double rs[7], rd[7];                       // row pass of the seven rows around r: smoothed / differentiated along x
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double* p = L + (size_t)reflect101(r + k - 3, H) * W;
+        rs[k] = ((20.0 * p[cc[3]] + 15.0 * (p[cc[4]] + p[cc[2]])) + 6.0 * (p[cc[5]] + p[cc[1]])) + (p[cc[6]] + p[cc[0]]);
+        rd[k] = (5.0 * (p[cc[4]] - p[cc[2]]) + 4.0 * (p[cc[5]] - p[cc[1]])) + (p[cc[6]] - p[cc[0]]);
+    }
+    const double x = ((20.0 * rd[3] + 15.0 * (rd[4] + rd[2])) + 6.0 * (rd[5] + rd[1])) + (rd[6] + rd[0]);
+    const double y = (5.0 * (rs[4] - rs[2]) + 4.0 * (rs[5] - rs[1])) + (rs[6] - rs[0]);
+    const size_t o = (size_t)r * W + c;
+    gx[o] = x; gy[o] = y; mag[o] = sqrt(x * x + y * y);
+}
+
 // One workgroup per cell.  cand[cellid][pos] = local index (row-major inside the cell) in the reference's push order.
 // The cell's magnitudes (>= 0, so their bit patterns order like the values) are SORTED once — bitonic network in LDS over (magnitude
 // descending, index ascending): position p then holds the element of descending rank p, exact ties resolved by index like the
@@ -484,7 +507,8 @@ int eds_keyframe_build(eds_trk* h, int slot, int img_type, const void* img, int 
     const int NB = 256;
     hipLaunchKernelGGL(k_minmax, dim3(NB), dim3(KF_T), 0, st, kb.d_raw, img_type, n, kb.d_partial);
     hipLaunchKernelGGL(k_log, dim3(NB), dim3(KF_T), 0, st, kb.d_raw, img_type, n, kb.d_partial, NB, kb.d_log);
-    hipLaunchKernelGGL(k_sobel, dim3((W + KF_T - 1) / KF_T, H), dim3(KF_T), 0, st, kb.d_log, H, W, kb.d_gx, kb.d_gy, kb.d_mag);
+    if (sel->sobel_ksize == 7) hipLaunchKernelGGL(k_sobel7, dim3((W + KF_T - 1) / KF_T, H), dim3(KF_T), 0, st, kb.d_log, H, W, kb.d_gx, kb.d_gy, kb.d_mag);
+    else hipLaunchKernelGGL(k_sobel, dim3((W + KF_T - 1) / KF_T, H), dim3(KF_T), 0, st, kb.d_log, H, W, kb.d_gx, kb.d_gy, kb.d_mag);
     const int ncx = W / cell, ncy = H / cell, ncell = ncx * ncy;       // only whole cells (KeyFrame.cpp:752-754)
     const int k_per_cell = sel->method == EDS_KF_MAX ? (sel->num_points > 0 ? sel->num_points / ncell : 0) : 0;
     hipLaunchKernelGGL(k_select, dim3(ncell), dim3(KF_T), 0, st, kb.d_mag, W, cell, ncx, (int)sel->method, k_per_cell, kb.d_cand, kb.d_cnt);

@@ -286,6 +286,52 @@ def test_build_event_frames_from_array_of_structs(gpu, capi, layout):
     h.close()
 
 
+def test_event_time_bookkeeping_like_eventframe_create():
+    """EventFrame::create's time bookkeeping (reference EventFrame.cpp:313-335), host only: first = events[0].ts, last = events[n-1].ts,
+    frame time = the MIDDLE ELEMENT events[n/2].ts (not a median of values), delta = last - first; first > last is the reference's throw;
+    a single event never reaches the `else if` that sets last_time."""
+    import importlib
+    capi = importlib.import_module("slam-eds_amd.capi")
+    dt = np.dtype([("ts", np.int64), ("x", np.uint16), ("y", np.uint16), ("polarity", np.uint8)], align=True)
+    ev = np.zeros(7, dtype=dt)
+    ev["ts"] = [1000, 1010, 1015, 1500, 1501, 1502, 2000]
+    t = capi.event_times(ev)
+    assert (t["first_time"], t["last_time"], t["time"], t["delta_time"], t["last_valid"]) == (1000, 2000, 1500, 1000, 1)
+    t = capi.event_times(ev[:6])                                       # even count: element n/2 = 3
+    assert (t["time"], t["last_time"], t["delta_time"]) == (1500, 1502, 502)
+    # only the two ends are compared: a slice that is out of order in the middle passes, like in the reference
+    mid = ev.copy(); mid["ts"][3] = 5
+    assert capi.event_times(mid)["time"] == 5
+    bad = ev.copy(); bad["ts"][0] = 3000
+    with pytest.raises(capi.EdsError) as e:
+        capi.event_times(bad)
+    assert e.value.code == capi.ERR_INVALID and "time[0]" in str(e.value)
+    one = capi.event_times(ev[:1])
+    assert one["first_time"] == 1000 and one["last_valid"] == 0 and one["time"] == 1000
+    assert capi.event_times(ev[:0])["first_time"] == 0
+
+
+@pytest.mark.gpu
+def test_timed_aos_builder_checks_the_times_before_it_builds(gpu, capi):
+    import np_frame_oracle as fo
+    H, W = 60, 80
+    x, y, pol, _, _ = make_events(78, 5000, H, W, distort=False)
+    dt = np.dtype([("ts", np.int64), ("x", np.uint16), ("y", np.uint16), ("polarity", np.uint8)], align=True)
+    ev = np.zeros(len(x), dtype=dt)
+    ev["x"], ev["y"], ev["polarity"], ev["ts"] = x, y, pol, 10 + np.arange(len(x)) * 3
+    h = capi.Handle(capi.default_config(), 1, 64, H, W)
+    norms, t = h.build_event_frames_aos_timed(0, 1, ev)
+    assert t["first_time"] == 10 and t["last_time"] == 10 + 3 * (len(x) - 1) and t["time"] == 10 + 3 * (len(x) // 2) and t["delta_time"] == 3 * (len(x) - 1)
+    ref_frames, ref_norms = fo.event_frames(x, y, pol, H, W, H, W, 1, None, None)
+    assert norms[0] == pytest.approx(ref_norms[0], rel=1e-11)
+    before = h.get_event_frame(0)
+    ev2 = ev.copy(); ev2["ts"][0] = 10 ** 9; ev2["x"][:] = 0                   # would draw a different frame ...
+    with pytest.raises(capi.EdsError):
+        h.build_event_frames_aos_timed(0, 1, ev2)
+    assert np.array_equal(h.get_event_frame(0), before)                        # ... but the time check comes first: nothing was touched
+    h.close()
+
+
 @pytest.mark.gpu
 def test_event_slice_without_a_vote_gives_the_references_nan_frame(gpu, capi):
     """Every event of a slice lands outside the image (undistortion map): the vote image stays zero, cv::norm is 0 and the reference

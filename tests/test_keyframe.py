@@ -36,6 +36,17 @@ def test_oracle_log_and_sobel_known_answers():
     assert np.allclose(gx[1:-1, 1:-1], 8 * 2.0) and np.allclose(gy[1:-1, 1:-1], 8 * 3.0)     # [1 2 1] . [-1 0 1] = 8 x slope
     assert np.allclose(gx[:, 0], 0.0) and np.allclose(gy[0, :], 0.0)         # reflect-101: the border derivative vanishes
     assert ko.magnitude(np.array([3.0]), np.array([4.0]))[0] == 5.0
+    # aperture 7 (KeyFrame.cpp:239-240): sum(smooth) = 64, sum(j * derivative) = 32 -> 2048 x slope on a ramp; symmetric, so a
+    # constant image has no gradient; and the kernels are the ones cv::getSobelKernels builds: (1 1)^6 and (1 1)^5 * (-1 1)
+    gx7, gy7 = ko.sobel7(np.add.outer(3.0 * np.arange(12), 2.0 * np.arange(13)))
+    assert np.allclose(gx7[3:-3, 3:-3], 2048 * 2.0) and np.allclose(gy7[3:-3, 3:-3], 2048 * 3.0)
+    assert np.all(ko.sobel7(np.full((9, 9), 7.0))[0] == 0.0)
+    smooth, deriv = np.poly1d([1, 1]) ** 6, np.poly1d([1, 1]) ** 5 * np.poly1d([1, -1])
+    assert list(smooth.coeffs) == [1, 6, 15, 20, 15, 6, 1] and list(deriv.coeffs) == [1, 4, 5, 0, -5, -4, -1]
+    imp = np.zeros((15, 15)); imp[7, 7] = 1.0                      # impulse response = the (flipped) separable kernel
+    gxi, gyi = ko.sobel7(imp)
+    assert np.array_equal(gxi[4:11, 4:11], np.outer([1, 6, 15, 20, 15, 6, 1], [1, 4, 5, 0, -5, -4, -1]))
+    assert np.array_equal(gyi[4:11, 4:11], np.outer([1, 4, 5, 0, -5, -4, -1], [1, 6, 15, 20, 15, 6, 1]))
 
 
 def test_oracle_candidate_points_rules():
@@ -103,6 +114,24 @@ def test_build_keyframe_vs_oracle(gpu, capi, shape, method, npts, dtype):
     out0 = h.build_keyframe(0, img, K, method=method, num_points=npts, min_depth=0.5, max_depth=4.5)
     _compare(out0, ref0)
     assert len(out0["coord"]) == ref0["num_candidates"] and np.all(out0["idp"] == 0.5)
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,npts", [(0, 2000), (1, 0)], ids=["max2000", "median"])
+def test_build_keyframe_sobel7_vs_oracle(gpu, capi, method, npts):
+    """eds_kf_select.sobel_ksize = 7: the aperture of the reference's KeyFrame constructor (KeyFrame.cpp:239-240)."""
+    import np_keyframe_oracle as ko
+    H, W = 181, 243
+    img = make_image(23, H, W, np.float32)
+    K = (0.78 * W, 0.78 * W, (W - 1) / 2, (H - 1) / 2)
+    xy, di = make_depth_map(24, H, W, 2000)
+    ref = ko.keyframe(img, K, method, npts, depth_xy=xy, depth_idp=di, sobel_ksize=7)
+    h = capi.Handle(capi.default_config(), 1, H * W, H, W)
+    out = h.build_keyframe(0, img, K, method=method, num_points=npts, depth_xy=xy, depth_idp=di, sobel_ksize=7)
+    _compare(out, ref)
+    ref3 = ko.keyframe(img, K, method, npts, depth_xy=xy, depth_idp=di)
+    assert np.median(np.abs(ref["grad"])) > 50 * np.median(np.abs(ref3["grad"]))          # a large constant factor, as SURVEY's appendix notes
     h.close()
 
 
