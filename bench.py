@@ -481,15 +481,20 @@ def main():
         h.optimize_batch(0, 0, B, sync=True)
         return h.results(0, B)
 
+    gatherer = batchmod.ResultGatherer(total, device=dev, to_host=(rank == 0), force=forced)    # buffers, stream and event allocated once
+
     def gather(local):
-        return batchmod.gather_results(local, total, device=dev, to_host=(rank == 0), force=forced)
+        gatherer.start(local)
+        return gatherer.finish()
 
     def step_sharded(prev_local):
-        """Several GPUs: the all-gather of step k-1 (RCCL on torch's stream) overlaps the solve of step k (library stream)."""
+        """Several GPUs: the all-gather of step k-1 (RCCL, on the gatherer's own stream) overlaps the solve of step k (library stream)."""
         h.set_states(0, p0, q0, v0)
         h.optimize_batch(0, 0, B, sync=False)
-        table = gather(prev_local) if prev_local is not None else None
+        if prev_local is not None:
+            gatherer.start(prev_local)
         h.sync()
+        table = gatherer.finish() if prev_local is not None else None
         return h.results(0, B), table
 
     for _ in range(a.warmup):
@@ -508,10 +513,13 @@ def main():
     else:
         prev = None
         for _ in range(a.steps):
+            ts_ = time.perf_counter()
             prev, t_prev = step_sharded(prev)
             if t_prev is not None:
                 table = t_prev
             dev_us.append(h.info(0)["device_time_us"])
+            if os.environ.get("EDS_BENCH_DEBUG"):
+                sys.stderr.write(f"[bench] rank {rank} step {1e3 * (time.perf_counter() - ts_):.3f} ms, kernel {dev_us[-1] * 1e-3:.3f} ms\n")
         t_last = gather(prev)                        # the last step's results: every step's gather ends inside the timed region
         if t_last is not None:
             table = t_last
@@ -744,7 +752,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        # RCCL prints its version banner through C stdio, which is flushed when the process exits — behind anything Python printed.
+        # The JSON line has to be the LAST line on stdout: empty the C buffers first.
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
         if not (out["parity_max_se3"] <= PARITY_TOL) or out["parity"]["iteration_count_mismatches"]:
             sys.stderr.write(f"bench.py: PARITY FAILURE: max SE(3) distance to the oracle {out['parity_max_se3']:.3e} (tolerance {PARITY_TOL}), "
                              f"{out['parity']['iteration_count_mismatches']} iteration-count mismatches\n")

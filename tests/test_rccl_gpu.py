@@ -36,15 +36,19 @@ dev = torch.device("cuda", 0)
 bt.reset_states(als); bt.solve(sync=True)
 want = bt.local_results().copy()
 # the sharded step of bench.py: launch step k (library stream), all-gather step k - 1 (torch stream, device tensor), then wait
+# (bench.py's step_sharded: a ResultGatherer with its own stream, pinned staging and event, started behind the launch of step k)
 tables, prev = [], None
+g = batch.ResultGatherer(B, device=dev, to_host=True, force=True)
 for k in range(4):
     bt.reset_states(als)
     bt.solve(sync=False)
     if prev is not None:
-        tables.append(batch.gather_results(prev, B, device=dev, to_host=True, force=True))
+        g.start(prev)
     bt.handle.sync()
+    if prev is not None:
+        tables.append(g.finish())
     prev = bt.local_results()
-tables.append(batch.gather_results(prev, B, device=dev, to_host=True, force=True))
+tables.append(batch.gather_results(prev, B, device=dev, to_host=True, force=True))      # and the one-shot form
 torch.cuda.synchronize()
 # the collective on a device tensor directly (what gather_results wraps), and a barrier
 x = torch.arange(16, dtype=torch.float64, device=dev).reshape(1, 16)
