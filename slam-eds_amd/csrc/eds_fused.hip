@@ -89,6 +89,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_posef[16];      // fp32 copies for the point phase: [0..11] R - I and t of the pose to evaluate (serial solver), [12..13] fx, fy
     __shared__ float s_red[EDS_FUSED_MAX_WAVES][EDS_RED_K6];
+    __shared__ float s_costp[2][EDS_FUSED_MAX_WAVES];   // per-wavefront cost of the pass in flight, double-buffered by pass parity (quick accept test)
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
     __shared__ int s_accept;           // the pass just consumed became the accepted pose
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         }
     }
     for (int k = tid; k < EDS_FUSED_MAX_WAVES * EDS_RED_K6; k += nthr) (&s_red[0][0])[k] = 0.0f;   // rows of absent wavefronts stay 0
+    if (tid < 2 * EDS_FUSED_MAX_WAVES) (&s_costp[0][0])[tid] = 0.0f;
     __syncthreads();
 
     // per-point constants: registers (PPT > 0) — loaded once, coalesced — and the normalised model
@@ -223,15 +225,27 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #else
 #define EDS_COUNT_MISS(m) do { } while (0)
 #endif
+    // One CU per alignment, prepared candidates: what decides a pass is its COST alone, and LM rejects more than half of its
+    // candidates — a rejected pass needs neither the other 27 sums nor the solver.  So the cost is reduced first (one value per
+    // wavefront, one barrier), every wavefront takes the accept test itself, and after a rejection all of them walk on to the next
+    // prepared candidate at once: no 28-value reduction, no second barrier, no serial section.  The control state each wavefront
+    // needs for that lives in its registers (k_r: candidate under evaluation, iter_r, have_cur_r, cur_cost_r), reloaded from LDS after
+    // every pass that did go through the solver lane.  The cost partials are double-buffered by pass parity (a wavefront can run at
+    // most one barrier ahead of the slowest reader).
+    constexpr bool QUICK = TEAM == 1 && PPT > 0;
+    int k_r = 0, iter_r = 0, have_cur_r = 0;
+    double cur_cost_r = 0.0;
+    unsigned parity = 0;
     float rcand[NREG], racc[NREG];      // residuals of the pass in flight / of the accepted pose (PPT > 0)
 #pragma unroll
     for (int j = 0; j < NREG; ++j) { rcand[j] = 0.0f; racc[j] = 0.0f; }
     for (;;) {
         EDS_STAMP(0);
         const int state = s_state;
+        const int kcur = (QUICK && spec_mode) ? k_r : sp.k;      // the prepared candidate this pass evaluates
         PoseF ps;
         if (PAIRS) { }
-        else if (spec_mode) load_pose_rt(sp.spec[sp.k].rt.D, sp.spec[sp.k].rt.t, s_pose, ps);
+        else if (spec_mode) load_pose_rt(sp.spec[kcur].rt.D, sp.spec[kcur].rt.t, s_pose, ps);
         else load_pose(s_pose, ps);
         float acc[EDS_RED_K6];
 #pragma unroll
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             typedef __attribute__((address_space(3))) void* lds_ptr;
             typedef const __attribute__((address_space(1))) void* glb_ptr;
             const int jr = lane & 3;
-            const float* __restrict__ rtf = spec_mode ? sp.spec[sp.k].rt.f : s_posef;
+            const float* __restrict__ rtf = spec_mode ? sp.spec[kcur].rt.f : s_posef;
             EDS_LOAD_POSE_SCALARS(rtf, s_posef + 12);
             PairGeom pg[NPAIR];
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             const int swz = (tid >> 2) & 3;
             const int cq0 = 16 * (0 ^ swz), cq1 = 16 * (1 ^ swz), cq2 = 16 * (2 ^ swz), cq3 = 16 * (3 ^ swz);
             const int cq[4] = {cq0, cq1, cq2, cq3};
-            const float* __restrict__ rtf = spec_mode ? sp.spec[sp.k].rt.f : s_posef;
+            const float* __restrict__ rtf = spec_mode ? sp.spec[kcur].rt.f : s_posef;
             EDS_LOAD_POSE_SCALARS(rtf, s_posef + 12);
             PairGeom pg[NPAIR];
             int org[NREG];
@@ -505,6 +519,49 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #if defined(EDS_FUSED_STAMPS) && EDS_FUSED_STAMPS == 3
         if (tid == 0) ++s_pass_total;
 #endif
+        double quick_cost = 0.0;
+        if (QUICK && spec_mode) {
+            // the pass's cost: in-row DPP sums, the four row totals by v_readlane, one float per wavefront, fp64 across the wavefronts
+            float c = acc[EDS_RED_N6 - 1];
+            c += dpp_f<0xB1>(c);                 // quad_perm [1,0,3,2]
+            c += dpp_f<0x4E>(c);                 // quad_perm [2,3,0,1]
+            c += dpp_f<0x141>(c);                // row_half_mirror
+            c += dpp_f<0x140>(c);                // row_mirror
+            const float wc = ((__int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 16))) +
+                              __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 32))) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), 48));
+            if (lane == 0) s_costp[parity][wave] = wc;
+            __syncthreads();
+#pragma unroll
+            for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) quick_cost += (double)s_costp[parity][wv];
+            parity ^= 1u;
+            const bool reject = have_cur_r && !(quick_cost < cur_cost_r);
+            const bool last = iter_r + 1 >= sv.max_iters;
+            if (reject && (last || k_r + 1 < EDS_NSPEC)) {
+                // Solver6::on_eval for a rejected candidate, without the solver lane: trace, counters, lambda (kept by lane 0 of
+                // wavefront 0 for the end of the solve and for the next proposal), then the candidate prepared for exactly this lambda
+                if (tid == 0) {
+                    const int nt = sv.ntrace;
+                    if (nt < EDS_MAX_TRACE) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sv.tr_xi[nt][i] = sp.spec[k_r].xi[i];
+                        sv.tr_cost[nt] = quick_cost; sv.tr_acc[nt] = 0;
+                        sv.ntrace = nt + 1;
+                    }
+                    sv.iter = iter_r + 1; sv.last_accepted = 0;
+                    sv.lambda = edsp::next_lambda_after_reject(sv.lambda);
+                    sp.k = last ? 0 : k_r + 1; sp.mode = last ? edsp::MODE_DONE : edsp::MODE_USE;
+                    if (last) { sv.final_cost = cur_cost_r; sv.done = 1; s_state = 2; }
+                }
+                ++iter_r;
+                if (last) break;
+                ++k_r;
+                if (!sp.spec[k_r].ok) {             // damped matrix not positive definite: Solver6 gives up here (iteration >= 1: not a failure)
+                    if (tid == 0) { sv.failed = 0; sv.final_cost = cur_cost_r; sv.done = 1; }
+                    break;
+                }
+                continue;
+            }
+        }
         wave_reduce_scatter<EDS_RED_K6>(acc, lane);
         if (lane < 32) s_red[wave][wave_red_index<EDS_RED_K6>(lane, 0)] = acc[0];
         EDS_STAMP2(1);
@@ -567,6 +624,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 int have_cur = sv.have_cur, iter = sv.iter, ntrace = sv.ntrace;
                 double lambda = sv.lambda;
                 const double cur_cost = sp.cur[EDS_RED_N6 - 1];
+                if (QUICK && lane == EDS_RED_N6 - 1) s = quick_cost;         // ONE cost per pass: the value every wavefront took its accept test on
                 const long long sb = __double_as_longlong(s);
                 const double cost = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(sb >> 32), EDS_RED_N6 - 1) << 32) |
                                                          (unsigned int)__builtin_amdgcn_readlane((int)(sb & 0xffffffffll), EDS_RED_N6 - 1));
@@ -630,6 +688,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
                 for (int j = 0; j < NREG; ++j) racc[j] = rcand[j];
             }
+            if (QUICK) { k_r = sp.k; iter_r = sv.iter; have_cur_r = sv.have_cur; cur_cost_r = sp.cur[EDS_RED_N6 - 1]; }
             if (sp.mode == edsp::MODE_DONE) break;
             if (!sp.spec[sp.k].ok) {                // damped matrix not positive definite: Solver6 gives up here (failed only at iteration 0)
                 if (tid == 0) { sv.failed = (sv.iter == 0); sv.final_cost = sp.cur[EDS_RED_N6 - 1]; sv.done = 1; }
