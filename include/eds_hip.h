@@ -110,7 +110,9 @@ typedef struct eds_trk_info {
     double   initial_cost;
     double   final_cost;
     double   device_time_us;        /* GPU time of the solve: between two stream events around the launch; for launches of up to 64
-                                     * alignments, from the kernel's own 100 MHz time stamps (first workgroup in .. result out) */
+                                     * alignments, from the kernels' own 100 MHz time stamps (member 0 of the first team in .. last result
+                                     * out: excludes dispatch latency — the two sources differ by a few microseconds;
+                                     * eds_trk_last_launch().timing_source says which one a call used) */
 } eds_trk_info;
 
 #define EDS_INFO_TEAM_TIMEOUT 1      /* this solve was launched on several CUs per alignment, a team did not assemble within 50 ms (something
@@ -260,8 +262,9 @@ int eds_trk_get_residuals(eds_trk* h, int slot, double* r);
 int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau);
 
 /* Batched form: tau[count] for slots [first, first+count).  When the residuals of the last solve are still resident
- * in HBM (device-mode solves) the median / MAD selection runs on the GPU — one workgroup per alignment, bitonic
- * sort in LDS — and only 8 bytes per alignment come back. */
+ * in HBM (device-mode solves) the median / MAD selection runs on the GPU — one workgroup per alignment, a most-significant-digit
+ * radix SELECT on order-preserving 64-bit keys (median and MAD are order statistics: nothing is sorted) — and only 8 bytes per
+ * alignment come back. */
 int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, double* tau);
 
 /* ---- post-solve point maintenance ---------------------------------------------------- */
