@@ -217,7 +217,7 @@ def latency_block(capi, synth, al, a):
     out["slice_ms"] = med(one_slice)
 
     # the same call as the drop-in shim makes it (Tracker::optimize with a HOST fp64 frame): depths, frame upload, solve,
-    # residuals, MAD loss scale, residuals again (the MAD reorders them)
+    # residuals + MAD loss scale in one call (kf->residuals as the MAD's reorder leaves them)
     frame64 = np.ascontiguousarray(al.frame, dtype=np.float64)
     idp64 = np.ascontiguousarray(al.idp, dtype=np.float64)
 
@@ -225,9 +225,7 @@ def latency_block(capi, synth, al, a):
         h.set_idepth(0, idp64)
         h.set_event_frame(0, frame64)
         h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
-        h.residuals(0)
-        h.loss_param(0, capi.LP_MAD)
-        h.residuals(0)
+        h.residuals_and_loss(0, capi.LP_MAD)
     out["live_call_ref12_ms"] = med(live_call)
     out["live_call_ref12_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
     h.close()

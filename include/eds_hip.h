@@ -261,6 +261,11 @@ int eds_trk_get_residuals(eds_trk* h, int slot, double* r);
  * it, on the host: 20 us against 80 us for a single-alignment sort on the GPU.  Batches: eds_trk_loss_param_batch. */
 int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau);
 
+/* Tracker.cpp:223-233 in one call and one read-back: r (N doubles) receives kf->residuals as the reference leaves them after
+ * `kf->residuals[i] = ...` AND `config.loss_params = getLossParams(method)` — the MAD selection partially reorders them in place —
+ * and *tau the loss scale (unchanged for EDS_LP_CONSTANT). */
+int eds_trk_residuals_and_loss(eds_trk* h, int slot, int method, double* r, double* tau);
+
 /* Batched form: tau[count] for slots [first, first+count).  When the residuals of the last solve are still resident
  * in HBM (device-mode solves) the median / MAD selection runs on the GPU — one workgroup per alignment, a most-significant-digit
  * radix SELECT on order-preserving 64-bit keys (median and MAD are order statistics: nothing is sorted) — and only 8 bytes per

@@ -37,7 +37,7 @@ EXPORTS = (
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
     "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
-    "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param",
+    "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param", "eds_trk_residuals_and_loss",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_last_launch", "eds_trk_prepare_frames",
@@ -476,6 +476,13 @@ class Handle:
         tau = C.c_double(current)
         _check(lib().eds_trk_loss_param(self._h, slot, int(method), C.cast(C.byref(tau), _dp)))
         return tau.value
+
+    def residuals_and_loss(self, slot, method, current=0.0):
+        """Tracker.cpp:223-233 in one call: (kf->residuals as the MAD selection leaves them, loss scale)."""
+        r = np.zeros(self._N[slot])
+        tau = C.c_double(current)
+        _check(lib().eds_trk_residuals_and_loss(self._h, slot, int(method), _p(r), C.cast(C.byref(tau), _dp)))
+        return r, tau.value
 
     def loss_param_batch(self, method, first=0, count=None):
         count = self.batch - first if count is None else count

@@ -367,8 +367,11 @@ class Tracker {
         for (int i = 0; i < 6; ++i) vx[i] = v[i];
         T_kf_ef = getTransform().inverse();                                                                                     // Tracker.cpp:220
         kf->residuals.resize(N);
-        eds_trk_get_residuals(h, 0, kf->residuals.data());                                                                      // Tracker.cpp:223-230
-        config.loss_params = getLossParams(loss_param_method);                                                                  // Tracker.cpp:233
+        // Tracker.cpp:223-233 — kf->residuals filled, then config.loss_params = getLossParams(method), whose MAD selection reorders
+        // kf->residuals in place — as ONE call and one read-back (round 2: get_residuals -> loss_param -> get_residuals)
+        double tau = config.loss_params.empty() ? 0.0 : config.loss_params[0];
+        if (eds_trk_residuals_and_loss(h, 0, (int)loss_param_method, kf->residuals.data(), &tau) == EDS_OK && loss_param_method != CONSTANT)
+            config.loss_params = std::vector<double>{tau};
         return true;
     }
     /** T_ef_kf = SE3(qx, px) (Tracker.cpp:243-249). */

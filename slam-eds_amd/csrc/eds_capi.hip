@@ -72,7 +72,13 @@ void fill_static(const eds_trk* h, int slot) {
 }
 
 void fill_pose(eds_trk* h, int slot, const double* p, const double* q, const double* v) {
-    if (h->gram_pending) { hipStreamSynchronize(h->st); h->gram_pending = false; }      // h_G as set_idepth's launch left it
+    if (h->gram_pending) { hipStreamSynchronize(h->st); h->gram_pending = false; }      // h_G as an earlier refresh left it
+    if (h->slots[slot].gram_host_stale) {           // set_idepth refreshed the Gram matrices in HBM only: fetch this slot's now
+        const size_t off = (size_t)slot * EDS_MAX_BLOCKS * 36;
+        hipMemcpyAsync(h->h_G + off, h->dG + off, (size_t)EDS_MAX_BLOCKS * 36 * 8, hipMemcpyDeviceToHost, h->st);
+        hipStreamSynchronize(h->st);
+        h->slots[slot].gram_host_stale = false;
+    }
     fill_static(h, slot);
     edsm::fill_pose_block(p, q, v, h->h_G + (size_t)slot * EDS_MAX_BLOCKS * 36, effective_blocks(h),
                           h->h_pose + (size_t)slot * EDS_POSE_STRIDE);
@@ -492,6 +498,7 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     EDS_HALLOC(h->h_f32, h->h_f32_elems * 4);
     EDS_HALLOC(h->h_r, BN * 4);
     EDS_HALLOC(h->h_idp, (size_t)h->Np * 4);
+    if (hipHostGetDevicePointer((void**)&h->d_idp, h->h_idp, 0) != hipSuccess) { (void)hipGetLastError(); h->d_idp = nullptr; }
     {   // mirror of the residual plane for the first few slots (eds_mirror_residuals)
         const size_t nr = (size_t)std::min(batch, EDS_RHOST_SLOTS) * h->Np;
         hipError_t e_ = hipHostMalloc((void**)&h->h_rmap, nr * 4, hipHostMallocMapped);
@@ -594,6 +601,7 @@ static int refresh_gram(eds_trk* h, int slot, bool wait = true) {
     EDS_HIP_TRY(hipGetLastError());
     const size_t off = (size_t)slot * EDS_MAX_BLOCKS * 36;
     EDS_HIP_TRY(hipMemcpyAsync(h->h_G + off, h->dG + off, (size_t)EDS_MAX_BLOCKS * 36 * 8, hipMemcpyDeviceToHost, h->st));
+    h->slots[slot].gram_host_stale = false;
     if (wait) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); h->gram_pending = false; }
     else h->gram_pending = true;        // the device solvers read dG on the stream; host readers of h_G wait in fill_pose
     return EDS_OK;
@@ -632,6 +640,17 @@ int eds_trk_set_idepth_strided(eds_trk* h, int slot, int N, const double* idp, i
     // (Tracker.cpp:167 re-reads the depths on every optimize: this is on the live path, so nothing here waits for the GPU)
     if (h->idp_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_idp)); h->idp_busy = false; }
     for (int i = 0; i < h->Np; ++i) h->h_idp[i] = i < N ? (float)idp[(size_t)i * stride] : 1.f;
+    if (h->d_idp) {
+        // ONE launch: the Gram kernel reads the new depths out of the mapped staging, stores them into the rho plane on its way and
+        // leaves the Gram matrices in HBM, where the device solvers read them; the host copy is fetched only if a host-side solver or
+        // eval asks for it (fill_pose).  (Round 2: copy + event + pose upload + launch + copy back = ~20 us of host time.)
+        eds_launch_gram(h->arrays(), slot, effective_blocks(h), h->st, h->d_idp);
+        EDS_HIP_TRY(hipGetLastError());
+        EDS_HIP_TRY(hipEventRecord(h->ev_idp, h->st));
+        h->idp_busy = true;
+        s.gram_host_stale = true;
+        return EDS_OK;
+    }
     EDS_HIP_TRY(hipMemcpyAsync(h->drho + (size_t)slot * h->Np, h->h_idp, (size_t)h->Np * 4, hipMemcpyHostToDevice, h->st));
     EDS_HIP_TRY(hipEventRecord(h->ev_idp, h->st));
     h->idp_busy = true;
@@ -1007,7 +1026,8 @@ int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau) {
         const size_t n = r.size() / 2;
         std::nth_element(r.begin(), r.begin() + n, r.end());
         const double median = r[n];
-        std::vector<double> am(r.size());
+        std::vector<double>& am = h->scratch;           // (no allocation per call on the live path)
+        am.resize(r.size());
         for (size_t i = 0; i < r.size(); ++i) am[i] = std::fabs(r[i] - median);
         const size_t m = am.size() / 2;
         std::nth_element(am.begin(), am.begin() + m, am.end());
@@ -1026,6 +1046,21 @@ int eds_trk_loss_param(eds_trk* h, int slot, int method, double* tau) {
         return EDS_OK;
     }
     return fail(EDS_ERR_INVALID, "unknown loss-param method");
+}
+
+// Tracker.cpp:223-233 in one call: kf->residuals <- the residuals at the solution, config.loss_params <- getLossParams(method) — whose
+// MAD selection partially reorders kf->residuals in place (n_quantile_vector, Utils.hpp:316-319).  `r` receives the residuals as that
+// sequence leaves them; one read-back instead of get_residuals -> loss_param -> get_residuals.
+int eds_trk_residuals_and_loss(eds_trk* h, int slot, int method, double* r, double* tau) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!r || !tau) return fail(EDS_ERR_INVALID, "null output");
+    if ((rc = materialise_residuals(h, slot))) return rc;
+    const Slot& s = h->slots[slot];
+    if ((int)s.residuals.size() != s.N) return fail(EDS_ERR_STATE, "no residuals stored (no usable solve yet)");
+    if (method != EDS_LP_CONSTANT && (rc = eds_trk_loss_param(h, slot, method, tau))) return rc;
+    std::memcpy(r, s.residuals.data(), sizeof(double) * s.N);
+    return EDS_OK;
 }
 
 int eds_trk_timer_start(eds_trk* h) {

@@ -23,6 +23,8 @@ struct Slot {
     int ntrace = 0;
     std::vector<double> tr_xi, tr_cost;
     std::vector<int32_t> tr_acc;
+    bool gram_host_stale = false;   // the Gram matrices in HBM are newer than the host copy h_G (set_idepth does not fetch them: only
+                                    // the host-driven solvers and eval read h_G, and they fetch it then — fill_pose)
     bool res_on_device = false;     // residuals of the last solve still only in HBM
     bool res_in_hostmap = false;    // ... and mirrored in the handle's pinned h_rmap by the kernel that produced them (small launches)
     bool trace_on_device = false;   // trace of the last solve still only in HBM
@@ -55,6 +57,8 @@ struct eds_trk {
     hipEvent_t ev_stage = nullptr;      // recorded behind the last copy out of h_fstage
     float *h_rmap = nullptr, *d_rmap = nullptr;       // pinned, device-mapped [min(B, EDS_RHOST_SLOTS)][Np]: residuals of small launches (eds_mirror_residuals)
     float* h_idp = nullptr;             // pinned [Np]: set_idepth narrows into it (private, like h_fstage)
+    float* d_idp = nullptr;             // ... as the device sees it (the gram kernel reads the new depths in place)
+    std::vector<double> scratch;        // host scratch of eds_trk_loss_param (no allocation per call on the live path)
     hipEvent_t ev_idp = nullptr;
     bool idp_busy = false;
     bool gram_pending = false;          // h_G's refresh is still in flight on the stream (set_idepth does not wait for it)

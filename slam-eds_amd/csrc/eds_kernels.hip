@@ -34,7 +34,10 @@ __device__ __forceinline__ bool decode_wg(int first, int count, int nchunk, int&
 }
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EDS_TPB) void eds_gram_kernel(EdsArrays A, int slot) {
+// new_rho (optional): the slot's inverse depths as the host just narrowed them into device-mapped pinned memory (set_idepth on the live
+// path: Tracker.cpp:167 re-reads the depths on every optimize) — every block stores its own points' values into the rho plane on its
+// way, block 0 the padding as well: the depth refresh is ONE launch, no copy call.
+__global__ __launch_bounds__(EDS_TPB) void eds_gram_kernel(EdsArrays A, int slot, const float* __restrict__ new_rho) {
     // grid.x = residual block index k; fp64 accumulation of the 21 unique products
     const int k = blockIdx.x;
     const double* pb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
@@ -45,10 +48,15 @@ __global__ __launch_bounds__(EDS_TPB) void eds_gram_kernel(EdsArrays A, int slot
     double acc[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) acc[i] = 0.0;
+    float* __restrict__ rho_plane = const_cast<float*>(A.rho);
+    if (new_rho && k == 0)
+        for (int i = N + threadIdx.x; i < A.Np; i += EDS_TPB) rho_plane[base + i] = new_rho[i];       // the padding (1.0)
     for (int i = threadIdx.x; i < n; i += EDS_TPB) {
         const size_t o = base + start + i;
+        float rho = A.rho[o];
+        if (new_rho) { rho = new_rho[start + i]; rho_plane[o] = rho; }
         float a[6];
-        model_row(A.x[o], A.y[o], A.rho[o], A.gx[o], A.gy[o], a);
+        model_row(A.x[o], A.y[o], rho, A.gx[o], A.gy[o], a);
         int c = 0;
 #pragma unroll
         for (int p = 0; p < 6; ++p)
@@ -287,8 +295,8 @@ __global__ __launch_bounds__(EDS_TPB) void eds_reduce_kernel(EdsArrays A, int fi
 // launchers (host side, same translation unit so the templates are instantiated here)
 static inline int grid_for(int count, int per_slot) { return ((count + 7) / 8) * 8 * per_slot; }
 
-void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st) {
-    hipLaunchKernelGGL(eds_gram_kernel, dim3(nb), dim3(EDS_TPB), 0, st, A, slot);
+void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st, const float* new_rho) {
+    hipLaunchKernelGGL(eds_gram_kernel, dim3(nb), dim3(EDS_TPB), 0, st, A, slot, new_rho);
 }
 void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st) {
     hipLaunchKernelGGL(eds_model_kernel, dim3(grid_for(count, nchunk)), dim3(EDS_TPB), 0, st, A, first, count, nchunk);

@@ -31,7 +31,7 @@ struct EdsArrays {
 
 #define EDS_RHOST_SLOTS 8
 
-void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st);
+void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st, const float* new_rho = nullptr);
 void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st);
 void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, int count, int nchunk, hipStream_t st);
 // PhotometricErrorNC (reference PhotometricErrorNC.hpp:124-192): block statistics of the sampled brightness, then the

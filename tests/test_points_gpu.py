@@ -221,3 +221,53 @@ def test_loss_param_on_device_with_all_equal_and_duplicated_residuals(gpu, capi,
         tau_exact, _ = po.loss_param(r, po.LP_MAD)
         assert tau_dev == pytest.approx(tau_exact, rel=1e-12, abs=1e-300)
         h.close()
+
+
+@pytest.mark.parametrize("solver", ["lm6", "ref12"])
+def test_residuals_and_loss_is_the_three_call_sequence(gpu, capi, synth, po, solver):
+    """eds_trk_residuals_and_loss = Tracker.cpp:223-233 in one call: the residuals as get_residuals -> loss_param(MAD) -> get_residuals
+    leaves them (the MAD's n_quantile_vector reorders kf->residuals in place) and the same tau, bit for bit; STD and CONSTANT too."""
+    al = synth.make_alignment(41, H=120, W=160, N=777)
+    sv = capi.SOLVER_LM6 if solver == "lm6" else capi.SOLVER_REF12
+    cfg = capi.default_config(solver=sv, exec=capi.EXEC_DEVICE, max_num_iterations=6)
+    for method, lp in ((capi.LP_MAD, po.LP_MAD), (capi.LP_STD, po.LP_STD), (capi.LP_CONSTANT, None)):
+        ha, hb = capi.Handle(cfg, 1, al.N, al.H, al.W), capi.Handle(cfg, 1, al.N, al.H, al.W)
+        for h in (ha, hb):
+            h.set_alignment(0, al)
+            h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+        r_first = ha.residuals(0)
+        tau_a = ha.loss_param(0, method, current=0.25)
+        r_a = ha.residuals(0)
+        r_b, tau_b = hb.residuals_and_loss(0, method, current=0.25)
+        assert np.array_equal(r_a, r_b) and tau_a == tau_b
+        assert np.array_equal(np.sort(r_b), np.sort(r_first))                     # a permutation of the residuals at the solution
+        if method == capi.LP_MAD:
+            assert not np.array_equal(r_b, r_first)                               # ... and the MAD did reorder them
+            assert tau_b == pytest.approx(po.loss_param(r_first, lp)[0], rel=1e-12)
+        if method == capi.LP_CONSTANT:
+            assert tau_b == 0.25 and np.array_equal(r_b, r_first)
+        ha.close(); hb.close()
+
+
+def test_set_idepth_in_one_launch_serves_device_and_host_readers(gpu, capi, synth, po):
+    """set_idepth refreshes the rho plane and the Gram matrices with ONE launch and leaves the host copy of the Gram matrices stale;
+    a device solve must see the new depths at once, and a host-side reader (eval, the host-driven loop) must fetch the matrices first:
+    both equal a fresh handle that got the new depths through set_keyframe."""
+    al = synth.make_alignment(43, H=120, W=160, N=900)
+    rng = np.random.default_rng(5)
+    idp2 = al.idp * rng.uniform(0.8, 1.25, al.N)
+    al2 = synth.Alignment(**{**al.__dict__, "idp": idp2})
+    for solver in (capi.SOLVER_LM6, capi.SOLVER_REF12):
+        cfg = capi.default_config(solver=solver, exec=capi.EXEC_DEVICE, max_num_iterations=6, num_blocks=2 if solver == capi.SOLVER_REF12 else 1)
+        h, fresh = capi.Handle(cfg, 1, al.N, al.H, al.W), capi.Handle(cfg, 1, al.N, al.H, al.W)
+        h.set_alignment(0, al); fresh.set_alignment(0, al2)
+        h.optimize(0, p=al.p0, q=al.q0, v=al.v0)                                  # something in flight before the refresh
+        h.set_idepth(0, idp2)
+        got = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+        want = fresh.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[3]["num_iterations"] == want[3]["num_iterations"]
+        ncols = 12 if solver == capi.SOLVER_REF12 else 6
+        h.set_idepth(0, al.idp); h.set_idepth(0, idp2)                            # twice in a row: the staging is re-used behind its event
+        e1, e2 = h.eval(0, al.p0, al.q0, al.v0, ncols=ncols), fresh.eval(0, al.p0, al.q0, al.v0, ncols=ncols)
+        assert np.array_equal(e1["r"], e2["r"]) and np.array_equal(e1["JtJ"], e2["JtJ"])
+        h.close(); fresh.close()
