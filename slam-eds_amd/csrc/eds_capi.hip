@@ -376,6 +376,38 @@ static int unshare_frames(eds_trk* h, int first, int count) {
     return EDS_OK;
 }
 #define EDS_UPLOAD_BANDS 4
+// fp64 -> fp32 narrowing of a band of the frame (set_event_frame's host work: 2.46 MB in, 1.23 MB out for 640x480).  The library is
+// built without -march, so the plain loop is SSE2 — cvtpd2ps, two doubles per instruction, 36 us per VGA frame; the hosts of the pool
+// (Zen 4 / 5) have AVX-512, older ones AVX2: pick at run time (function multiversioning by hand, __builtin_cpu_supports).
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx512f"))) static void narrow_avx512(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        _mm256_storeu_ps(dst + i, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i)));
+        _mm256_storeu_ps(dst + i + 8, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i + 8)));
+    }
+    for (; i < n; ++i) dst[i] = (float)src[i];
+}
+__attribute__((target("avx2"))) static void narrow_avx2(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        _mm_storeu_ps(dst + i, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)));
+        _mm_storeu_ps(dst + i + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4)));
+    }
+    for (; i < n; ++i) dst[i] = (float)src[i];
+}
+#endif
+static void narrow_band(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
+#if defined(__x86_64__)
+    static const int level = __builtin_cpu_supports("avx512f") ? 2 : (__builtin_cpu_supports("avx2") ? 1 : 0);
+    if (level == 2) return narrow_avx512(src, dst, n);
+    if (level == 1) return narrow_avx2(src, dst, n);
+#endif
+    for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i];       // (round-to-nearest-even in every variant: bit-identical results)
+}
+static void narrow_band(const float* __restrict__ src, float* __restrict__ dst, size_t n) { std::memcpy(dst, src, n * sizeof(float)); }
+
 template <class T>
 static int upload_frame(eds_trk* h, int slot, const T* frame) {
     { int rc_ = unshare_frames(h, slot, 1); if (rc_) return rc_; }     // a frame of its own again
@@ -384,7 +416,7 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
     for (int k = 0; k < EDS_UPLOAD_BANDS; ++k) {
         const int rb = h->H * k / EDS_UPLOAD_BANDS, re = h->H * (k + 1) / EDS_UPLOAD_BANDS;
         const size_t b = (size_t)rb * h->W, e = (size_t)re * h->W;
-        for (size_t i = b; i < e; ++i) stage[i] = (float)frame[i];
+        narrow_band(frame + b, stage + b, e - b);
         eds_frame_store_rowmajor(h, slot, h->d_fstage, rb, re);
     }
     EDS_HIP_TRY(hipGetLastError());
