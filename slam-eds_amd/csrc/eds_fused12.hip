@@ -437,6 +437,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     s_k = k; s_head = head;
                 }
             }
+            EDS_WSYNC();
+            if (edsc::uniform_int(s_walk) == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[edsc::uniform_int(s_k)], lane);
         }
         __syncthreads();
         // the sums are consumed: every thread clears its share for the next evaluation (the barrier that ends the solver phase orders
@@ -464,6 +466,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 s_k = k; s_head = head;
             }
             __syncthreads();
+            if (wave == 0 && s_walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[s_k], lane);     // (ordered before its readers by the barrier below)
         }
         if (tid == 0) {
 #ifdef EDS_FUSED_STAMPS

@@ -72,6 +72,7 @@ struct Cand12 {                 // one prepared step
 };
 struct Step12 {                 // LDS scratch of one proposing wavefront
     double y[12], t[12];
+    double L[144];              // the Cholesky factor, row-major, so that lane i can pick up COLUMN i for the back substitution
     int ok, pad;
 };
 
@@ -116,10 +117,7 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
             } else {
                 const double rel = cost_change / sv.model_cost_change;
                 if (rel > 1e-3) {                                       // HandleSuccessfulStep, first half
-                    for (int i = 0; i < 3; ++i) sv.p[i] = sv.cp[i];
-                    for (int i = 0; i < 4; ++i) sv.q[i] = sv.cq[i];
-                    for (int i = 0; i < 6; ++i) sv.v[i] = sv.cv[i];
-                    sv.x_norm = Solver12::norm13(sv.p, sv.q, sv.v);
+                    sv.x_norm = Solver12::norm13(sv.cp, sv.cq, sv.cv);  // (x <- candidate: the 13 copies are done by 13 lanes below)
                     W.rel = rel;
                     mode = M_LIN_ACCEPT;
                 } else {                                                // HandleUnsuccessfulStep
@@ -134,6 +132,12 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
     EDS_CSTAMP(0);
     const int mode = uniform_int(W.mode);
     if (mode == M_RETURN || mode == M_ADVANCE) return mode;
+    if (mode == M_LIN_ACCEPT) {          // x <- candidate point (HandleSuccessfulStep), one double per lane
+        if (lane < 3) sv.p[lane] = sv.cp[lane];
+        else if (lane < 7) sv.q[lane - 3] = sv.cq[lane - 3];
+        else if (lane < 13) sv.v[lane - 7] = sv.cv[lane - 7];
+        EDS_WSYNC();
+    }
 
     {                                   // Solver12::linearise at the (new) accepted point
         bool bad = !(fabs(W.cost) < 1e300);
@@ -267,13 +271,24 @@ __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand1
         const double yk = bcast(bi, k);
         if (row > k) bi -= Lr[k] * yk;
     }
+    // L^T x = y.  Entry (k, i) of L lives in lane k, the sum of row i of L^T needs it in lane i: written with v_readlane that was two
+    // cross-lane moves per term inside the dependent chain (66 terms, ~4 000 cycles per proposal).  Round 3: the factor goes through
+    // LDS once (12 stores and 11 loads per lane, all in flight together), lane i then holds column i, and the substitution is the
+    // mirror image of the forward one: x_k is final on lane k, one broadcast, every lane i < k takes its term off.  (Terms leave
+    // s_i for k = 11 down to i + 1 — the serial code subtracts them upwards; the sums differ in the last bits.)
+    if (lane < 12) {
 #pragma unroll
-    for (int i = 11; i >= 0; --i) {                                      // L^T x = y
-        double s = bcast(bi, i);
+        for (int b = 0; b < 12; ++b) W.L[12 * lane + b] = Lr[b];
+    }
+    EDS_WSYNC();
+    double Lc[12];                                                       // Lc[k] = L[k][row], k > row
 #pragma unroll
-        for (int k = i + 1; k < 12; ++k) s -= bcast(Lr[i], k) * bcast(bi, k);          // L[k][i] lives in lane k
-        const double xi = s * bcast(idr, i);
-        if (row == i) bi = xi;
+    for (int k = 0; k < 12; ++k) Lc[k] = W.L[12 * k + row];
+#pragma unroll
+    for (int k = 11; k >= 0; --k) {
+        if (row == k) bi = bi * idr;
+        const double xk = bcast(bi, k);
+        if (row < k) bi -= Lc[k] * xk;
     }
     if (lane == 0) W.ok = okl ? 1 : 0;
     if (lane < 12) { W.y[lane] = bi; c.step[lane] = -bi; }
@@ -320,9 +335,19 @@ __device__ inline int coop12_walk(edss::Solver12& sv, const Cand12* cand, int* k
                 ++sv.num_successful;
                 if (sv.x_cost < sv.minimum_cost || sv.iteration == 0) {
                     sv.minimum_cost = sv.x_cost;
-                    for (int i = 0; i < 3; ++i) sv.best_p[i] = sv.p[i];
-                    for (int i = 0; i < 4; ++i) sv.best_q[i] = sv.q[i];
-                    for (int i = 0; i < 6; ++i) sv.best_v[i] = sv.v[i];
+                    double bp[3], bq[4], bv[6];         // all loads in flight before the first store waits for one
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) bp[i] = sv.p[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) bq[i] = sv.q[i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) bv[i] = sv.v[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) sv.best_p[i] = bp[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) sv.best_q[i] = bq[i];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) sv.best_v[i] = bv[i];
                 }
             } else {
                 ++sv.num_unsuccessful;
@@ -343,14 +368,21 @@ __device__ inline int coop12_walk(edss::Solver12& sv, const Cand12* cand, int* k
             continue;                   // counts as an unsuccessful iteration
         }
         sv.consecutive_invalid = 0;
-        for (int i = 0; i < 12; ++i) sv.step[i] = c.step[i];
-        sv.model_cost_change = c.mcc;
-        for (int i = 0; i < 3; ++i) sv.cp[i] = c.cp[i];
-        for (int i = 0; i < 4; ++i) sv.cq[i] = c.cq[i];
-        for (int i = 0; i < 6; ++i) sv.cv[i] = c.cv[i];
         *head_done = 0;
-        return W_EVAL;
+        return W_EVAL;                  // the step itself is taken by coop12_take (26 doubles: one per lane instead of one after the other)
     }
+}
+
+// Second half of the W_EVAL case of coop12_walk: the prepared step `c` becomes the solver's step and candidate point.  Wavefront 0, all
+// lanes, after lane 0's coop12_walk returned W_EVAL (and a wave-level sync).  On lane 0 these 26 LDS-to-LDS copies ran one after the
+// other, each waiting for its load: ~2 000 cycles of every evaluation.
+__device__ inline void coop12_take(edss::Solver12& sv, const Cand12& c, const int lane) {
+    if (lane < 12) sv.step[lane] = c.step[lane];
+    else if (lane == 12) sv.model_cost_change = c.mcc;
+    else if (lane < 16) sv.cp[lane - 13] = c.cp[lane - 13];
+    else if (lane < 20) sv.cq[lane - 16] = c.cq[lane - 16];
+    else if (lane < 26) sv.cv[lane - 20] = c.cv[lane - 20];
+    EDS_WSYNC();
 }
 
 // edsm::fill_pose_block, cooperatively (G: the per-block Gram matrices of the slot, nb <= EDS_DEV_MAX_BLOCKS)

@@ -105,4 +105,42 @@ int hl_frame_layout(int H, int W, int tiled, int* Hp_out, int* Wp_out, int r, in
     return bad;
 }
 
+// Strip copies of the frames (eds_layout.hpp, round 3).  Builds the copies of an Hp x Wp allocation whose element (r, c) holds the
+// value r * Wp + c with the rule of the conversion kernel (eds_strips.hip: copy 2 p + cc holds allocation row r at position r - p,
+// strips cut at column 4 cc), then walks every patch position a kernel can ask for (first row ra in [1, Hp - 4], first column ca in
+// [1, Wp - 4]) through eds_strips_row_offset and checks the 16 taps; returns the number of wrong taps and, in stats, the number of
+// patches and how many of them start on a 32 * phases byte boundary / lie inside ONE 128-byte line.
+int hl_strips_layout(int Hp, int Wp, int phases, long long* stats) {
+    const int NS = eds_strips_count(Wp);
+    const size_t copy_elems = eds_strips_copy_elems(Hp, Wp);
+    std::vector<float> alloc((size_t)Hp * Wp), strips((size_t)2 * phases * copy_elems, -1.0f);
+    for (int r = 0; r < Hp; ++r)
+        for (int c = 0; c < Wp; ++c) alloc[(size_t)r * Wp + c] = (float)(r * Wp + c);
+    for (int p = 0; p < phases; ++p)
+        for (int cc = 0; cc < 2; ++cc)
+            for (int sidx = 0; sidx < NS; ++sidx)
+                for (int pos = 0; pos < Hp; ++pos)
+                    for (int j = 0; j < 8; ++j) {
+                        int row = pos + p; if (row > Hp - 1) row = Hp - 1;
+                        int col = 8 * sidx + 4 * cc + j; if (col > Wp - 1) col = Wp - 1;      // (the kernel clamps whole 4-column pieces: never sampled either way)
+                        strips[(size_t)(2 * p + cc) * copy_elems + ((size_t)sidx * Hp + pos) * 8 + j] = alloc[(size_t)row * Wp + col];
+                    }
+    long long bad = 0, patches = 0, aligned = 0, one_line = 0;
+    const unsigned copy_bytes = (unsigned)(copy_elems * 4);
+    for (int ra = 1; ra <= Hp - 4; ++ra)
+        for (int ca = 1; ca <= Wp - 4; ++ca) {
+            const unsigned off = eds_strips_row_offset(ra, ca, Hp, copy_bytes, phases);
+            ++patches;
+            aligned += (off & ~31u) % (32u * phases) == 0 ? 1 : 0;          // the 32-byte strip row the patch starts in
+            one_line += ((off & ~31u) / 128u == ((off & ~31u) + 127u) / 128u) ? 1 : 0;
+            for (int k = 0; k < 4; ++k)
+                for (int j = 0; j < 4; ++j) {
+                    const size_t e = (size_t)(off / 4) + 8 * k + j;
+                    if (e >= strips.size() || strips[e] != alloc[(size_t)(ra + k) * Wp + ca + j]) ++bad;
+                }
+        }
+    stats[0] = patches; stats[1] = aligned; stats[2] = one_line;
+    return (int)(bad > 2000000000ll ? 2000000000ll : bad);
+}
+
 }  // extern "C"

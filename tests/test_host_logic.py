@@ -171,3 +171,21 @@ def test_frame_allocation_index_is_a_bijection(hl, H, W, tiled):
         assert got == list(range(16))
         hl.hl_frame_layout(H, W, 1, C.byref(Hp), C.byref(Wp), -1, -1, C.byref(idx))           # margin pixel: last element of the tile up-left
         assert idx.value == origin - (Wp.value // 4 + 1) * 16 + 15
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (61, 83), (720, 1280)])
+@pytest.mark.parametrize("phases", [1, 2, 4])
+def test_strip_copies_hold_every_patch_in_place(hl, H, W, phases):
+    """eds_layout.hpp, round 3: for every patch position a kernel can ask for, the 16 taps sit at eds_strips_row_offset + 32 k + 4 j of
+    the strip copies (built here with the conversion kernel's rule); with 4 row phases every patch starts on a 128-byte boundary, i.e.
+    is exactly ONE L2 line — the property the layout exists for; with 1 phase 1 in 4 patches is."""
+    Hp, Wp = ((H + 3) & ~3) + 8, ((W + 3) & ~3) + 8
+    stats = (C.c_longlong * 3)()
+    bad = hl.hl_strips_layout(Hp, Wp, phases, stats)
+    patches, aligned, one_line = stats[0], stats[1], stats[2]
+    assert bad == 0 and patches == (Hp - 4) * (Wp - 4)
+    assert aligned == patches                                       # every patch starts at a multiple of 32 * phases bytes
+    if phases == 4:
+        assert one_line == patches
+    else:
+        assert abs(one_line / patches - phases / 4.0) < 0.02        # 1 phase: rows = 0 mod 4 only; 2 phases: rows = 0, 1 mod 4

@@ -1,0 +1,75 @@
+"""eds_trk_last_launch / eds_trk_prepare_frames (include/eds_hip.h, round 3): the library says which kernel a solve launched — bench.py
+prices that kernel instead of mirroring the selection rule — and the strip copies of the frames (csrc/eds_layout.hpp) follow every
+change of a frame without the caller doing anything."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(capi, synth, B, N=2000, H=240, W=320, distinct=8, **cfg):
+    als = [synth.make_alignment(8100 + i, H=H, W=W, N=N) for i in range(distinct)]
+    h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, max_num_iterations=6, **cfg), B, N, H, W)
+    for b in range(B):
+        h.set_alignment(b, als[b % distinct])
+    P = np.stack([als[b % distinct].p0 for b in range(B)]); Q = np.stack([als[b % distinct].q0 for b in range(B)]); V = np.stack([als[b % distinct].v0 for b in range(B)])
+    return h, als, (P, Q, V)
+
+
+def test_last_launch_names_the_kernel_that_ran(gpu, capi, synth):
+    h, als, (P, Q, V) = _batch(capi, synth, 200, solver=capi.SOLVER_LM6)
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, 200)
+    li = h.last_launch()
+    assert li["kernel"] == "eds_fused6_kernel<0, 4, 512, 3, 1>" and li["layout"] == 2           # strips, LDS landing zone, one CU per alignment
+    assert (li["workgroups"], li["cus_per_alignment"], li["first"], li["count"], li["timing_source"]) == (200, 1, 0, 200, 0)
+    assert li["span_us"] > 0 and 0.0 < li["covered"] <= 1.0 and li["mean_workgroup_us"] <= li["span_us"] and li["tail_idle_us"] >= 0
+    # a handful of alignments: several CUs each, timed from the kernels' own stamps, no digest
+    h.set_states(0, P[:8], Q[:8], V[:8]); h.optimize_batch(0, 0, 8)
+    li = h.last_launch()
+    assert li["cus_per_alignment"] == 4 and li["workgroups"] == 32 and li["timing_source"] == 1 and li["span_us"] == 0.0
+    assert li["kernel"].startswith("eds_fused6_kernel<0, 1, 512,") and li["kernel"].endswith(", 4>")
+    # the reference problem, and the per-point Huber variant of the pose-only kernel
+    h.set_config(capi.default_config(exec=capi.EXEC_DEVICE, max_num_iterations=6, solver=capi.SOLVER_REF12))
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, 200)
+    assert h.last_launch()["kernel"] == "eds_fused12_kernel<0, 512, 1408, false, 1, 2>" and h.last_launch()["layout"] == 2
+    h.set_config(capi.default_config(exec=capi.EXEC_DEVICE, max_num_iterations=6, solver=capi.SOLVER_LM6, huber_tau=0.01))
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, 200)
+    assert h.last_launch()["kernel"] == "eds_fused6_kernel<0, 4, 512, 4, 1>"
+    h.close()
+
+
+def test_strip_copies_follow_the_frames(gpu, capi, synth):
+    """A frame that changes between two solves (set_event_frame, a device-built frame, a shared frame) must be sampled as it is NOW:
+    every slot's result equals what a fresh handle gives for the same inputs, bit for bit."""
+    B = 64
+    h, als, (P, Q, V) = _batch(capi, synth, B, solver=capi.SOLVER_LM6)
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, B)
+    first = h.results(0, B).copy()
+    assert h.prepare_frames(0, B) >= 0.0                                          # nothing stale: a no-op
+    assert h.prepare_frames(0, B, force=True) > 0.0                               # measured conversion of all 64 frames
+    # slot 5 gets slot 6's frame, slot 9 shares slot 2's storage
+    h.set_event_frame(5, np.ascontiguousarray(als[6 % 8].frame, dtype=np.float32))
+    h.share_event_frame(9, 2)
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, B)
+    second = h.results(0, B).copy()
+    same = [b for b in range(B) if b not in (5, 9)]
+    assert np.array_equal(second[same], first[same])
+    assert not np.array_equal(second[5], first[5]) and not np.array_equal(second[9], first[9])
+    fresh = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, max_num_iterations=6, solver=capi.SOLVER_LM6), B, 2000, 240, 320)
+    for b in range(B):
+        a = als[b % 8]
+        fresh.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+        fresh.set_event_frame(b, np.ascontiguousarray(als[{5: 6, 9: 2}.get(b, b) % 8].frame, dtype=np.float32))
+    fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
+    assert np.array_equal(fresh.results(0, B), second)
+    # and the tile kernels (EDS_FUSED_LAYOUT=tiles is read per solve) agree with the strip kernels to the last bits of the fp32 sums
+    import os
+    os.environ["EDS_FUSED_LAYOUT"] = "tiles"
+    try:
+        fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
+        assert fresh.last_launch()["layout"] == 1
+        tiles = fresh.results(0, B)
+    finally:
+        os.environ.pop("EDS_FUSED_LAYOUT", None)
+    assert np.abs(tiles[:, :7] - second[:, :7]).max() < 1e-6 and np.array_equal(tiles[:, 14], second[:, 14])
+    h.close(); fresh.close()
