@@ -562,6 +562,9 @@ def main():
             t = pmc_traffic(launch["kernel"], a)
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
+                roof["traffic_note"] = ("raw (FETCH_SIZE + WRITE_SIZE) x 1024 of the committed rocprofv3 PMC passes; FETCH_SIZE tallies a fabric request "
+                                        "at 64 B and this kernel's requests are 128-byte line fills (one per gathered patch): bytes through the fabric "
+                                        "~ 2 x FETCH_SIZE + WRITE_SIZE (profiles/r03_summary.md)")
             launch_digest = {k: launch[k] for k in ("workgroups", "span_us", "mean_workgroup_us", "covered", "tail_idle_us")}
         rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
         both_ms = h.bench_eval(0, B, ncols=6, with_reduction=True, reps=20)
