@@ -1030,7 +1030,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const bool hub = tau > 0;                        // QUAD = 2 / 4: the per-point Huber weight compiled into the pair-packed point phase
     // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
     // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
-    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);
+    const bool strips = bicubic && quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);     // (bicubic: the bilinear
+                                                                                                                          // sampler has its own kernels)
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     if (strips) {
         if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }

@@ -123,6 +123,38 @@ def test_bench_shape_kernel_selected_by_optimize(gpu, capi, synth, po, als64):
     h.close()
 
 
+@pytest.mark.parametrize("sampling", [0, 1])
+@pytest.mark.parametrize("count", [8, 40, 300])
+@pytest.mark.parametrize("npts", [700, 1753])
+def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling, count, npts):
+    """The kernel rule switches gathers with the batch size (lane gather, pair-packed tiles, strips from 32 alignments) and with the
+    points per thread (1, 2, 4): at every combination the configured SAMPLER must be the one that runs.  (Round 3's soak found
+    bilinear batches of >= 32 alignments on 2 or 4 points per thread being solved by the bicubic strips kernel: 5e-3 from the
+    oracle.  The first template argument of the reported kernel is the sampler; the oracle comparison is the proof.)"""
+    H, W = 120, 160
+    als = [synth.make_alignment(900 + i, H=H, W=W, N=n, margin=2) for i, n in enumerate((npts, npts - 37, 130, npts // 2))]
+    # start away from the identity: there every point sits exactly on a pixel centre, where the bilinear sampler's derivative is
+    # one-sided and which side a coordinate falls on is a matter of the last bit (fp32 kernel vs fp64 oracle)
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    for tau in (0.0, 0.02):
+        cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, sampling=sampling, max_num_iterations=5, huber_tau=tau)
+        h = capi.Handle(cfg, count, npts, H, W)
+        for b in range(count):
+            h.set_alignment(b, als[b % 4])
+        h.set_states(0, np.stack([ps] * count), np.stack([qs] * count), np.stack([als[b % 4].v0 for b in range(count)]))
+        h.optimize_batch(0, 0, count)
+        tab = h.results(0, count)
+        kern = h.last_launch()["kernel"]
+        assert kern.startswith(f"eds_fused6_kernel<{sampling},"), kern
+        for i, a in enumerate(als):
+            ref = po.Oracle(a, sampling=sampling).pose6_lm(ps, qs, a.v0, iters=5, lambda0=cfg.lambda0, huber_tau=tau)
+            for slot in (i, i + 4 * ((count - 1 - i) // 4)):
+                assert po.se3_distance(tab[slot, 0:3], tab[slot, 3:7], ref["p"], ref["q"]) <= TOL_POSE, (kern, slot)
+                assert tab[slot, 14] == ref["iterations"]
+                assert np.array_equal(h.trace(slot)["accepted"], ref["accepted"]), (kern, slot)
+        h.close()
+
+
 def test_new_keyframe_invalidates_device_residuals(gpu, capi, synth):
     """after a device-mode solve, set_keyframe must not leave 'residuals still in HBM' set — get_residuals /
     loss_param before the next optimize then report EDS_ERR_STATE instead of the previous keyframe's plane."""

@@ -13,7 +13,35 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 H, W = 120, 160
 pool = [synth.make_alignment(int(rng.integers(1 << 30)), H=H, W=W, N=int(n), margin=2) for n in
         list(rng.integers(1, 60, 6)) + list(rng.integers(60, 700, 14)) + list(rng.integers(700, 2300, 8))]
-bad = 0
+bad = sensitive = 0
+
+
+def oracle_solution(a, kw):
+    """fp64 oracle for the same problem: where the lone fp32 solve is itself as far from it as the batch is from the lone solve, the
+    difference is the problem's conditioning (undamped Gauss-Newton on 5 points, say), not the batch path."""
+    if kw["solver"] == capi.SOLVER_REF12:
+        o = po.Oracle(a, sampling=kw["sampling"], num_blocks=kw["num_blocks"], loss_type=kw["loss_type"], loss_param=kw["loss_param"],
+                      max_num_iterations=kw["max_num_iterations"])
+        r = o.solve_lm(a.p0, a.q0, a.v0)
+        return r["p"], r["q"], r["num_iterations"]
+    o = po.Oracle(a, sampling=kw["sampling"])
+    if kw["solver"] == capi.SOLVER_LM6:
+        r = o.pose6_lm(a.p0, a.q0, a.v0, iters=kw["max_num_iterations"], lambda0=0.01, huber_tau=kw["huber_tau"])
+    else:
+        r = o.pose6_gn(a.p0, a.q0, a.v0, iters=kw["max_num_iterations"], huber_tau=kw["huber_tau"])
+    return r["p"], r["q"], r["iterations"]
+
+
+def is_sensitive(a, kw, ts, d):
+    try:
+        p, q, it = oracle_solution(a, kw)
+    except Exception:
+        return True                                  # the fp64 oracle cannot solve it either (singular normal equations)
+    if ts[15] != 1.0 or it != ts[14]:
+        return True
+    return po.se3_distance(ts[0:3], ts[3:7], p, q) >= 0.3 * d
+
+
 for t in range(trials):
     B = int(rng.choice([2, 7, 33, 97, 130, 257, 300, 520]))
     solver = capi.SOLVER_REF12 if rng.random() < 0.5 else (capi.SOLVER_LM6 if rng.random() < 0.8 else capi.SOLVER_GN6)
@@ -44,13 +72,20 @@ for t in range(trials):
             hs.close()
         ts, rs = singles[i]
         if ts[15] != tab[k, 15] or ts[14] != tab[k, 14]:
-            print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver}: status/iterations differ: batch {tab[k, 14:16]} single {ts[14:16]}"); bad += 1
+            if is_sensitive(pool[i], kw, ts, 1e-5):
+                sensitive += 1
+            else:
+                print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver}: status/iterations differ: batch {tab[k, 14:16]} single {ts[14:16]}"); bad += 1
             continue
         if ts[15] != 1.0:
             continue
         d = po.se3_distance(tab[k, 0:3], tab[k, 3:7], ts[0:3], ts[3:7])
         dr = np.abs(res[k] - rs).max() / max(np.abs(rs).max(), 1e-30)
         if (d > 1e-5 or dr > 1e-3) and pool[i].N >= 100:
-            print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver} kw={kw}: pose differs by {d:.2e}, residuals by {dr:.2e}"); bad += 1
+            if is_sensitive(pool[i], kw, ts, max(d, 1e-5)):
+                sensitive += 1
+            else:
+                print(f"trial {t} B={B} slot {first + k} N={pool[i].N} solver={solver} kw={kw}: pose differs by {d:.2e}, residuals by {dr:.2e}"); bad += 1
     print(f"trial {t}: B={B} range [{first}, {first + count}) solver={solver} ok", flush=True)
-print(f"{trials} trials, {bad} disagreements")
+print(f"{trials} trials, {bad} disagreements ({sensitive} slots differed on problems where the lone fp32 solve is as far from the fp64 oracle: conditioning, not counted)")
+sys.exit(1 if bad else 0)

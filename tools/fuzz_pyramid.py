@@ -21,6 +21,7 @@ for t in range(trials):
     pyr.set_event_frame(al.frame)
     p, q, v, infos = pyr.optimize(al.p0, al.q0, al.v0)
     cp, cq, cv = al.p0.copy(), al.q0.copy(), al.v0.copy()
+    chain = [None] * L
     for l in range(L - 1, -1, -1):
         hl, wl = pyr.level_size(l)
         h = capi.Handle(cfg, 1, counts[l], hl, wl)
@@ -29,13 +30,19 @@ for t in range(trials):
         h.set_keyframe(0, al.norm_coord[:n], al.grad[:n], al.idp[:n], al.weights[:n], *K)
         h.set_event_frame(0, pyr.level_frame(l))
         try:
-            cp, cq, cv, _ = h.optimize(0, level=l, p=cp, q=cq, v=cv)
-        except capi.EdsError:
-            pass                                    # not usable: the next level starts from the last good pose
+            cp, cq, cv, chain[l] = h.optimize(0, level=l, p=cp, q=cq, v=cv)
+            chain[l]["kernel"] = h.last_launch()["kernel"]
+        except capi.EdsError as e:
+            chain[l] = {"error": str(e)}            # not usable: the next level starts from the last good pose
         h.close()
     d = po.se3_distance(p, q, cp, cq)
     ok = d <= 1e-8 and np.abs(v - cv).max() <= 1e-8
     print(f"trial {t}: {H}x{W} L={L} counts={counts} ref12={ref12}  distance {d:.2e}  {'ok' if ok else 'DISAGREE'}", flush=True)
+    if not ok:
+        keys = ("num_iterations", "num_successful_steps", "termination", "initial_cost", "final_cost", "usable", "flags")
+        for l in range(L - 1, -1, -1):
+            print(f"    level {l}: pyramid " + " ".join(f"{k}={infos[l].get(k)}" for k in keys), flush=True)
+            print(f"    level {l}: chain   " + " ".join(f"{k}={chain[l].get(k)}" for k in keys) + f" {chain[l].get('kernel', chain[l].get('error'))}", flush=True)
     bad += 0 if ok else 1
     pyr.close()
 print(f"{trials} trials, {bad} disagreements")
