@@ -621,7 +621,7 @@ def main():
             out["bilinear_sampling"] = {"iterations_per_s": B * float(np.mean(bt[:, 14])) / (float(np.median(b_ms[1:])) * 1e-3),
                                         "kernel_ms": float(np.median(b_dev[1:])),
                                         "roofline_frac": B * N * passes * per_pt_b / (float(np.median(b_dev[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                        "success_fraction": float(np.mean(bt[:, 15]))}
+                                        "success_fraction": float(np.mean(bt[:, 15])), "kernel": h.last_launch()["kernel"]}
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device" and N <= 2048 and not a.no_ref12:
             # the reference's own problem on the same batch (12 local parameters, Ceres-LM rules; one residual block, no

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     constexpr int NREG = PPT > 0 ? PPT : 1;
     constexpr bool CACHE = true;
-    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NTAP : 1][CACHE ? EDS_CACHE_CAP : 1];
+    constexpr int NPATCH = (QUAD >= 3) ? 16 : NTAP;      // the strips' landing zone holds 4 rows x 4 pixels per point whatever the sampler reads of them
+    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NPATCH : 1][CACHE ? EDS_CACHE_CAP : 1];
     __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     // start of that allocation (quad gather); fslot is wave-uniform, so this is scalar arithmetic and the address lives in SGPRs
     // (the product in a 32-bit scalar multiply: 64-bit it became VALU work whose result sat in VGPRs — two v_readfirstlane per load)
     const float* __restrict__ tiles = A.frame + (size_t)((unsigned)fslot * (unsigned)(A.Hp * A.Wp / 16)) * 16;
-    static_assert(!QUAD || (SAMPLING == 0 && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: bicubic, register-resident points, all cached");
+    static_assert(!QUAD || ((SAMPLING == 0 || QUAD >= 3) && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: register-resident points, all cached; the bilinear sampler on strips only");
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     const int oq[4] = {o0, o1, o2, o3};
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (oq[q] < 0)
+                        if (oq[q] < 0 && (SAMPLING == 0 || jr == 1 || jr == 2))      // (the bilinear sampler reads rows 1 and 2 of the patch only)
                             __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * 256), 16, 0, 0);
                 }
             }
@@ -314,14 +315,24 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     tb[k] = (f2){mine[(4 * j + 2) * 256 + k], mine[(4 * j + 3) * 256 + k]};
                 }
                 f2 f01, d01, f23, d23;
-                hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
-                hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
+                if constexpr (SAMPLING == 0) {
+                    hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
+                    hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
+                } else {            // bilinear: the row's two middle pixels, value and column difference (oracle/eds_oracle.hpp bilinear())
+                    d01 = ta[2] - ta[1]; f01 = ta[1] + x01 * d01;
+                    d23 = tb[2] - tb[1]; f23 = tb[1] + x23 * d23;
+                }
                 float f[4] = {f01.x, f01.y, f23.x, f23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
                 quad_transpose(f, lane);
                 quad_transpose(d, lane);
                 f2 EEc, dE;
                 const f2 y2 = (f2)(ay_j);
-                hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
+                if constexpr (SAMPLING == 0) {
+                    hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
+                } else {
+                    dE = (f2){f[2] - f[1], d[2] - d[1]};
+                    EEc = (f2){f[1], d[1]} + y2 * dE;
+                }
                 const float iz_j = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_j = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_j = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
                 const float w_j = (j & 1) ? k2w[g].y : k2w[g].x, mh_j = (j & 1) ? k2mh[g].y : k2mh[g].x;
                 rcand[j] = row6_accumulate<(QUAD == 4)>(ps_fx, ps_fy, iz_j, un_j, vn_j, EEc.x, dE.x, EEc.y, w_j, mh_j, tau, A6);
@@ -980,9 +991,11 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
     if (team > 1) {
         const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-        const bool q = bic && count * team >= 128 && h->H < 8000;   // enough gathers in flight for the quad-cooperative form to pay
-        // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member)
-        const bool strips = q && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_prepare(h, first, count);
+        const bool qany = count * team >= 128 && h->H < 8000;       // enough gathers in flight for the quad-cooperative form to pay
+        const bool q = bic && qany;                                 // (on tiles: the bicubic sampler only)
+        // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member);
+        // either sampler
+        const bool strips = qany && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_prepare(h, first, count);
         A.strips = h->dstrips; A.strip_phases = h->strip_phases;
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
@@ -997,7 +1010,8 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         fb.ticket_base += (unsigned)(count * team);
         for (int s = first; s < first + count; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
         // (QUAD = 2: the pair-packed point phase with the per-point Huber weight compiled in; points in pairs need an even PPT)
-#define EDS_TEAM_Q2(K) do { if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K);                           \
+#define EDS_TEAM_Q2(K) do { if (!bic && strips) { if (tau > 0) EDS_LAUNCH_TEAM(1, 2, 4, K); else EDS_LAUNCH_TEAM(1, 2, 3, K); }            \
+                            else if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K);                      \
                             else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 4, K); else EDS_LAUNCH_TEAM(0, 2, 3, K); }                 \
                             else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
         if (team == 4 && maxN <= 2048) {             // 512 points per member, one per lane
@@ -1030,12 +1044,15 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const bool hub = tau > 0;                        // QUAD = 2 / 4: the per-point Huber weight compiled into the pair-packed point phase
     // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
     // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
-    const bool strips = bicubic && quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);     // (bicubic: the bilinear
-                                                                                                                          // sampler has its own kernels)
+    // Either sampler: the bilinear one reads the two middle rows / columns of the same 4 x 4 patch (its own kernels everywhere else).
+    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
-    if (strips) {
+    if (strips && bicubic) {
         if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }
         else { if (hub) EDS_LAUNCH_FUSED(0, 4, 512, 4); else EDS_LAUNCH_FUSED(0, 4, 512, 3); }
+    } else if (strips) {
+        if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(1, 2, 4); else EDS_LAUNCH_FUSED_T(1, 2, 3); }
+        else { if (hub) EDS_LAUNCH_FUSED(1, 4, 512, 4); else EDS_LAUNCH_FUSED(1, 4, 512, 3); }
     } else
     switch (ppt) {
         case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_BILINEAR(1, 1); break;

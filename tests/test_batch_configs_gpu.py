@@ -125,12 +125,13 @@ def test_bench_shape_kernel_selected_by_optimize(gpu, capi, synth, po, als64):
 
 @pytest.mark.parametrize("sampling", [0, 1])
 @pytest.mark.parametrize("count", [8, 40, 300])
-@pytest.mark.parametrize("npts", [700, 1753])
+@pytest.mark.parametrize("npts", [700, 1753, 3000])
 def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling, count, npts):
     """The kernel rule switches gathers with the batch size (lane gather, pair-packed tiles, strips from 32 alignments) and with the
     points per thread (1, 2, 4): at every combination the configured SAMPLER must be the one that runs.  (Round 3's soak found
     bilinear batches of >= 32 alignments on 2 or 4 points per thread being solved by the bicubic strips kernel: 5e-3 from the
-    oracle.  The first template argument of the reported kernel is the sampler; the oracle comparison is the proof.)"""
+    oracle.  The first template argument of the reported kernel is the sampler; the oracle comparison is the proof.)  3 000 points
+    run on teams of 4 CUs; from 32 alignments both samplers gather from the strips."""
     H, W = 120, 160
     als = [synth.make_alignment(900 + i, H=H, W=W, N=n, margin=2) for i, n in enumerate((npts, npts - 37, 130, npts // 2))]
     # start away from the identity: there every point sits exactly on a pixel centre, where the bilinear sampler's derivative is
@@ -146,6 +147,9 @@ def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling,
         tab = h.results(0, count)
         kern = h.last_launch()["kernel"]
         assert kern.startswith(f"eds_fused6_kernel<{sampling},"), kern
+        # the rule of eds_fused_solve: strips from 32 alignments, except where teams of 4 CUs x 512 points (one per lane) run
+        expect_strips = count >= 32 and not (1024 < npts <= 2048 and count <= 128)
+        assert (h.last_launch()["layout"] == 2) == expect_strips, (kern, h.last_launch()["layout"])
         for i, a in enumerate(als):
             ref = po.Oracle(a, sampling=sampling).pose6_lm(ps, qs, a.v0, iters=5, lambda0=cfg.lambda0, huber_tau=tau)
             for slot in (i, i + 4 * ((count - 1 - i) // 4)):
