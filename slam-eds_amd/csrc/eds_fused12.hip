@@ -176,6 +176,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             for (int jj = 0; jj < 2; ++jj) {
                 const int i = j0 + jj * nthr + tid;
                 const bool valid = i < hi;
+                // a wavefront whose 64 points of this half all lie beyond the slice skips the half altogether (wave-uniform): a lone
+                // alignment on 8 CUs has 250 points for 512 threads x 2 points — without this every lane dragged a second, silent
+                // point through projection, gather and spline
+                if (!QUAD && edsc::uniform_int(j0 + jj * nthr + wave * 64) >= hi) { miss[jj] = false; kw[jj] = 0.0f; continue; }
                 const size_t o = base + (valid ? i : 0);
                 const float* __restrict__ c = A.kf + o;                 // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
                 const size_t pl = A.kf_plane;
@@ -231,6 +235,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const int i = j0 + jj * nthr + tid;
                 const bool valid = i < hi;
                 const int i_first = j0 + jj * nthr + wave * 64;        // this wavefront's 64 consecutive points
+                if (!QUAD && edsc::uniform_int(i_first) >= hi) continue;
                 const int i_last = (i_first + 63 < hi) ? i_first + 63 : hi - 1;
                 const int b_lo = edsc::uniform_int(block_of(i_first < hi ? i_first : 0, ne, nb));
                 const int b_hi = edsc::uniform_int(block_of(i_last > 0 ? i_last : 0, ne, nb));
@@ -394,21 +399,24 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 // all 2 K granules of the entry in flight at once (the members sit on other XCDs: every load is a fabric round trip,
                 // and 2 K of them one after the other were ~4 us per evaluation), then only the late ones are polled again
                 double tot = 0.0;
-                constexpr int GM = TEAM < 4 ? TEAM : 4;             // members per round of loads
+                constexpr int GM = TEAM < 4 ? TEAM : 4;             // members per round of loads (all 8 members of a team in one round: no faster)
 #pragma unroll
                 for (int m0 = 0; m0 < TEAM; m0 += GM) {
                     unsigned long long v[2 * GM];
 #pragma unroll
                     for (int k = 0; k < 2 * GM; ++k)
                         v[k] = __hip_atomic_load(mb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {                  // the late ones are asked for again TOGETHER (one after the other, every straggler cost
+                        bool late = false;      // a fabric round trip of its own even when all of them had long arrived)
 #pragma unroll
-                    for (int k = 0; k < 2 * GM; ++k) {
-                        const unsigned long long* g = mb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1);
-                        while ((unsigned)(v[k] >> 32) != tag) {
-                            if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
-                            __builtin_amdgcn_s_sleep(2);
-                            v[k] = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
+                        for (int k = 0; k < 2 * GM; ++k) late |= (unsigned)(v[k] >> 32) != tag;
+                        if (!late) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int k = 0; k < 2 * GM; ++k)
+                            if ((unsigned)(v[k] >> 32) != tag)
+                                v[k] = __hip_atomic_load(mb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #pragma unroll
                     for (int m = 0; m < GM; ++m)
@@ -426,19 +434,16 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         EDS12_STAMP(1);
         if (wave == 0) {                        // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
             const int mode = edsc::coop12_decide(sv, sums, work, s_pose, lane);          // linearisation if it was accepted,
-            if (lane == 0) {                    // and the bookkeeping up to the next step — a prepared one, if there is one
-                s_accept = work.accepted;
-                if (mode == edsc::M_RETURN) {
-                    s_walk = edsc::W_RETURN;
-                } else {
-                    int k = (mode == edsc::M_ADVANCE) ? s_k + 1 : EDS_NCAND;             // one notch down the radius sequence / all stale
-                    int head = 0;
-                    s_walk = edsc::coop12_walk(sv, s_cand, &k, &head);
-                    s_k = k; s_head = head;
-                }
+            // and the bookkeeping up to the next step — a prepared one, if there is one (every lane walks; lane 0 keeps the outcome)
+            edsc::Walk12 wk{edsc::W_RETURN, 0, 0};
+            if (mode != edsc::M_RETURN)
+                wk = edsc::coop12_walk(sv, s_cand, (mode == edsc::M_ADVANCE) ? edsc::uniform_int(s_k) + 1 : EDS_NCAND, 0, lane);   // one notch down the radius sequence / all stale
+            if (lane == 0) {
+                s_accept = (mode == edsc::M_LIN_ITER0 || mode == edsc::M_LIN_ACCEPT) ? 1 : 0;
+                s_walk = wk.walk;
+                if (mode != edsc::M_RETURN) { s_k = wk.k; s_head = wk.head; }
             }
-            EDS_WSYNC();
-            if (edsc::uniform_int(s_walk) == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[edsc::uniform_int(s_k)], lane);
+            if (wk.walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[wk.k], lane);
         }
         __syncthreads();
         // the sums are consumed: every thread clears its share for the next evaluation (the barrier that ends the solver phase orders
@@ -460,13 +465,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
             __syncthreads();
             EDS12_SOLVE_STAMP(5);               // waiting for the slowest of the proposing wavefronts
-            if (tid == 0) {
-                int k = 0, head = s_head;
-                s_walk = edsc::coop12_walk(sv, s_cand, &k, &head);
-                s_k = k; s_head = head;
+            if (wave == 0) {
+                const edsc::Walk12 wk = edsc::coop12_walk(sv, s_cand, 0, edsc::uniform_int(s_head), lane);
+                if (lane == 0) { s_walk = wk.walk; s_k = wk.k; s_head = wk.head; }
+                if (wk.walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[wk.k], lane);
             }
-            __syncthreads();
-            if (wave == 0 && s_walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[s_k], lane);     // (ordered before its readers by the barrier below)
+            __syncthreads();            // (s_walk: the loop condition of every thread; the taken step: before its readers)
         }
         if (tid == 0) {
 #ifdef EDS_FUSED_STAMPS

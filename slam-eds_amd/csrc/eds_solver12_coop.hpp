@@ -85,52 +85,70 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
 #ifdef EDS_FUSED_STAMPS
     if (lane == 0) W.st_t = __builtin_readcyclecounter();
 #endif
+    // Round 3: every lane takes the decision (same operands, read from LDS as broadcasts, all loads in flight together; the block
+    // costs come by v_readlane) — on lane 0 alone this was a chain of dependent LDS round trips: r0 -> cost -> final_pass? ->
+    // started? -> the 26 coordinates -> mode -> W.mode -> every lane.  Lane 0 stores what the decision changes.
+    double r0 = 0.0, r1 = 1.0;
     if (lane < nb) {
-        double r0, r1;
         loss_eval(sv.loss_type, sv.loss_a, S.s[lane], &r0, &r1);
-        W.r0[lane] = r0; W.r1[lane] = r1;
+        W.r1[lane] = r1;                // (the linearisation weighs the blocks' sums with it)
     }
-    EDS_WSYNC();
-    if (lane == 0) {                    // what does this evaluation mean?  (Solver12::on_eval)
-        double c = 0.0;
-        for (int k = 0; k < nb; ++k) c += 0.5 * W.r0[k];
-        W.cost = c;
-        W.accepted = 0;
-        int mode;
-        if (sv.final_pass) {
-            sv.final_cost = c; sv.done = 1; mode = M_RETURN;
-        } else if (!sv.started) {       // IterationZero
-            sv.started = 1;
-            sv.x_norm = Solver12::norm13(sv.p, sv.q, sv.v);
-            mode = M_LIN_ITER0;
+    const int final_pass = sv.final_pass, started = sv.started;
+    double xa[13], xc[13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { xa[i] = sv.p[i]; xc[i] = sv.cp[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xa[3 + i] = sv.q[i]; xc[3 + i] = sv.cq[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { xa[7 + i] = sv.v[i]; xc[7 + i] = sv.cv[i]; }
+    const double x_cost = sv.x_cost, x_norm0 = sv.x_norm, mcc = sv.model_cost_change, ptol = sv.ptol, ftol = sv.ftol;
+    const double radius = sv.radius, df = sv.decrease_factor;
+    double c = 0.0;
+    {
+        const long long rb = __double_as_longlong(r0);
+        const int nbu = uniform_int(nb);
+        for (int k = 0; k < nbu; ++k) {
+            const int lo = __builtin_amdgcn_readlane((int)(rb & 0xffffffffll), k), hi = __builtin_amdgcn_readlane((int)(rb >> 32), k);
+            c += 0.5 * __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        }
+    }
+    int mode;
+    double rel = 0.0;
+    if (final_pass) {
+        mode = M_RETURN;
+        if (lane == 0) { sv.final_cost = c; sv.done = 1; }
+    } else if (!started) {              // IterationZero
+        mode = M_LIN_ITER0;
+        const double xn = Solver12::norm13(xa, xa + 3, xa + 7);
+        if (lane == 0) { sv.started = 1; sv.x_norm = xn; }
+    } else {
+        const double cand_cost = ((c == c) && fabs(c) < 1e300) ? c : 1.7976931348623157e308;
+        double sn = 0.0;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) sn += (xa[i] - xc[i]) * (xa[i] - xc[i]);
+        const double cost_change = x_cost - cand_cost;
+        if (sqrt(sn) <= ptol * (x_norm0 + ptol)) {                      // ParameterToleranceReached
+            mode = M_RETURN;
+            if (lane == 0) sv.finish(TERM_CONVERGENCE);
+        } else if (fabs(cost_change) <= ftol * x_cost) {                // FunctionToleranceReached
+            mode = M_RETURN;
+            if (lane == 0) sv.finish(TERM_CONVERGENCE);
         } else {
-            const double cand_cost = ((c == c) && fabs(c) < 1e300) ? c : 1.7976931348623157e308;
-            double sn = 0.0;
-            for (int i = 0; i < 3; ++i) sn += (sv.p[i] - sv.cp[i]) * (sv.p[i] - sv.cp[i]);
-            for (int i = 0; i < 4; ++i) sn += (sv.q[i] - sv.cq[i]) * (sv.q[i] - sv.cq[i]);
-            for (int i = 0; i < 6; ++i) sn += (sv.v[i] - sv.cv[i]) * (sv.v[i] - sv.cv[i]);
-            const double cost_change = sv.x_cost - cand_cost;
-            if (sqrt(sn) <= sv.ptol * (sv.x_norm + sv.ptol)) {          // ParameterToleranceReached
-                sv.finish(TERM_CONVERGENCE); mode = M_RETURN;
-            } else if (fabs(cost_change) <= sv.ftol * sv.x_cost) {      // FunctionToleranceReached
-                sv.finish(TERM_CONVERGENCE); mode = M_RETURN;
-            } else {
-                const double rel = cost_change / sv.model_cost_change;
-                if (rel > 1e-3) {                                       // HandleSuccessfulStep, first half
-                    sv.x_norm = Solver12::norm13(sv.cp, sv.cq, sv.cv);  // (x <- candidate: the 13 copies are done by 13 lanes below)
-                    W.rel = rel;
-                    mode = M_LIN_ACCEPT;
-                } else {                                                // HandleUnsuccessfulStep
-                    sv.radius /= sv.decrease_factor; sv.decrease_factor *= 2.0; sv.reuse_diagonal = 1;
-                    mode = M_ADVANCE;
-                }
+            rel = cost_change / mcc;
+            if (rel > 1e-3) {                                           // HandleSuccessfulStep, first half
+                mode = M_LIN_ACCEPT;                                    // (x <- candidate: the 13 copies are done by 13 lanes below)
+                const double xn = Solver12::norm13(xc, xc + 3, xc + 7);
+                if (lane == 0) sv.x_norm = xn;
+            } else {                                                    // HandleUnsuccessfulStep
+                mode = M_ADVANCE;
+                if (lane == 0) { sv.radius = radius / df; sv.decrease_factor = df * 2.0; sv.reuse_diagonal = 1; }
             }
         }
-        W.mode = mode;
     }
+    mode = uniform_int(mode);
+    if (lane == 0) { W.cost = c; W.rel = rel; W.accepted = 0; }
     EDS_WSYNC();
     EDS_CSTAMP(0);
-    const int mode = uniform_int(W.mode);
     if (mode == M_RETURN || mode == M_ADVANCE) return mode;
     if (mode == M_LIN_ACCEPT) {          // x <- candidate point (HandleSuccessfulStep), one double per lane
         if (lane < 3) sv.p[lane] = sv.cp[lane];
@@ -323,54 +341,74 @@ __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand1
     EDS_WSYNC();
 }
 
-// Solver12::advance on prepared steps: lane 0 of wavefront 0.  `k` = index of the prepared step that belongs to the radius the
-// solver is at (EDS_NCAND or more: none prepared), `head_done`: the per-iteration bookkeeping of advance() has already run for the
-// step about to be taken (the walk was interrupted to have steps prepared).  Returns W_RETURN (solve ended), W_EVAL (sv.cp/cq/cv
-// hold the point to evaluate; *k is the prepared step taken) or W_NEED (steps for the current radius are missing).
-__device__ inline int coop12_walk(edss::Solver12& sv, const Cand12* cand, int* k, int* head_done) {
+// Solver12::advance on prepared steps.  Wavefront 0, ALL lanes (round 3: every lane walks, on state read from LDS in one batch of
+// broadcast loads, and lane 0 stores what changed — on lane 0 alone each test waited for its own LDS round trip).  `k` = index of the
+// prepared step that belongs to the radius the solver is at (EDS_NCAND or more: none prepared), `head_done`: the per-iteration
+// bookkeeping of advance() has already run for the step about to be taken (the walk was interrupted to have steps prepared).
+// Returns {W_RETURN (solve ended) | W_EVAL (take prepared step k: coop12_take) | W_NEED (steps for the current radius are missing), k,
+// head_done}, the same on every lane.
+struct Walk12 { int walk, k, head; };
+__device__ inline Walk12 coop12_walk(edss::Solver12& sv, const Cand12* cand, int k, int head_done, const int lane) {
     using namespace edss;
+    int step_successful = sv.step_successful, num_s = sv.num_successful, num_u = sv.num_unsuccessful;
+    int iteration = sv.iteration, cinv = sv.consecutive_invalid;
+    const int max_iters = sv.max_iters;
+    const double x_cost = sv.x_cost, gmn = sv.grad_max_norm, gtol = sv.gtol;
+    double minimum_cost = sv.minimum_cost, radius = sv.radius, df = sv.decrease_factor;
+    int valid[EDS_NCAND];
+#pragma unroll
+    for (int i = 0; i < EDS_NCAND; ++i) valid[i] = cand[i].valid;
+    bool copy_best = false, touched_radius = false, reuse = false;
+    int term = -1, res;
     for (;;) {
-        if (!*head_done) {
-            if (sv.step_successful) {
-                ++sv.num_successful;
-                if (sv.x_cost < sv.minimum_cost || sv.iteration == 0) {
-                    sv.minimum_cost = sv.x_cost;
-                    double bp[3], bq[4], bv[6];         // all loads in flight before the first store waits for one
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) bp[i] = sv.p[i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) bq[i] = sv.q[i];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) bv[i] = sv.v[i];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) sv.best_p[i] = bp[i];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) sv.best_q[i] = bq[i];
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) sv.best_v[i] = bv[i];
-                }
+        if (!head_done) {
+            if (step_successful) {
+                ++num_s;
+                if (x_cost < minimum_cost || iteration == 0) { minimum_cost = x_cost; copy_best = true; }
             } else {
-                ++sv.num_unsuccessful;
+                ++num_u;
             }
-            if (sv.iteration >= sv.max_iters) { sv.finish(TERM_NO_CONVERGENCE); return W_RETURN; }
-            if (sv.step_successful && sv.grad_max_norm <= sv.gtol) { sv.finish(TERM_CONVERGENCE); return W_RETURN; }
-            if (sv.radius < 1e-32) { sv.finish(TERM_CONVERGENCE); return W_RETURN; }
-            ++sv.iteration; sv.step_successful = 0;
-            *head_done = 1;
+            if (iteration >= max_iters) { term = TERM_NO_CONVERGENCE; res = W_RETURN; break; }
+            if (step_successful && gmn <= gtol) { term = TERM_CONVERGENCE; res = W_RETURN; break; }
+            if (radius < 1e-32) { term = TERM_CONVERGENCE; res = W_RETURN; break; }
+            ++iteration; step_successful = 0;
+            head_done = 1;
         }
-        if (*k >= EDS_NCAND) return W_NEED;
-        const Cand12& c = cand[*k];
-        sv.reuse_diagonal = 1;
-        if (!c.valid) {                 // HandleInvalidStep
-            if (++sv.consecutive_invalid >= 5) { sv.finish(TERM_FAILURE); return W_RETURN; }
-            sv.radius /= sv.decrease_factor; sv.decrease_factor *= 2.0;
-            ++*k; *head_done = 0;
+        if (k >= EDS_NCAND) { res = W_NEED; break; }
+        reuse = true;
+        int vk = valid[0];
+#pragma unroll
+        for (int i = 1; i < EDS_NCAND; ++i) vk = (k == i) ? valid[i] : vk;
+        if (!vk) {                      // HandleInvalidStep
+            if (++cinv >= 5) { term = TERM_FAILURE; res = W_RETURN; break; }
+            radius /= df; df *= 2.0; touched_radius = true;
+            ++k; head_done = 0;
             continue;                   // counts as an unsuccessful iteration
         }
-        sv.consecutive_invalid = 0;
-        *head_done = 0;
-        return W_EVAL;                  // the step itself is taken by coop12_take (26 doubles: one per lane instead of one after the other)
+        cinv = 0;
+        head_done = 0;
+        res = W_EVAL;                   // the step itself is taken by coop12_take (26 doubles: one per lane instead of one after the other)
+        break;
     }
+    copy_best = __builtin_amdgcn_readfirstlane(copy_best ? 1 : 0) != 0;
+    if (copy_best) {                    // the accepted point is the best one so far: 13 doubles, one per lane
+        if (lane < 3) sv.best_p[lane] = sv.p[lane];
+        else if (lane < 7) sv.best_q[lane - 3] = sv.q[lane - 3];
+        else if (lane < 13) sv.best_v[lane - 7] = sv.v[lane - 7];
+    }
+    if (lane == 0) {
+        sv.step_successful = step_successful; sv.num_successful = num_s; sv.num_unsuccessful = num_u;
+        sv.iteration = iteration; sv.consecutive_invalid = cinv; sv.minimum_cost = minimum_cost;
+        if (reuse) sv.reuse_diagonal = 1;
+        if (touched_radius) { sv.radius = radius; sv.decrease_factor = df; }
+    }
+    term = uniform_int(term);
+    if (term >= 0) {                    // (finish() reads the best point: after the copy above)
+        EDS_WSYNC();
+        if (lane == 0) sv.finish(term);
+    }
+    EDS_WSYNC();
+    return Walk12{uniform_int(res), uniform_int(k), uniform_int(head_done)};
 }
 
 // Second half of the W_EVAL case of coop12_walk: the prepared step `c` becomes the solver's step and candidate point.  Wavefront 0, all
