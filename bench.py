@@ -197,9 +197,13 @@ def latency_block(capi, synth, al, a):
     h.set_alignment(0, al)
     out["B1_lm6_ms"] = med(lambda: h.optimize(0, p=al.p0, q=al.q0, v=al.v0))
     out["B1_lm6_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
+    # the same calls looped INSIDE the library (eds_trk_bench_live): what a C++ caller pays — the figures above include the Python
+    # binding's own work around every call (argument conversion, ~10 us)
+    out["B1_lm6_c_ms"] = h.bench_live(0, al.p0, al.q0, al.v0, reps=100)["optimize_us"] * 1e-3
     h.set_config(capi.default_config(sampling=samp, solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, num_blocks=1))
     out["B1_ref12_ms"] = med(lambda: h.optimize(0, p=al.p0, q=al.q0, v=al.v0))
     out["B1_ref12_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
+    out["B1_ref12_c_ms"] = h.bench_live(0, al.p0, al.q0, al.v0, reps=100)["optimize_us"] * 1e-3
     # one live slice
     h.set_config(capi.default_config(sampling=samp, solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, num_blocks=4,
                                      loss_type=capi.LOSS_HUBER, loss_param=0.3))
@@ -228,6 +232,10 @@ def latency_block(capi, synth, al, a):
         h.residuals_and_loss(0, capi.LP_MAD)
     out["live_call_ref12_ms"] = med(live_call)
     out["live_call_ref12_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
+    lc = h.bench_live(0, al.p0, al.q0, al.v0, idp=idp64, frame=frame64, method=capi.LP_MAD, reps=200)
+    out["live_call_ref12_c_ms"] = lc["total_us"] * 1e-3
+    out["live_call_ref12_c_kernel_ms"] = lc["kernel_us"] * 1e-3
+    out["live_call_ref12_c_steps_us"] = {k[:-3]: round(v, 1) for k, v in lc.items() if k not in ("total_us", "kernel_us")}
     h.close()
 
     # configs[3]: one coarse-to-fine call, 4 levels of one scene, 2 000 -> 16 000 points, the pose carried on
@@ -278,7 +286,8 @@ def latency_block(capi, synth, al, a):
     h.close()
     out["note"] = ("wall time per call through the C ABI, inputs resident; B1: one 640x480-class alignment, B64: one launch of 64 (configs[4] on "
                    "one GPU); slice: 100 k events -> frame -> REF12 (4 blocks, Huber) -> MAD -> getCoord; live_call: the shim's sequence with a host fp64 "
-                   "frame; config3: one 4-level coarse-to-fine call (2 000 .. 16 000 points); B64_step: events -> 64 frames -> 64 solves -> MAD -> getCoord criterion, batched calls")
+                   "frame; config3: one 4-level coarse-to-fine call (2 000 .. 16 000 points); B64_step: events -> 64 frames -> 64 solves -> MAD -> getCoord criterion, batched calls; "
+                   "*_c_ms: the same calls looped inside ONE C call (eds_trk_bench_live, std::chrono around each): the C ABI's own cost, without the Python binding's ~10 us per call")
     return out
 
 

@@ -372,6 +372,14 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the 
  * [first, first+count) `reps` times back-to-back at the stored states and reports the mean
  * duration per launch in ms, measured with HIP events on the handle's stream. */
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
+/* Latency of the live sequence measured INSIDE the library's language (no interpreter between the calls): `reps` times
+ *   [eds_trk_set_idepth(idp)] -> [eds_trk_set_event_frame(frame)] -> eds_trk_optimize(level, p0, q0, v0) -> [eds_trk_residuals_and_loss(method)]
+ * on `slot` (Tracker.cpp:167 -> EventFrame -> :104-241 -> :223-233), each from the same start state; the bracketed calls are skipped when
+ * their pointer is NULL (`method` < 0 skips the last).  out_us[6] = medians over the repetitions of { whole sequence, set_idepth,
+ * set_event_frame, optimize, residuals_and_loss, device time of the solve }, all in microseconds (std::chrono::steady_clock around
+ * each call).  The state of the slot after the call is that of the last repetition. */
+int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const double* frame, const double p0[3], const double q0[4],
+                       const double v0[6], int method, int reps, double out_us[6]);
 /* What the last on-device solve (eds_trk_optimize / _optimize_batch with exec = device) actually launched — so that a benchmark
  * prices the kernel that ran instead of mirroring the library's selection rule. */
 /* The persistent kernels (and the streaming residual/Jacobian kernel on batches) gather from STRIP COPIES of the event frames

@@ -40,7 +40,7 @@ EXPORTS = (
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param", "eds_trk_residuals_and_loss",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
-    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_last_launch", "eds_trk_prepare_frames",
+    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_last_launch", "eds_trk_prepare_frames",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
     "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
@@ -193,6 +193,7 @@ def lib():
         L.eds_trk_timer_start.argtypes = [C.c_void_p]
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.eds_trk_bench_live.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
         L.eds_pyr_create.argtypes = [C.POINTER(Cfg), C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.eds_pyr_destroy.argtypes = [C.c_void_p]
         L.eds_pyr_destroy.restype = None
@@ -583,6 +584,16 @@ class Handle:
         d = {k: getattr(li, k) for k, _ in li._fields_}
         d["kernel"] = li.kernel.decode()
         return d
+
+    def bench_live(self, slot, p0, q0, v0, level=0, idp=None, frame=None, method=-1, reps=50) -> dict:
+        """``eds_trk_bench_live``: the live sequence timed inside the library (medians, microseconds)."""
+        p0, q0, v0 = _f64(p0), _f64(q0), _f64(v0)
+        idp = None if idp is None else _f64(idp)
+        frame = None if frame is None else _f64(frame)
+        out = np.zeros(6)
+        _check(lib().eds_trk_bench_live(self._h, int(slot), int(level), None if idp is None else _p(idp), None if frame is None else _p(frame),
+                                        _p(p0), _p(q0), _p(v0), int(method), int(reps), _p(out)))
+        return dict(zip(("total_us", "set_idepth_us", "set_event_frame_us", "optimize_us", "residuals_and_loss_us", "kernel_us"), out.tolist()))
 
     def bench_eval(self, first, count, ncols=6, with_reduction=False, reps=20) -> float:
         ms = C.c_float(0.0)

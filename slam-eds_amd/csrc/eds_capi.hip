@@ -345,7 +345,7 @@ void free_all(eds_trk* h) {
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
     eds_keyframe_free(&h->kf_build);
-    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap, h->h_idp};
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap, h->h_idp, h->h_fprog};
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -413,6 +413,24 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
     { int rc_ = unshare_frames(h, slot, 1); if (rc_) return rc_; }     // a frame of its own again
     float* stage = h->h_fstage;
     if (h->stage_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_stage)); h->stage_busy = false; }   // the previous frame's reads (long done)
+    static const bool banded = [] { const char* ev = getenv("EDS_UPLOAD"); return ev && std::strcmp(ev, "bands") == 0; }();     // A/B knob: one launch per band (round 2)
+    if (h->d_fprog && !banded && h->H < (1 << 20)) {
+        // ONE launch (round 3): k_store_follow's workgroups wait for the rows they move; the host publishes its progress after every
+        // band in a pinned word (release store behind the band's plain stores: x86 keeps them in order for the device's reads).
+        // 16 bands: what is left after the host's last store is 1/16 of a frame over PCIe.  (4 launches cost the host 16 of its 44 us.)
+        if (h->h_fprog[1] & 0x80000000u) { h->h_fprog[1] = 0; return fail(EDS_ERR_HIP, "the previous frame upload timed out waiting for the host"); }
+        // bands of 32 k rows (a band boundary is then a multiple of 128 bytes into the staging buffer whatever W is), at most 16 of them
+        const int rows_per = 32 * std::max(1, (h->H + 32 * 16 - 1) / (32 * 16)), nbands = (h->H + rows_per - 1) / rows_per;
+        const unsigned seq = (++h->upload_seq) & 0xfffu;
+        __atomic_store_n(&h->h_fprog[0], seq << 20, __ATOMIC_RELEASE);
+        eds_frame_store_follow(h, slot, seq, rows_per);
+        for (int k = 0; k < nbands; ++k) {
+            const int rb = rows_per * k, re = std::min(h->H, rows_per * (k + 1));
+            const size_t b = (size_t)rb * h->W, e = (size_t)re * h->W;
+            narrow_band(frame + b, stage + b, e - b);
+            __atomic_store_n(&h->h_fprog[0], (seq << 20) | (unsigned)re, __ATOMIC_RELEASE);
+        }
+    } else
     for (int k = 0; k < EDS_UPLOAD_BANDS; ++k) {
         const int rb = h->H * k / EDS_UPLOAD_BANDS, re = h->H * (k + 1) / EDS_UPLOAD_BANDS;
         const size_t b = (size_t)rb * h->W, e = (size_t)re * h->W;
@@ -542,6 +560,12 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
         hipError_t e_ = hipHostMalloc((void**)&h->h_fstage, (size_t)H * W * 4, hipHostMallocMapped);
         if (e_ == hipSuccess) e_ = hipHostGetDevicePointer((void**)&h->d_fstage, h->h_fstage, 0);
         if (e_ != hipSuccess) { free_all(h); return fail(EDS_ERR_HIP, std::string("hipHostMalloc (frame staging): ") + hipGetErrorString(e_)); }
+    }
+    {   // progress / time-out words of the follower upload (eds_frame_store_follow); without them set_event_frame launches per band
+        hipError_t e_ = hipHostMalloc((void**)&h->h_fprog, 64, hipHostMallocMapped);
+        if (e_ == hipSuccess) e_ = hipHostGetDevicePointer((void**)&h->d_fprog, h->h_fprog, 0);
+        if (e_ != hipSuccess) { (void)hipGetLastError(); if (h->h_fprog) hipHostFree(h->h_fprog); h->h_fprog = nullptr; h->d_fprog = nullptr; }
+        else std::memset(h->h_fprog, 0, 64);
     }
     std::memset(h->h_pose, 0, (size_t)batch * EDS_POSE_STRIDE * 8);
     std::memset(h->h_G, 0, (size_t)batch * EDS_MAX_BLOCKS * 36 * 8);
@@ -1004,6 +1028,11 @@ int eds_trk_sync(eds_trk* h) {
     if (!h) return fail(EDS_ERR_INVALID, "null handle");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     EDS_HIP_TRY(wait_stream(h));
+    if (h->h_fprog && (h->h_fprog[1] & 0x80000000u)) {      // a frame upload gave up waiting for the host: that slot's frame is incomplete
+        h->h_fprog[1] = 0;
+        if (h->cfg.exec == EDS_EXEC_DEVICE) (void)eds_fused_collect(h);
+        return fail(EDS_ERR_HIP, "a frame upload timed out waiting for the host (set the event frame again)");
+    }
     if (h->cfg.exec == EDS_EXEC_DEVICE) return eds_fused_collect(h);
     return EDS_OK;
 }
@@ -1131,6 +1160,39 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms) {
     EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
     EDS_HIP_TRY(hipEventSynchronize(h->ev1));
     EDS_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return EDS_OK;
+}
+
+int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const double* frame, const double p0[3], const double q0[4],
+                       const double v0[6], int method, int reps, double out_us[6]) {
+    int rc = check_slot(h, slot);
+    if (rc) return rc;
+    if (!p0 || !q0 || !v0 || !out_us || reps < 1) return fail(EDS_ERR_INVALID, "null state / output or reps < 1");
+    const int N = h->slots[slot].N;
+    std::vector<double> t[6], res((size_t)(N > 0 ? N : 1));
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    for (int r = 0; r < reps; ++r) {
+        double p[3], q[4], v[6], tau = 0.0;
+        std::memcpy(p, p0, sizeof(p)); std::memcpy(q, q0, sizeof(q)); std::memcpy(v, v0, sizeof(v));
+        eds_trk_info info;
+        const clk::time_point a = clk::now();
+        if (idp && (rc = eds_trk_set_idepth(h, slot, N, idp))) return rc;
+        const clk::time_point b = clk::now();
+        if (frame && (rc = eds_trk_set_event_frame(h, slot, frame))) return rc;
+        const clk::time_point c = clk::now();
+        rc = eds_trk_optimize(h, slot, level, p, q, v, &info);
+        if (rc != EDS_OK && rc != EDS_ERR_NOT_USABLE) return rc;
+        const clk::time_point d = clk::now();
+        if (method >= 0 && rc == EDS_OK && (rc = eds_trk_residuals_and_loss(h, slot, method, res.data(), &tau))) return rc;
+        const clk::time_point e = clk::now();
+        t[0].push_back(us(a, e)); t[1].push_back(us(a, b)); t[2].push_back(us(b, c)); t[3].push_back(us(c, d)); t[4].push_back(us(d, e));
+        t[5].push_back(info.device_time_us);
+    }
+    for (int k = 0; k < 6; ++k) {
+        std::nth_element(t[k].begin(), t[k].begin() + t[k].size() / 2, t[k].end());
+        out_us[k] = t[k][t[k].size() / 2];
+    }
     return EDS_OK;
 }
 

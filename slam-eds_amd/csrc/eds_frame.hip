@@ -11,6 +11,7 @@
 //   5. divide by the Frobenius norm (EventFrame.cpp:359-383) and store as fp32 in the handle's frame layout
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -240,6 +241,68 @@ __global__ void k_store_rowmajor(const float* __restrict__ src, float* __restric
     dst[eds_frame_index(r, c, Wp, tiled)] = src[(size_t)min(max(r, 0), H - 1) * W + min(max(c, 0), W - 1)];
 }
 
+// The same for a frame the host is STILL NARROWING (round 3): one launch per frame instead of one per band.  Workgroup (band, part)
+// waits until the host has published "rows [0, n) of upload `seq` are in the staging buffer" in a pinned word, then moves its part
+// of the band.  A workgroup waits for the host only, never for another workgroup: no residency assumption.  The wait is
+// bounded (EDS_FOLLOW_TIMEOUT_TICKS of the 100 MHz clock: a host that stops mid-frame for seconds); a workgroup that gives up
+// marks prog[1] and the next wait on the handle reports it.
+#define EDS_FOLLOW_PARTS 4
+#define EDS_FOLLOW_THREADS 1024
+#define EDS_FOLLOW_TIMEOUT_TICKS 200000000ull
+__global__ __launch_bounds__(EDS_FOLLOW_THREADS) void k_store_follow(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Hp, int Wp,
+                                                                  int tiled, unsigned* prog, unsigned seq, int rows_per, int nbands) {
+    const int band = blockIdx.x / EDS_FOLLOW_PARTS, part = blockIdx.x - band * EDS_FOLLOW_PARTS;
+    const int rb = rows_per * band, re = min(H, rows_per * (band + 1));
+    const int lo = band == 0 ? -EDS_FRAME_MARGIN : rb, hi = band == nbands - 1 ? Hp - EDS_FRAME_MARGIN : re;
+    __shared__ int s_ok;
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        for (;;) {
+            const unsigned v = __hip_atomic_load(prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((v >> 20) == seq && (int)(v & 0xfffffu) >= re) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > EDS_FOLLOW_TIMEOUT_TICKS) {
+                ok = 0;
+                __hip_atomic_store(prog + 1, 0x80000000u | seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            // (every poll is a PCIe read of the host's cache line: workgroups whose band is far away ask rarely)
+            if ((v >> 20) == seq && (int)(v & 0xfffffu) + rows_per < rb) __builtin_amdgcn_s_sleep(100); else __builtin_amdgcn_s_sleep(6);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // four consecutive columns per lane: one 16-byte read of the staging buffer (plain: the lines of this band are first touched here,
+    // after the host has written them — the caller cuts the bands at multiples of 32 rows, so no 128-byte line of the staging buffer
+    // belongs to two bands) and one 16-byte write of a tile row
+    const int Q = Wp >> 2, n = (hi - lo) * Q;
+    const bool vec = (W & 3) == 0;
+    constexpr int U = 4, STEP = EDS_FOLLOW_PARTS * EDS_FOLLOW_THREADS;
+    for (int e0 = part * EDS_FOLLOW_THREADS + (int)threadIdx.x; e0 < n; e0 += U * STEP) {
+        float4 v[U];
+        int rr_[U], c_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                        // U reads over PCIe in flight per lane
+            const int e = e0 + u * STEP;
+            rr_[u] = INT_MIN;
+            if (e < n) {
+                const int rq = e / Q, r = lo + rq, c = 4 * (e - rq * Q) - EDS_FRAME_MARGIN;
+                rr_[u] = r; c_[u] = c;
+                const float* row = src + (size_t)min(max(r, 0), H - 1) * W;
+                if (vec && c >= 0 && c + 3 < W) v[u] = *reinterpret_cast<const float4*>(row + c);
+                else v[u] = make_float4(row[min(max(c, 0), W - 1)], row[min(max(c + 1, 0), W - 1)], row[min(max(c + 2, 0), W - 1)], row[min(max(c + 3, 0), W - 1)]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rr_[u] == INT_MIN) continue;
+            float* d = dst + eds_frame_index(rr_[u], c_[u], Wp, tiled);      // c is a multiple of 4: the four pixels are contiguous in either layout
+            *reinterpret_cast<float4*>(d) = v[u];
+        }
+    }
+}
+
 __global__ void k_mirror_rows(const float* __restrict__ src, float* __restrict__ dst, int n) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
     float4* d4 = reinterpret_cast<float4*>(dst);
@@ -261,6 +324,13 @@ void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_
     if (hi <= lo) return;
     hipLaunchKernelGGL(k_store_rowmajor, dim3((h->Wp + 255) / 256, hi - lo), dim3(256), 0, h->st, d_src,
                        h->dframe + (size_t)slot * h->Hp * h->Wp, h->H, h->W, h->Hp, h->Wp, h->tiled, lo);
+}
+
+// One launch that follows the host through the staging buffer (k_store_follow); the caller publishes its progress in h->h_fprog[0].
+void eds_frame_store_follow(eds_trk* h, int slot, unsigned seq, int rows_per) {
+    const int nbands = (h->H + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(k_store_follow, dim3(nbands * EDS_FOLLOW_PARTS), dim3(EDS_FOLLOW_THREADS), 0, h->st, h->d_fstage,
+                       h->dframe + (size_t)slot * h->Hp * h->Wp, h->H, h->W, h->Hp, h->Wp, h->tiled, h->d_fprog, seq, rows_per, nbands);
 }
 
 void eds_frame_free(EdsFrameBuffers* fb) {

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 if constexpr (SAMPLING == 0) {
                     hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
                     hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
-                } else {            // bilinear: the row's two middle pixels, value and column difference (oracle/eds_oracle.hpp bilinear())
+                } else {            // bilinear: the row's two middle pixels, value and column difference
                     d01 = ta[2] - ta[1]; f01 = ta[1] + x01 * d01;
                     d23 = tb[2] - tb[1]; f23 = tb[1] + x23 * d23;
                 }
@@ -758,6 +758,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
         for (int j = 0; j < NREG; ++j) {
             const int i = tid + j * nthr;
             if (i < N) A.r[base + i] = racc[j];
+            if (TEAM > 1 && A.rmap && i < N) A.rmap[base + i] = racc[j];      // the caller reads them next (Tracker.cpp:223-233)
         }
     }
 #ifdef EDS_FUSED_STAMPS
@@ -986,6 +987,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         if (v == 1 || feasible) team = v;
     }
     if (team > 1) { stream = false; wide = false; }
+    // team launches (the latency regime) write the kept residuals into the pinned mirror themselves: one launch less behind the solve
+    const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
+    A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     fb.pending_team = team; fb.pending_level = level;
     fb.pending_ticks = count <= 64 && !stream;       // the latency regime: time stamps from inside the kernel instead of event packets
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
@@ -1067,7 +1071,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH_TEAM
 #undef EDS_LAUNCH_BILINEAR
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
-    fb.pending_host_r = eds_mirror_residuals(h, first, count);
+    fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

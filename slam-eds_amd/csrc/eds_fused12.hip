@@ -497,6 +497,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }
 #endif
+    if (TEAM > 1 && A.rmap) {                   // the kept residuals into the pinned mirror (each thread: the entries it wrote itself)
+        for (int i = lo + tid; i < hi; i += nthr) A.rmap[base + i] = A.r[base + i];
+    }
     if (TEAM > 1 && member != 0) return;        // every member holds the same result; member 0 reports it
     if (tid == 0) {
         EdsFused12Out& O = out[slot];
@@ -573,6 +576,8 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         }
     }
     fb.pending_team = team; fb.pending_level = level;
+    const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;       // (see eds_fused_solve)
+    A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     const unsigned ticket_base = fb.ticket_base;
     if (team > 1) {
         fb.ticket_base += (unsigned)(count * team);
@@ -609,7 +614,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_LAUNCH12
 #undef EDS_LAUNCH12_
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
-    fb.pending_host_r = eds_mirror_residuals(h, first, count);
+    fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

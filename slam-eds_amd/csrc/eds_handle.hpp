@@ -55,6 +55,9 @@ struct eds_trk {
     float *h_f32 = nullptr, *h_r = nullptr;
     float *h_fstage = nullptr, *d_fstage = nullptr;   // pinned, device-mapped H x W fp32: set_event_frame narrows into it; nobody else writes it
     hipEvent_t ev_stage = nullptr;      // recorded behind the last copy out of h_fstage
+    unsigned *h_fprog = nullptr, *d_fprog = nullptr;  // pinned, device-mapped: [0] (upload number << 20 | rows of h_fstage narrowed so far), [1] time-out
+                                                      // mark of the follower kernel (eds_frame_store_follow)
+    unsigned upload_seq = 0;
     float *h_rmap = nullptr, *d_rmap = nullptr;       // pinned, device-mapped [min(B, EDS_RHOST_SLOTS)][Np]: residuals of small launches (eds_mirror_residuals)
     float* h_idp = nullptr;             // pinned [Np]: set_idepth narrows into it (private, like h_fstage)
     float* d_idp = nullptr;             // ... as the device sees it (the gram kernel reads the new depths in place)
@@ -71,7 +74,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.strips = nullptr /* set by the launch sites that made sure the copies are current */; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.rmap = nullptr; A.strips = nullptr /* set by the launch sites that made sure the copies are current */; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

@@ -22,6 +22,8 @@ struct EdsArrays {
     double* G;           // [B][EDS_MAX_BLOCKS][36]
     // per-pass outputs
     float* r;            // [B][Np]
+    float* rmap;         // pinned host mirror of the first EDS_RHOST_SLOTS rows of `r` (device view) or null: team launches store the kept
+                         // residuals there themselves (no mirror launch behind a lone solve)
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
     double* ncstat;      // [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC block statistics (eds_layout.hpp)

@@ -112,8 +112,16 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
             c += 0.5 * __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
         }
     }
+    // the three 13-term sums with a square root behind them (distance moved, norm of the candidate / of the start point) are
+    // independent chains: formed side by side here, whichever the decision then needs
+    double sn = 0.0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) sn += (xa[i] - xc[i]) * (xa[i] - xc[i]);
+    const double moved = sqrt(sn), xn_c = Solver12::norm13(xc, xc + 3, xc + 7);
+    const double cand_cost = ((c == c) && fabs(c) < 1e300) ? c : 1.7976931348623157e308;
+    const double cost_change = x_cost - cand_cost;
+    double rel = cost_change / mcc;     // (meaningful where it is used: after the start point has been linearised)
     int mode;
-    double rel = 0.0;
     if (final_pass) {
         mode = M_RETURN;
         if (lane == 0) { sv.final_cost = c; sv.done = 1; }
@@ -122,23 +130,16 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
         const double xn = Solver12::norm13(xa, xa + 3, xa + 7);
         if (lane == 0) { sv.started = 1; sv.x_norm = xn; }
     } else {
-        const double cand_cost = ((c == c) && fabs(c) < 1e300) ? c : 1.7976931348623157e308;
-        double sn = 0.0;
-#pragma unroll
-        for (int i = 0; i < 13; ++i) sn += (xa[i] - xc[i]) * (xa[i] - xc[i]);
-        const double cost_change = x_cost - cand_cost;
-        if (sqrt(sn) <= ptol * (x_norm0 + ptol)) {                      // ParameterToleranceReached
+        if (moved <= ptol * (x_norm0 + ptol)) {                      // ParameterToleranceReached
             mode = M_RETURN;
             if (lane == 0) sv.finish(TERM_CONVERGENCE);
         } else if (fabs(cost_change) <= ftol * x_cost) {                // FunctionToleranceReached
             mode = M_RETURN;
             if (lane == 0) sv.finish(TERM_CONVERGENCE);
         } else {
-            rel = cost_change / mcc;
             if (rel > 1e-3) {                                           // HandleSuccessfulStep, first half
                 mode = M_LIN_ACCEPT;                                    // (x <- candidate: the 13 copies are done by 13 lanes below)
-                const double xn = Solver12::norm13(xc, xc + 3, xc + 7);
-                if (lane == 0) sv.x_norm = xn;
+                if (lane == 0) sv.x_norm = xn_c;
             } else {                                                    // HandleUnsuccessfulStep
                 mode = M_ADVANCE;
                 if (lane == 0) { sv.radius = radius / df; sv.decrease_factor = df * 2.0; sv.reuse_diagonal = 1; }

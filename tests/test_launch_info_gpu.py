@@ -73,3 +73,42 @@ def test_strip_copies_follow_the_frames(gpu, capi, synth):
         os.environ.pop("EDS_FUSED_LAYOUT", None)
     assert np.abs(tiles[:, :7] - second[:, :7]).max() < 1e-6 and np.array_equal(tiles[:, 14], second[:, 14])
     h.close(); fresh.close()
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (45, 70), (33, 129), (720, 1280), (64, 64), (600, 37)])
+def test_host_frame_upload_in_one_launch(gpu, capi, shape):
+    """set_event_frame with a host frame (fp64 and fp32): ONE launch follows the host through the staging buffer (bands of 32 k rows,
+    progress published in a pinned word).  What arrives must be the fp32-rounded frame, on sizes whose width is not a multiple of 4,
+    whose height is not a multiple of the band, and on several frames in a row through the same staging buffer (the next frame must
+    never show rows of the previous one); the margin replicates the border (sampled through the bilinear clamp in other tests)."""
+    H, W = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    h = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE), 2, 64, H, W)
+    for rep in range(4):
+        f64 = rng.standard_normal((H, W)) * (10.0 ** rng.integers(-3, 2))
+        h.set_event_frame(rep & 1, f64)
+        got = h.get_event_frame(rep & 1)
+        assert np.array_equal(got, f64.astype(np.float32).astype(np.float64)), (shape, rep)
+        f32 = rng.standard_normal((H, W)).astype(np.float32)
+        h.set_event_frame(rep & 1, f32)
+        assert np.array_equal(h.get_event_frame(rep & 1), f32.astype(np.float64)), (shape, rep)
+    h.close()
+
+
+def test_live_sequence_timed_inside_the_library(gpu, capi, synth, po):
+    """eds_trk_bench_live: the live sequence looped inside one C call must leave the slot where a plain sequence of the same calls
+    leaves it, and report plausible medians."""
+    al = synth.make_alignment(5003, H=240, W=320, N=1500)
+    cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=8, num_blocks=2)
+    h = capi.Handle(cfg, 1, al.N, al.H, al.W)
+    h.set_alignment(0, al)
+    p, q, v, info = h.optimize(0, p=al.p0, q=al.q0, v=al.v0)
+    r0, tau0 = h.residuals_and_loss(0, capi.LP_MAD)
+    t = h.bench_live(0, al.p0, al.q0, al.v0, idp=al.idp, frame=al.frame, method=capi.LP_MAD, reps=5)
+    tab = h.results(0, 1)[0]
+    assert np.array_equal(tab[0:3], p) and np.array_equal(tab[3:7], q) and np.array_equal(tab[7:13], v)
+    assert 0 < t["kernel_us"] < t["optimize_us"] < t["total_us"] < 1e5
+    assert abs(t["total_us"] - (t["set_idepth_us"] + t["set_event_frame_us"] + t["optimize_us"] + t["residuals_and_loss_us"])) < 0.5 * t["total_us"]
+    with pytest.raises(capi.EdsError):
+        h.bench_live(3, al.p0, al.q0, al.v0)
+    h.close()
