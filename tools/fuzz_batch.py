@@ -39,7 +39,16 @@ def is_sensitive(a, kw, ts, d):
         return True                                  # the fp64 oracle cannot solve it either (singular normal equations)
     if ts[15] != 1.0 or it != ts[14]:
         return True
-    return po.se3_distance(ts[0:3], ts[3:7], p, q) >= 0.3 * d
+    if po.se3_distance(ts[0:3], ts[3:7], p, q) >= 0.3 * d:
+        return True
+    # how much the fp64 solution itself moves when the start moves by an fp32 rounding error: an undamped Gauss-Newton with steps of
+    # 0.1 amplifies 1e-7 to 1e-4 in six iterations (both fp32 kernels then sit within that of the oracle, and of each other)
+    try:
+        a2 = synth.Alignment(**{**a.__dict__, "p0": a.p0 + 1e-7 * np.array([1.0, -1.0, 1.0])})
+        p2, q2, _ = oracle_solution(a2, kw)
+    except Exception:
+        return True
+    return 3.0 * po.se3_distance(p2, q2, p, q) >= d
 
 
 for t in range(trials):
