@@ -138,11 +138,16 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #ifdef EDS_FUSED_STAMPS
     unsigned long long st_acc[3] = {0, 0, 0}, st_t = __builtin_readcyclecounter();
     int st_n = 0;
-#define EDS12_STAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[k] += n_ - st_t; st_t = n_; } while (0)
+#define EDS12_STAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[k] += n_ - st_t; st_t = n_; pst_t = n_; } while (0)
+    unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pst_t = st_t;        // the point phase in five pieces (wavefront 0)
+#define EDS12_PSTAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); pst[k] += n_ - pst_t; pst_t = n_; } while (0)
 #else
 #define EDS12_STAMP(k) do { } while (0)
+#define EDS12_PSTAMP(k) do { } while (0)
 #endif
+    float rkeep[2] = {0.0f, 0.0f};                           // candidate residuals of this lane's first two points (all sweeps write them)
     for (;;) {
+        EDS12_PSTAMP(5);                                     // residual copy of an accepted evaluation, loop back
         const double* __restrict__ s_pose = s_pb[s_k];      // the pose block under evaluation
         PoseF ps;
         load_pose(s_pose, ps);
@@ -151,6 +156,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
         acc4d C = {0, 0, 0, 0}, C2 = {0, 0, 0, 0};
         int cb = -1;                    // residual block the tile currently belongs to (wave-uniform)
+        EDS12_PSTAMP(6);                // pose block -> registers
         // One sweep over the points.  MODE 0: the plain residual (PhotometricError).  PhotometricErrorNC needs the block norm of
         // the sampled brightness before any row can be formed, so it sweeps twice: MODE 1 samples, forms the un-weighted pose
         // columns J' = -dE and accumulates [J' | E]^T [J' | E] (which holds sum E^2 and sum E J') while stashing E and J' in
@@ -187,6 +193,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;
                 kgx[jj] = c[EDS_KF_GX * pl]; kgy[jj] = c[EDS_KF_GY * pl];
                 miss[jj] = false;
+#ifdef EDS_FUSED_STAMPS
+                if (jj == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EDS12_PSTAMP(7); }     // (diagnostic builds wait for the constants here)
+#endif
                 if (MODE == 2) continue;                                // rows come from the stash: no projection, no gather
                 kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
                 project_point(ps, kf[jj], pg[jj]);
@@ -229,6 +238,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     }
                 }
             }
+            EDS12_PSTAMP(0);                                            // constants, projection, probe, gathers issued
             // phase B: residual + 1x12 row (closed forms of SURVEY §8a), rows through LDS into the MFMA
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                     if (SAMPLING == 0) bicubic_patch(reinterpret_cast<float(&)[16]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
                     else bilinear_patch(reinterpret_cast<float(&)[4]>(tap[jj]), pg[jj].ay, pg[jj].ax, E, Er, Ec);
                     }
+                    EDS12_PSTAMP(1);                                    // taps arrived, spline done
                     PointProj pp;
                     finish_point(ps, pg[jj], E, Er, Ec, pp);
                     const float wp = MODE == 1 ? (valid ? 1.0f : 0.0f) : w;  // NC: pose columns un-weighted until the norm is known
@@ -333,7 +344,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         x[12] = w * (m * inv_n - E * inv_e);
                     }
                     if (valid) A.mhat[base + i] = x[12];              // candidate residual
+                    if (j0 == lo) rkeep[jj] = x[12];                  // (the first two of a lane also stay in registers: see the accept copy)
                 }
+                EDS12_PSTAMP(2);                                        // row formed, candidate residual stored
                 if (i_first < hi) {
                     for (int b = b_lo; b <= b_hi; ++b) {
                         if (b != cb) {
@@ -357,8 +370,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 }
             }
         }
+        EDS12_PSTAMP(3);                                                // staging + matrix core
         if (cb >= 0) flush(C + C2, cb);
         C = acc4d{0, 0, 0, 0}; C2 = acc4d{0, 0, 0, 0}; cb = -1;
+        EDS12_PSTAMP(4);                                                // tile added to the sums in LDS
         };
         if (!NC) {
             sweep(std::integral_constant<int, 0>());
@@ -484,7 +499,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         ++st_n;
 #endif
         if (s_accept) {                         // the candidate became the accepted point: its residuals are the ones to keep
-            for (int i = lo + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];    // each thread copies what it wrote itself
+            // each thread copies what it wrote itself; its first two points out of registers — a lone alignment on 8 CUs has nothing
+            // else, and the load of the value just stored (an L2 round trip) sat at the head of the next evaluation
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) { const int i = lo + jj * nthr + tid; if (i < hi) A.r[base + i] = rkeep[jj]; }
+            for (int i = lo + 2 * nthr + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];
         }
         if (s_state == 2) break;
     }
@@ -493,6 +512,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     if (tid == 0 && blockIdx.x == 0) {
         printf("[stamps12] lane-0 cycles per evaluation: points %llu  reduce %llu  solver %llu  (%d evaluations, %d threads)\n",
                st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_n, NTHR);
+        printf("[stamps12]   point phase: copy+loop %llu  pose %llu  constants %llu  project+probe+issue %llu  taps+spline %llu  row %llu  stage+mfma %llu  flush %llu\n",
+               pst[5] / st_n, pst[6] / st_n, pst[7] / st_n, pst[0] / st_n, pst[1] / st_n, pst[2] / st_n, pst[3] / st_n, pst[4] / st_n);
         printf("[stamps12]   solver split: decide %llu linearise %llu bookkeeping %llu propose %llu poseblock %llu wait %llu walk+rest %llu\n",
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }
