@@ -114,7 +114,9 @@ static EdsArrays arrays_for_pass(eds_trk* h, int first, int count) {
     bool ok = false;
     if (h->tiled && h->cfg.sampling == EDS_SAMPLE_BICUBIC && h->H < 8000) {
         const char* ev = getenv("EDS_FUSED_LAYOUT");
-        if (!(ev && std::strcmp(ev, "tiles") == 0) && (count >= 32 || h->dstrips)) ok = eds_strips_prepare(h, first, count);
+        // (a stand-alone pass never has the copies MADE: they cost ~60 passes' worth of what a pass gains from them — it uses the
+        // ones a solve or eds_trk_prepare_frames left behind)
+        if (!(ev && std::strcmp(ev, "tiles") == 0)) ok = eds_strips_current(h, first, count);
     }
     A.strips = ok ? h->dstrips : nullptr;
     A.strip_phases = h->strip_phases;
@@ -1135,7 +1137,7 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
     int rc = check_range(h, first, count);
     if (rc) return rc;
     if (elapsed_ms) *elapsed_ms = 0.f;
-    if (!h->tiled || h->cfg.sampling != EDS_SAMPLE_BICUBIC) return EDS_OK;
+    if (!h->tiled) return EDS_OK;      // (both samplers gather from the strips: the bilinear one reads the middle of the same patches)
     EDS_HIP_TRY(hipSetDevice(h->dev));
     if (force)
         for (int s = first; s < first + count; ++s) h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s].strips_version = 0;

@@ -999,7 +999,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         const bool q = bic && qany;                                 // (on tiles: the bicubic sampler only)
         // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member);
         // either sampler
-        const bool strips = qany && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_prepare(h, first, count);
+        const bool strips = qany && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_for_solve(h, first, count);
         A.strips = h->dstrips; A.strip_phases = h->strip_phases;
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
@@ -1049,7 +1049,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
     // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
     // Either sampler: the bilinear one reads the two middle rows / columns of the same 4 x 4 patch (its own kernels everywhere else).
-    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_prepare(h, first, count);
+    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_for_solve(h, first, count);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     if (strips && bicubic) {
         if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }

@@ -94,6 +94,8 @@ int  eds_fused_last_launch(eds_trk* h, eds_trk_launch_info* out);
 // eds_strips.hip: makes the strip copies of the frames the slots [first, first + count) sample current (allocates them at the first call;
 // one conversion launch per run of stale slots, on h->st).  false: no memory for them — the caller uses the tiles.
 bool eds_strips_prepare(eds_trk* h, int first, int count);
+bool eds_strips_for_solve(eds_trk* h, int first, int count);      // the solve kernels' question: gather from strips this time? (converts what the policy says)
+bool eds_strips_current(const eds_trk* h, int first, int count);  // every sampled slot of the range has an up-to-date strip copy (nothing is converted)
 void eds_strips_free(eds_trk* h);
 
 bool eds_fused12_supported(const eds_trk* h, int first, int count);

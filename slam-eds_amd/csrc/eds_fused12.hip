@@ -623,7 +623,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
     quad = quad && h->H < 8000;                   // 13-bit row field of the packed origins (pack_origin)
     // QUAD = 2: the same gather on the strip copies of the frames (EDS_FUSED_LAYOUT=tiles keeps the tiles; so does a failed allocation)
-    const bool strips = quad && want_strips && eds_strips_prepare(h, first, count);
+    const bool strips = quad && want_strips && eds_strips_for_solve(h, first, count);
     if (want_strips && !strips && count < 1024) quad = false;         // (no room for the copies: the tiles' rule)
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }

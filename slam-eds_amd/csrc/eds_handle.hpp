@@ -16,6 +16,7 @@ struct Slot {
     int frame_slot = -1;            // >= 0: this alignment samples THAT slot's frame storage (eds_trk_share_event_frame); -1: its own
     unsigned frame_version = 0;     // bumped by everything that writes this slot's frame storage ...
     unsigned strips_version = 0;    // ... and the version its strip copy (eds_layout.hpp) was made from; 0 = never
+    unsigned solved_version = 0;    // ... and the version the last on-device solve sampled: a frame that is solved AGAIN gets its strip copy (eds_strips_for_solve)
     double p[3] = {0, 0, 0}, q[4] = {0, 0, 0, 1}, v[6];
     double K[4] = {0, 0, 0, 0};
     eds_trk_info info;

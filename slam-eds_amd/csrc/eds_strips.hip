@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "eds_fused.hpp"
@@ -69,6 +70,46 @@ bool eds_strips_prepare(eds_trk* h, int first, int count) {
         s = e;
     }
     return hipGetLastError() == hipSuccess;
+}
+
+bool eds_strips_current(const eds_trk* h, int first, int count) {
+    if (!h->tiled || !h->dstrips) return false;
+    for (int s = first; s < first + count; ++s) {
+        const Slot& src = h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s];
+        if (src.strips_version == 0 || src.strips_version != src.frame_version) return false;
+    }
+    return true;
+}
+
+// Strips or tiles for this solve?  The copies cost what they weigh: 2 x phases x 1.3 MB written per 640x480 frame — 2.9 us of the
+// whole GPU per frame with 4 row phases (bench.py frame_layout_prep), against 0.26 us that a 2 000-point solve gains from them
+// (0.40 instead of 0.66 us per alignment at 4 096 per launch).  A frame that is solved ONCE — a live tracker: one event frame, one
+// optimize — is therefore sampled from the tiles it was written in; a frame that is solved AGAIN (the second solve that finds the same
+// frame version: batches that are re-solved, parameter sweeps, bench.py's steps over resident inputs) gets its copy then, and
+// eds_trk_prepare_frames makes it up front.  A few new frames among many kept ones are converted at once (one launch of tiles for
+// the whole range would cost more than their copies).  EDS_STRIPS_POLICY = reuse (default) | eager (convert at the first solve:
+// round 3's first rule) | never.
+bool eds_strips_for_solve(eds_trk* h, int first, int count) {
+    static const int policy = [] {
+        const char* ev = getenv("EDS_STRIPS_POLICY");
+        return !ev ? 0 : (std::strcmp(ev, "eager") == 0 ? 1 : (std::strcmp(ev, "never") == 0 ? 2 : 0));
+    }();
+    if (!h->tiled) return false;
+    int stale = 0, fresh = 0;
+    for (int s = first; s < first + count; ++s) {
+        Slot& src = h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s];
+        if (src.frame_version == 0) src.frame_version = 1;       // (frames written before versions were kept)
+        const bool cur = h->dstrips && src.strips_version == src.frame_version;
+        if (!cur) { ++stale; if (src.solved_version != src.frame_version) ++fresh; }
+    }
+    for (int s = first; s < first + count; ++s) {
+        Slot& src = h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s];
+        src.solved_version = src.frame_version;
+    }
+    if (policy == 2) return false;
+    if (stale == 0) return true;
+    if (policy == 0 && fresh * 11 > count) return false;          // first solve on (most of) these frames: the tiles
+    return eds_strips_prepare(h, first, count);
 }
 
 void eds_strips_free(eds_trk* h) {

@@ -142,6 +142,7 @@ def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling,
         h = capi.Handle(cfg, count, npts, H, W)
         for b in range(count):
             h.set_alignment(b, als[b % 4])
+        h.prepare_frames(0, count)          # (left to itself the library makes the strip copies when a frame is solved again)
         h.set_states(0, np.stack([ps] * count), np.stack([qs] * count), np.stack([als[b % 4].v0 for b in range(count)]))
         h.optimize_batch(0, 0, count)
         tab = h.results(0, count)
