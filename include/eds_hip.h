@@ -384,10 +384,13 @@ int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const
  * prices the kernel that ran instead of mirroring the library's selection rule. */
 /* The persistent kernels (and the streaming residual/Jacobian kernel on batches) gather from STRIP COPIES of the event frames
  * (csrc/eds_layout.hpp): 8-column-wide strips stored 2 x `phases` times so that every bicubic 4x4 patch is ONE 128-byte L2 line.
- * The frame writers keep writing the 4x4 tiles; a solve converts the slots whose copy is out of date before it launches.  This call
- * does that conversion NOW for slots [first, first + count) — to take it off a latency-critical optimize, or (force != 0: convert
- * even what is current) to measure it: elapsed_ms (optional) = HIP events around the conversion launches.  No-op for handles that
- * never use the copies (bilinear sampling, row-major layout). */
+ * The frame writers keep writing the 4x4 tiles.  The copies cost more than ONE solve gains from them (10 MB written per 640x480 frame
+ * with 4 phases: 2.9 us of the GPU, against 0.26 us gained per 2 000-point solve), so the library makes them for frames that are
+ * solved AGAIN: the first solve on a new frame samples the tiles, the second one that finds the same frame converts it; a few new
+ * frames among many converted ones are converted at once (csrc/eds_strips.hip; EDS_STRIPS_POLICY=eager|never overrides).  This
+ * call makes the copies NOW for slots [first, first + count) — for frames that WILL be solved many times (batches that are
+ * re-solved, parameter sweeps, benchmarks over resident inputs), or (force != 0: convert even what is current) to measure the
+ * conversion: elapsed_ms (optional) = HIP events around the conversion launches.  No-op for the row-major layout. */
 int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* elapsed_ms);
 
 typedef struct eds_trk_launch_info {
