@@ -307,6 +307,18 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             for (int j = 0; j < NREG; ++j) {
                 const int g = j >> 1;
                 const float ax_j = (j & 1) ? pg[g].ax.y : pg[g].ax.x, ay_j = (j & 1) ? pg[g].ay.y : pg[g].ay.x;
+                if constexpr (SAMPLING == 1) {
+                    // bilinear: the lane's own point needs pixels 1-2 of rows 1-2 of its patch — the rows quad lanes 1 and 2 fetched
+                    // (the wavefront's vmcnt(0) covers every lane's loads): four LDS reads, no row pass, no transposes
+                    const float* __restrict__ r1 = zone + (4 * j + (lane & 3)) * 256 + 4 * ((lane & ~3) + 1);
+                    const float p4[4] = {r1[1], r1[2], r1[5], r1[6]};          // row 2 sits one lane (4 floats) further
+                    float E, Er, Ec;
+                    bilinear_patch(p4, ay_j, ax_j, E, Er, Ec);
+                    const float iz_b = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_b = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_b = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
+                    const float w_b = (j & 1) ? k2w[g].y : k2w[g].x, mh_b = (j & 1) ? k2mh[g].y : k2mh[g].x;
+                    rcand[j] = row6_accumulate<(QUAD == 4)>(ps_fx, ps_fy, iz_b, un_b, vn_b, E, Er, Ec, w_b, mh_b, tau, A6);
+                    continue;
+                }
                 const f2 x01 = {quad_bcast_f<0>(ax_j), quad_bcast_f<1>(ax_j)}, x23 = {quad_bcast_f<2>(ax_j), quad_bcast_f<3>(ax_j)};
                 f2 ta[4], tb[4];
 #pragma unroll
@@ -315,24 +327,14 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     tb[k] = (f2){mine[(4 * j + 2) * 256 + k], mine[(4 * j + 3) * 256 + k]};
                 }
                 f2 f01, d01, f23, d23;
-                if constexpr (SAMPLING == 0) {
-                    hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
-                    hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
-                } else {            // bilinear: the row's two middle pixels, value and column difference
-                    d01 = ta[2] - ta[1]; f01 = ta[1] + x01 * d01;
-                    d23 = tb[2] - tb[1]; f23 = tb[1] + x23 * d23;
-                }
+                hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
+                hermite_pair(tb[0], tb[1], tb[2], tb[3], x23, 0.5f * x23, 3.0f * x23, f23, d23);
                 float f[4] = {f01.x, f01.y, f23.x, f23.y}, d[4] = {d01.x, d01.y, d23.x, d23.y};
                 quad_transpose(f, lane);
                 quad_transpose(d, lane);
                 f2 EEc, dE;
                 const f2 y2 = (f2)(ay_j);
-                if constexpr (SAMPLING == 0) {
-                    hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
-                } else {
-                    dE = (f2){f[2] - f[1], d[2] - d[1]};
-                    EEc = (f2){f[1], d[1]} + y2 * dE;
-                }
+                hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
                 const float iz_j = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_j = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_j = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
                 const float w_j = (j & 1) ? k2w[g].y : k2w[g].x, mh_j = (j & 1) ? k2mh[g].y : k2mh[g].x;
                 rcand[j] = row6_accumulate<(QUAD == 4)>(ps_fx, ps_fy, iz_j, un_j, vn_j, EEc.x, dE.x, EEc.y, w_j, mh_j, tau, A6);
