@@ -369,7 +369,7 @@ def configs_block(capi, synth, a):
     out["config3"] = {"workload": f"{B3} coarse-to-fine pyramids, levels 80x60 .. 640x480 with {counts[::-1]} points, {a.iters} LM6 iterations per level, "
                                   f"one launch per level for all pyramids",
                       "iterations_per_s": B3 * sum(its_l) / wall, "pyramids_per_s": B3 / wall, "ms_per_step": 1e3 * wall,
-                      "iterations_per_level_finest_first": its_l, "kernel": "eds_fused6_kernel, teams of 1 024 points per CU above 2 048 points (one launch per level)",
+                      "iterations_per_level_finest_first": its_l, "kernel": "eds_fused6_kernel, teams of 1 024 or 2 048 points per CU above 2 048 points (one launch per level)",
                       "roofline": roof(sum(B3 * n * (a.iters + 1) for n in counts), k_ms),
                       "parity": {"rows_checked": D3, "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
     pyr.close()

@@ -160,6 +160,40 @@ def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling,
         h.close()
 
 
+@pytest.mark.parametrize("npts", [2049, 3000, 4097, 7000])
+def test_wide_team_members_vs_oracle(gpu, capi, synth, po, npts):
+    """Above 2 048 points a launch whose members of 1 024 points would be more than one workgroup per CU gives every member 2 048
+    points instead (four per lane; eds_fused_solve): half the exchanges per point.  First solve on new frames (tiles), the same
+    frames again (strips), with and without the per-point Huber weight, ragged counts (a last member with one point), against the
+    oracle and against each other."""
+    H, W, count = 240, 320, 140
+    als = [synth.make_alignment(7600 + i, H=H, W=W, N=n) for i, n in enumerate((npts, npts - 1, max(2049, npts - 700), npts))]
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    K = 2 if npts <= 4096 else 4
+    for tau in (0.0, 0.01):
+        cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=6, huber_tau=tau)
+        h = capi.Handle(cfg, count, npts, H, W)
+        for b in range(count):
+            h.set_alignment(b, als[b % 4])
+        S = (np.stack([ps] * count), np.stack([qs] * count), np.stack([als[b % 4].v0 for b in range(count)]))
+        tabs = []
+        for layout, q in ((1, 2 if tau > 0 else 1), (2, 4 if tau > 0 else 3)):
+            h.set_states(0, *S); h.optimize_batch(0, 0, count)
+            li = h.last_launch()
+            assert li["kernel"] == f"eds_fused6_kernel<0, 4, 512, {q}, {K}>" and li["layout"] == layout and li["cus_per_alignment"] == K, li
+            tabs.append(h.results(0, count).copy())
+        assert np.abs(tabs[0][:, :7] - tabs[1][:, :7]).max() < 1e-6
+        for i, a in enumerate(als):
+            ref = po.Oracle(a).pose6_lm(ps, qs, a.v0, iters=6, lambda0=cfg.lambda0, huber_tau=tau)
+            for slot in (i, i + 4 * ((count - 1 - i) // 4)):
+                assert po.se3_distance(tabs[1][slot, 0:3], tabs[1][slot, 3:7], ref["p"], ref["q"]) <= TOL_POSE, (npts, slot)
+                assert tabs[1][slot, 14] == ref["iterations"] and np.array_equal(h.trace(slot)["accepted"], ref["accepted"])
+            er = po.Oracle(a).pose6_eval(tabs[1][i, 0:3], tabs[1][i, 3:7], a.v0)["r"]
+            r = h.residuals(i)
+            assert r.shape == (a.N,) and np.abs(r - er).max() <= 1e-5 * np.abs(er).max()
+        h.close()
+
+
 def test_new_keyframe_invalidates_device_residuals(gpu, capi, synth):
     """after a device-mode solve, set_keyframe must not leave 'residuals still in HBM' set — get_residuals /
     loss_param before the next optimize then report EDS_ERR_STATE instead of the previous keyframe's plane."""

@@ -15,5 +15,5 @@ for B in (int(x) for x in (sys.argv[2:] or ["32", "64", "256", "512"])):
     for _ in range(6):
         h.set_states(0, p0, q0, v0); t = time.perf_counter(); h.optimize_batch(0, 0, B); ts.append(time.perf_counter() - t)
     it = h.info(0)["num_iterations"]
-    print(f"N={N} B={B:5d}: {np.median(ts[2:])*1e3:8.3f} ms -> {B*it/np.median(ts[2:])/1e6:7.3f} M iterations/s  ({B*N*(it+1)/np.median(ts[2:])/1e9:5.1f} G point-evaluations/s)", flush=True)
+    print(f"N={N} B={B:5d} {h.last_launch()['kernel'][17:]:>22s}: {np.median(ts[2:])*1e3:8.3f} ms -> {B*it/np.median(ts[2:])/1e6:7.3f} M iterations/s  ({B*N*(it+1)/np.median(ts[2:])/1e9:5.1f} G point-evaluations/s)", flush=True)
     h.close()
