@@ -12,7 +12,8 @@ nmin = int(sys.argv[3]) if len(sys.argv) > 3 else 2049
 nmax = int(sys.argv[4]) if len(sys.argv) > 4 else 12000
 bad = 0
 for t in range(trials):
-    N = int(rng.integers(nmin, nmax)); B = int(rng.integers(1, 24)); sampling = int(rng.integers(0, 2)); tau = float(rng.choice([0.0, 0.01]))
+    N = int(rng.integers(nmin, nmax)); B = int(rng.integers(1, 24)) if rng.random() < 0.6 else int(rng.integers(24, 200)); sampling = int(rng.integers(0, 2));   # (large batches: members of 2 048 points)
+    tau = float(rng.choice([0.0, 0.01]))
     ref12 = bool(rng.integers(0, 3) == 0)
     H, W = 240, 320
     als = [synth.make_alignment(8800 + 10 * t + k, H=H, W=W, N=N, start="ctor" if ref12 else "truth_velocity") for k in range(2)]
