@@ -32,7 +32,11 @@
 extern "C" {
 #endif
 
-#define EDS_HIP_ABI_VERSION 1
+/* 3 (round 3): eds_trk_info.flags (was reserved), eds_kf_select.sobel_ksize, eds_event_times, eds_trk_launch_info; new entry points
+ * eds_trk_last_launch, eds_trk_prepare_frames, eds_trk_residuals_and_loss, eds_event_times_aos, eds_trk_build_event_frames_aos_timed,
+ * eds_pyr_*_batch / _slot, eds_trk_bench_live.  Nothing was removed or re-ordered; a caller built against 1 that zero-initialises
+ * its structs keeps working except for eds_kf_select (one field longer: call eds_kf_select_default first, as the header always said). */
+#define EDS_HIP_ABI_VERSION 3
 #define EDS_MAX_LEVELS 8
 
 typedef enum eds_status {

@@ -23,4 +23,13 @@ for name, pick in (("strong pixels", strong[rng.integers(0, len(strong), B * NE)
             assert rc == 0
             ts.append((time.perf_counter() - t0) * 1e6)
         print(f"   exp weights {use_exp}: {np.median(ts[2:]):.0f} us per batch of {B} frames")
+# the part that does not depend on the events (image clears, blur, level + norm, tile store, launches, one wait): slices of 16 events
+cx = np.full(B * 16, 100, np.uint16); cy = np.full(B * 16, 100, np.uint16); cp = np.ones(B * 16, np.uint8); offs = (np.arange(B + 1) * 16).astype(np.int32)
+ts = []
+for rep in range(8):
+    t0 = time.perf_counter()
+    capi.lib().eds_trk_build_event_frame_batch(h._h, 0, B, offs.ctypes.data_as(C.POINTER(C.c_int32)), cx.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                               cy.ctypes.data_as(C.POINTER(C.c_uint16)), cp.ctypes.data_as(C.POINTER(C.c_uint8)), 0, 0.5, 1, None)
+    ts.append((time.perf_counter() - t0) * 1e6)
+print(f"16 events per slice: {np.median(ts[2:]):.0f} us per batch of {B} frames")
 h.close()
