@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 // all 2 K granules of the entry in flight at once (the members sit on other XCDs: every load is a fabric round trip,
                 // and 2 K of them one after the other were ~4 us per evaluation), then only the late ones are polled again
                 double tot = 0.0;
-                constexpr int GM = TEAM < 4 ? TEAM : 4;             // members per round of loads (all 8 members of a team in one round: no faster)
+                constexpr int GM = TEAM < 4 ? TEAM : (TEAM == 16 ? 8 : 4);             // members per round of loads (all 8 members of a team in one round: no faster)
 #pragma unroll
                 for (int m0 = 0; m0 < TEAM; m0 += GM) {
                     unsigned long long v[2 * GM];
