@@ -439,7 +439,8 @@ class Handle:
 
     def optimize(self, slot, level=0, p=None, q=None, v=None):
         """Tracker::optimize for one slot.  Returns (p, q, v, info dict); raises EdsError(ERR_NOT_USABLE)."""
-        sp, sq, sv = self.get_state(slot)
+        if p is None or q is None or v is None:         # (the stored state only where the caller leaves one out: a call less on the live path)
+            sp, sq, sv = self.get_state(slot)
         p = sp if p is None else _f64(p).copy()
         q = sq if q is None else _f64(q).copy()
         v = sv if v is None else _f64(v).copy()
