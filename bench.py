@@ -691,6 +691,17 @@ def main():
                                                              f"{r_evals:.2f} evaluations per solve"}}
             k12 = h.last_launch()["kernel"]
             out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = k12
+            # ... and on frames that are new for every solve (the tiles: what a first solve launches, as for new_frame_per_solve)
+            os.environ["EDS_FUSED_LAYOUT"] = "tiles"
+            try:
+                n_ms = []
+                for k in range(3):
+                    h.set_states(0, p0, q0, v0)
+                    t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); n_ms.append(1e3 * (time.perf_counter() - t1))
+                out["reference_problem"]["new_frame_per_solve"] = {"lm_iterations_per_s": B * float(np.mean(h.results(0, B)[:, 14])) / (float(np.median(n_ms[1:])) * 1e-3),
+                                                                   "kernel_ms": h.info(0)["device_time_us"] * 1e-3, "kernel": h.last_launch()["kernel"]}
+            finally:
+                os.environ.pop("EDS_FUSED_LAYOUT", None)
             t = pmc_traffic(k12, a)
             if t:
                 out["reference_problem"]["roofline"]["traffic"] = t["bytes"]
