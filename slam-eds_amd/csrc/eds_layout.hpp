@@ -107,3 +107,16 @@ EDS_LAYOUT_HD static inline unsigned eds_strips_row_offset(int ra, int ca, int H
     const int p = ra & (phases - 1);
     return (unsigned)(2 * p + copy) * copy_bytes + (unsigned)((((cc >> 3) * Hp + (ra - p)) << 5) + ((cc & 7) << 2));
 }
+
+// ---- when the strip copies are made (eds_strips.hip) -------------------------------------------------------------------------
+// `stale` sampled slots of a solve's range have no up-to-date copy, `fresh` of those hold a frame no solve has sampled yet.
+// policy 0 (default, "reuse"): copies for frames that are solved AGAIN — a launch whose frames are (mostly) new samples the tiles;
+// a few new frames among many converted ones (< 1 in 11: a tile launch for the whole range would cost more than their copies) are
+// converted at once.  policy 1 ("eager"): convert whatever is stale.  policy 2 ("never").
+// Returns 0: sample the tiles, 1: the copies are current, use them, 2: convert the stale ones, then use them.
+EDS_LAYOUT_HD static inline int eds_strips_decide(int policy, int stale, int fresh, int count) {
+    if (policy == 2) return 0;
+    if (stale == 0) return 1;
+    if (policy == 0 && fresh * 11 > count) return 0;
+    return 2;
+}

@@ -106,9 +106,9 @@ bool eds_strips_for_solve(eds_trk* h, int first, int count) {
         Slot& src = h->slots[h->slots[s].frame_slot >= 0 ? h->slots[s].frame_slot : s];
         src.solved_version = src.frame_version;
     }
-    if (policy == 2) return false;
-    if (stale == 0) return true;
-    if (policy == 0 && fresh * 11 > count) return false;          // first solve on (most of) these frames: the tiles
+    const int what = eds_strips_decide(policy, stale, fresh, count);           // (eds_layout.hpp; tested on the CPU: tests/test_host_logic.py)
+    if (what == 0) return false;          // first solve on (most of) these frames: the tiles
+    if (what == 1) return h->dstrips != nullptr;
     return eds_strips_prepare(h, first, count);
 }
 

@@ -110,6 +110,8 @@ int hl_frame_layout(int H, int W, int tiled, int* Hp_out, int* Wp_out, int r, in
 // strips cut at column 4 cc), then walks every patch position a kernel can ask for (first row ra in [1, Hp - 4], first column ca in
 // [1, Wp - 4]) through eds_strips_row_offset and checks the 16 taps; returns the number of wrong taps and, in stats, the number of
 // patches and how many of them start on a 32 * phases byte boundary / lie inside ONE 128-byte line.
+int hl_strips_decide(int policy, int stale, int fresh, int count) { return eds_strips_decide(policy, stale, fresh, count); }
+
 int hl_strips_layout(int Hp, int Wp, int phases, long long* stats) {
     const int NS = eds_strips_count(Wp);
     const size_t copy_elems = eds_strips_copy_elems(Hp, Wp);

@@ -189,3 +189,16 @@ def test_strip_copies_hold_every_patch_in_place(hl, H, W, phases):
         assert one_line == patches
     else:
         assert abs(one_line / patches - phases / 4.0) < 0.02        # 1 phase: rows = 0 mod 4 only; 2 phases: rows = 0, 1 mod 4
+
+
+def test_strip_copy_rule(hl):
+    """eds_layout.hpp eds_strips_decide: the copies are made for frames that are solved again (0 tiles, 1 copies current, 2 convert)."""
+    d = hl.hl_strips_decide
+    assert d(0, 0, 0, 4096) == 1                                    # everything current
+    assert d(0, 4096, 4096, 4096) == 0                              # first solve on new frames: the tiles
+    assert d(0, 4096, 0, 4096) == 2                                 # the same frames again: convert
+    assert d(0, 372, 372, 4096) == 2 and d(0, 373, 373, 4096) == 0  # a few new frames among many: converted at once (< 1 in 11)
+    assert d(0, 40, 3, 40) == 2 and d(0, 40, 4, 40) == 0
+    assert d(1, 4096, 4096, 4096) == 2 and d(1, 0, 0, 8) == 1       # eager
+    assert d(2, 0, 0, 8) == 0 and d(2, 8, 0, 8) == 0                # never
+
