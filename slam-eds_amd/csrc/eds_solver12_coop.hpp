@@ -31,9 +31,9 @@ enum { M_RETURN = 0, M_LIN_ITER0 = 1, M_LIN_ACCEPT = 2, M_ADVANCE = 3, M_LOOP = 
 struct Work12 {                 // LDS scratch of the cooperative solver
     double y[12], t[12];
     double T[144];              // A P while the velocity columns are being projected
-    double r0[EDS_DEV_MAX_BLOCKS], r1[EDS_DEV_MAX_BLOCKS];
+    double r1[EDS_DEV_MAX_BLOCKS];   // rho' of every block's loss (the linearisation weighs the blocks' sums with it)
     double cost, rel;
-    int mode, ok, accepted;     // accepted: the evaluation just consumed became the accepted point
+    int ok, accepted;           // accepted: the evaluation just consumed became the accepted point
 #ifdef EDS_FUSED_STAMPS
     unsigned long long st[8], st_t;
 #endif
