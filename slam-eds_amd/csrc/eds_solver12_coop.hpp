@@ -219,14 +219,22 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
         if (lane == 0) {
             sv.have_scale = 1;
             sv.x_cost = W.cost;
+            // max |x - Plus(x, -g)| is only ever compared with the gradient tolerance (coop12_walk).  Its translation part is |g_t| as the
+            // additive block forms it; when that alone is clearly above the tolerance — every linearisation of a solve that is not
+            // about to end — the quaternion and velocity parts (a square root, two polynomials, a normalisation: ~1 500 cycles on
+            // this lane, on the critical path of every accepted step) cannot change the comparison and are not formed.
             double ng[12], pp[3], pq[4], pv[6];
             for (int k = 0; k < 12; ++k) ng[k] = -sv.g[k];
-            edsm::state_plus12(sv.p, sv.q, sv.v, ng, pp, pq, pv);
             double m = 0.0;
-            for (int i = 0; i < 3; ++i) m = fmax(m, fabs(sv.p[i] - pp[i]));
-            for (int i = 0; i < 4; ++i) m = fmax(m, fabs(sv.q[i] - pq[i]));
-            for (int i = 0; i < 6; ++i) m = fmax(m, fabs(sv.v[i] - pv[i]));
-            sv.grad_max_norm = m;
+            for (int i = 0; i < 3; ++i) { const double pi_ = sv.p[i]; m = fmax(m, fabs(pi_ - (pi_ + ng[i]))); }
+            if (!(m > 2.0 * sv.gtol)) {
+                edsm::state_plus12(sv.p, sv.q, sv.v, ng, pp, pq, pv);
+                m = 0.0;
+                for (int i = 0; i < 3; ++i) m = fmax(m, fabs(sv.p[i] - pp[i]));
+                for (int i = 0; i < 4; ++i) m = fmax(m, fabs(sv.q[i] - pq[i]));
+                for (int i = 0; i < 6; ++i) m = fmax(m, fabs(sv.v[i] - pv[i]));
+            }
+            sv.grad_max_norm = m;          // (a lower bound above the tolerance, or the value itself)
             if (mode == M_LIN_ITER0) {
                 sv.initial_cost = sv.x_cost; sv.minimum_cost = sv.x_cost;
                 sv.iteration = 0; sv.step_successful = 1;
