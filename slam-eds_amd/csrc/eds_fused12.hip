@@ -137,7 +137,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 
 #ifdef EDS_FUSED_STAMPS
     unsigned long long st_acc[3] = {0, 0, 0}, st_t = __builtin_readcyclecounter();
-    int st_n = 0;
+    int st_n = 0, st_prop = 0;
+    if (tid < 8) for (int w_ = 0; w_ < EDS_NCAND; ++w_) s_step[w_].pst[tid] = 0;
 #define EDS12_STAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); st_acc[k] += n_ - st_t; st_t = n_; pst_t = n_; } while (0)
     unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pst_t = st_t;        // the point phase in five pieces (wavefront 0)
 #define EDS12_PSTAMP(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); pst[k] += n_ - pst_t; pst_t = n_; } while (0)
@@ -471,6 +472,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #define EDS12_SOLVE_STAMP(k) do { } while (0)
 #endif
             EDS12_SOLVE_STAMP(2);               // bookkeeping + barrier
+#ifdef EDS_FUSED_STAMPS
+            if (tid == 0) ++st_prop;
+#endif
             if (wave < EDS_NCAND) {
                 edsc::coop12_propose(sv, wave, s_cand[wave], s_step[wave], lane);
                 EDS12_SOLVE_STAMP(3);           // factorisation, substitutions, model cost change, candidate point
@@ -514,6 +518,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                st_acc[0] / st_n, st_acc[1] / st_n, st_acc[2] / st_n, st_n, NTHR);
         printf("[stamps12]   point phase: copy+loop %llu  pose %llu  constants %llu  project+probe+issue %llu  taps+spline %llu  row %llu  stage+mfma %llu  flush %llu\n",
                pst[5] / st_n, pst[6] / st_n, pst[7] / st_n, pst[0] / st_n, pst[1] / st_n, pst[2] / st_n, pst[3] / st_n, pst[4] / st_n);
+        printf("[stamps12]   propose (wavefront 0, per call): loads+damping %llu  factorisation %llu  substitutions %llu  A s %llu  model cost change %llu  candidate point %llu\n",
+               s_step[0].pst[0] / (st_prop > 0 ? st_prop : 1), s_step[0].pst[1] / (st_prop > 0 ? st_prop : 1), s_step[0].pst[2] / (st_prop > 0 ? st_prop : 1),
+               s_step[0].pst[3] / (st_prop > 0 ? st_prop : 1), s_step[0].pst[4] / (st_prop > 0 ? st_prop : 1), s_step[0].pst[5] / (st_prop > 0 ? st_prop : 1));
         printf("[stamps12]   solver split: decide %llu linearise %llu bookkeeping %llu propose %llu poseblock %llu wait %llu walk+rest %llu\n",
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }

@@ -61,7 +61,8 @@ __device__ __forceinline__ double bcast(double x, int src) {
 // the solver is at and for the next EDS_NCAND - 1 radii of that sequence (each on its own SIMD: the wall time of one), including
 // the candidate point and its pose block.  An unsuccessful evaluation then only does the O(1) bookkeeping and moves on to the
 // prepared step: linearisation, factorisation and pose block are off its critical path.  Decisions, counters, radii and the order of
-// every floating-point operation are those of edss::Solver12 (which the host-driven loop and the CPU tests run).
+// every floating-point operation are those of edss::Solver12 (which the host-driven loop and the CPU tests run) — except the back
+// substitution, whose terms leave in the opposite order (last bits).
 #define EDS_NCAND 4
 enum { W_RETURN = 0, W_EVAL = 1, W_NEED = 2 };
 
@@ -71,9 +72,11 @@ struct Cand12 {                 // one prepared step
     int valid, pad;
 };
 struct Step12 {                 // LDS scratch of one proposing wavefront
-    double y[12], t[12];
     double L[144];              // the Cholesky factor, row-major, so that lane i can pick up COLUMN i for the back substitution
     int ok, pad;
+#ifdef EDS_FUSED_STAMPS
+    unsigned long long pst[8];  // diagnostic build: cycles of the pieces of coop12_propose (lane 0), summed over the calls
+#endif
 };
 
 // Solver12::on_eval up to (and including) the linearisation at a newly accepted point.  Wavefront 0, all lanes.
@@ -258,7 +261,16 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
 // `c`, its scratch `W` and (ahead == 0, first solve after a linearisation) sv.diagonal.  Lane i (< 12) holds ROW i of the lower
 // triangle in registers; pivots and pivot-row entries travel by v_readlane, so the factorisation and both substitutions never
 // touch LDS.  Operation order per entry is that of edsm::chol_solve_packed.
+#ifdef EDS_FUSED_STAMPS
+#define EDS_PT(k) do { pt_[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define EDS_PT(k) do { } while (0)
+#endif
 __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand12& c, Step12& W, const int lane) {
+#ifdef EDS_FUSED_STAMPS
+    unsigned long long pt_[8];
+#endif
+    EDS_PT(0);
     double radius = sv.radius, df = sv.decrease_factor;
     for (int i = 0; i < ahead; ++i) { radius /= df; df *= 2.0; }
     const int row = lane < 12 ? lane : 0;
@@ -280,6 +292,7 @@ __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand1
 #pragma unroll
         for (int b = 0; b < 12; ++b) Lr[b] = (b == row) ? dg : Lr[b];
     }
+    EDS_PT(1);                      // loads, scaling, damping
     double idr = 0.0;               // 1 / L_rr of this lane's row
     bool okl = true;
 #pragma unroll
@@ -292,6 +305,7 @@ __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand1
 #pragma unroll
         for (int cc = j + 1; cc < 12; ++cc) Lr[cc] -= Lr[j] * bcast(Lr[j], cc);   // L[i][j] * L[c][j]
     }
+    EDS_PT(2);                      // factorisation
 #pragma unroll
     for (int k = 0; k < 12; ++k) {                                       // L y = b
         if (row == k) bi = bi * idr;
@@ -317,37 +331,67 @@ __device__ inline void coop12_propose(edss::Solver12& sv, const int ahead, Cand1
         const double xk = bcast(bi, k);
         if (row < k) bi -= Lc[k] * xk;
     }
-    if (lane == 0) W.ok = okl ? 1 : 0;
-    if (lane < 12) { W.y[lane] = bi; c.step[lane] = -bi; }
-    EDS_WSYNC();
-    if (lane < 12) {
-        double t = 0.0;
-        for (int b = 0; b < 12; ++b) t += sv.A[12 * lane + b] * sv.scale[b] * c.step[b];
-        W.t[lane] = t;
+    EDS_PT(3);                      // both substitutions (the factor through LDS in between)
+    // Round 3: the rest — A s, the model cost change, the candidate point — without a trip through LDS per piece and without a serial
+    // lane: lane a (< 12) holds y_a; the step goes round by v_readlane, lane a forms t_a = sum_b A[a][b] scale[b] step[b] from its own
+    // row of A, the t_a go round the same way, and EVERY lane forms the three 12-term sums and the candidate point (same operands,
+    // same order as edss::Solver12::advance: the results are bit for bit what lane 0 computed alone); lane 0 stores.
+    double Ar[12], sc[12], gg[12];
+#pragma unroll
+    for (int b = 0; b < 12; ++b) { Ar[b] = sv.A[12 * row + b]; sc[b] = sv.scale[b]; gg[b] = sv.g[b]; }      // one batch of LDS reads (scale, g: broadcasts)
+    double pq_[13];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pq_[i] = sv.p[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pq_[3 + i] = sv.q[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pq_[7 + i] = sv.v[i];
+    double st_[12];                 // the step, on every lane
+#pragma unroll
+    for (int b = 0; b < 12; ++b) st_[b] = -bcast(bi, b);
+    double t = 0.0;
+#pragma unroll
+    for (int b = 0; b < 12; ++b) t += Ar[b] * sc[b] * st_[b];
+    EDS_PT(4);                      // A s
+    double chk = 0.0, sg = 0.0, sAs = 0.0;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+        chk += -st_[a];             // (= y_a)
+        sg += st_[a] * gg[a] * sc[a];
+        sAs += st_[a] * sc[a] * bcast(t, a);
     }
-    EDS_WSYNC();
+    bool valid = okl && (chk == chk) && (fabs(chk) < 1e300);
+    double mcc = 0.0;
+    if (valid) {
+        mcc = -sg - 0.5 * sAs;
+        valid = mcc > 0.0;
+    }
+    EDS_PT(5);                      // model cost change
+    double cp_[3], cq_[4], cv_[6];
+    if (valid) {
+        double delta[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) delta[k] = st_[k] * sc[k];
+        edsm::state_plus12(pq_, pq_ + 3, pq_ + 7, delta, cp_, cq_, cv_);
+    }
+    if (lane < 12) c.step[lane] = -bi;
     if (lane == 0) {
-        double chk = 0.0;
-        for (int a = 0; a < 12; ++a) chk += W.y[a];
-        bool valid = W.ok && (chk == chk) && (fabs(chk) < 1e300);
-        double mcc = 0.0;
-        if (valid) {
-            double sg = 0.0, sAs = 0.0;
-            for (int a = 0; a < 12; ++a) {
-                sg += c.step[a] * sv.g[a] * sv.scale[a];
-                sAs += c.step[a] * sv.scale[a] * W.t[a];
-            }
-            mcc = -sg - 0.5 * sAs;
-            valid = mcc > 0.0;
-        }
+        W.ok = okl ? 1 : 0;
         c.mcc = mcc; c.valid = valid ? 1 : 0;
         if (valid) {
-            double delta[12];
-            for (int k = 0; k < 12; ++k) delta[k] = c.step[k] * sv.scale[k];
-            edsm::state_plus12(sv.p, sv.q, sv.v, delta, c.cp, c.cq, c.cv);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) c.cp[i] = cp_[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c.cq[i] = cq_[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) c.cv[i] = cv_[i];
         }
     }
     EDS_WSYNC();
+#ifdef EDS_FUSED_STAMPS
+    EDS_PT(6);                      // candidate point
+    if (lane == 0) for (int k = 0; k < 6; ++k) W.pst[k] += pt_[k + 1] - pt_[k];
+#endif
 }
 
 // Solver12::advance on prepared steps.  Wavefront 0, ALL lanes (round 3: every lane walks, on state read from LDS in one batch of
