@@ -163,15 +163,16 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
 
     {                                   // Solver12::linearise at the (new) accepted point
         bool bad = !(fabs(W.cost) < 1e300);
+        const int nbu = uniform_int(nb);        // (scalar loops over the blocks: nb comes out of LDS, i.e. in a vector register)
         for (int i = lane; i < 144; i += 64) {
             double a = 0.0;
-            for (int k = 0; k < nb; ++k) a += W.r1[k] * S.H[k][i];
+            for (int k = 0; k < nbu; ++k) a += W.r1[k] * S.H[k][i];
             sv.A[i] = a;
             bad |= !(fabs(a) < 1e300);
         }
         if (lane < 12) {
             double a = 0.0;
-            for (int k = 0; k < nb; ++k) a += W.r1[k] * S.g[k][lane];
+            for (int k = 0; k < nbu; ++k) a += W.r1[k] * S.g[k][lane];
             sv.g[lane] = a;
             bad |= !(fabs(a) < 1e300);
         }
@@ -217,8 +218,10 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
             if (lane < 12) sv.g[lane] = gp;
             EDS_WSYNC();
         }
-        if (!sv.have_scale && lane < 12) sv.scale[lane] = 1.0 / (1.0 + sqrt(sv.A[13 * lane]));
-        EDS_WSYNC();
+        if (!uniform_int(sv.have_scale)) {      // (first linearisation of a solve only)
+            if (lane < 12) sv.scale[lane] = 1.0 / (1.0 + sqrt(sv.A[13 * lane]));
+            EDS_WSYNC();
+        }
         if (lane == 0) {
             sv.have_scale = 1;
             sv.x_cost = W.cost;
