@@ -1007,8 +1007,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         // members, half the exchanges and solver runs per point.  Measured (tools/bench_large_n.py, 1280x720): 8 000 points x 256
         // alignments 3.56 -> 4.73 M it/s, 16 000 x 256 1.87 -> 2.65 M, 4 000 x 256 6.4 -> 8.7 M; at exactly 256 members of 1 024 (64 x 4 000,
         // 32 x 8 000, 16 x 16 000) the narrow form is 15-20 % faster, below it by more.  Knob: EDS_TEAM_WIDE=0|1.
-        bool wide_members = q && maxN > 2048 && count * team > 256;
-        if (const char* ev = getenv("EDS_TEAM_WIDE")) wide_members = q && maxN > 2048 && atoi(ev) != 0;
+        const bool wide_ok = (q || (!bic && strips)) && maxN > 2048;       // bicubic on either layout, the bilinear sampler on the strips
+        bool wide_members = wide_ok && count * team > 256;
+        if (const char* ev = getenv("EDS_TEAM_WIDE")) wide_members = wide_ok && atoi(ev) != 0;
         if (wide_members) { team = team / 2; fb.pending_team = team; }
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
@@ -1027,8 +1028,9 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
                             else if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K);                      \
                             else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 4, K); else EDS_LAUNCH_TEAM(0, 2, 3, K); }                 \
                             else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
-        if (wide_members) {                          // 2 048 points per member, four per lane (bicubic; strips, or tiles on a first solve)
-#define EDS_TEAM_Q4(K) do { if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 4, 4, K); else EDS_LAUNCH_TEAM(0, 4, 3, K); }                     \
+        if (wide_members) {                          // 2 048 points per member, four per lane (bicubic: strips, or tiles on a first solve; bilinear: strips)
+#define EDS_TEAM_Q4(K) do { if (!bic) { if (tau > 0) EDS_LAUNCH_TEAM(1, 4, 4, K); else EDS_LAUNCH_TEAM(1, 4, 3, K); }                      \
+                            else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 4, 4, K); else EDS_LAUNCH_TEAM(0, 4, 3, K); }                \
                             else if (tau > 0) EDS_LAUNCH_TEAM(0, 4, 2, K); else EDS_LAUNCH_TEAM(0, 4, 1, K); } while (0)
             if (team == 2) EDS_TEAM_Q4(2); else if (team == 4) EDS_TEAM_Q4(4); else EDS_TEAM_Q4(8);
 #undef EDS_TEAM_Q4
