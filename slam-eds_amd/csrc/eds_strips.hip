@@ -1,9 +1,10 @@
 // Strip copies of the event frames (eds_layout.hpp): the layout the persistent pose-only kernel gathers from since round 3.
 //
 // The frame writers (set_event_frame, the event-frame builders, the pyramid) keep writing 4x4 tiles — every other kernel samples
-// those — and bump the slot's frame_version; a solve that wants strips calls eds_strips_prepare, which converts the slots whose
-// copy is out of date: one launch per run of stale slots, every thread moving one aligned 16-byte tile row into its place in a
-// strip (reads 2 x 1.26 MB, writes 2.5 MB per 640x480 frame: ~1 us per frame at the rates the batched image passes reach).
+// those — and bump the slot's frame_version.  A solve asks eds_strips_for_solve whether to gather from the copies: they are made for
+// frames that are solved AGAIN (the rule and its arithmetic: below), by eds_strips_prepare — one launch per run of stale slots,
+// every thread moving one aligned 16-byte tile row into its place in a strip (per 640x480 frame and row phase: 2.5 MB written,
+// 1.0 us of the GPU with one phase, 2.9-3.2 us with four).  eds_trk_prepare_frames makes them on request.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
