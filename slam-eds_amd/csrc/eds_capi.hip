@@ -97,10 +97,12 @@ int max_points(const eds_trk* h, int first, int count) {
 }
 
 // geometry of the reduction grid for `count` slots with at most N points each
-void reduce_geometry(int N, int nb_red, int* cpb, int* nseg) {
+// (a segment = one workgroup's record: 256 points, or 1 024 for the 6-column pass, whose lanes fold four points each — eds_kernels.hpp)
+void reduce_geometry(int N, int nb_red, int ncols, int* cpb, int* nseg) {
     const int ne = N / nb_red;
     const int last = ne + (N - nb_red * ne);
-    *cpb = std::max(1, (last + EDS_TPB - 1) / EDS_TPB);
+    const int per_seg = EDS_TPB * eds_reduce_points_per_lane(ncols, nb_red);
+    *cpb = std::max(1, (last + per_seg - 1) / per_seg);
     *nseg = nb_red * (*cpb);
 }
 
@@ -136,7 +138,7 @@ int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bo
     if (with_reduction) {
         const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
         int cpb, nseg;
-        reduce_geometry(N, nb_red, &cpb, &nseg);
+        reduce_geometry(N, nb_red, ncols, &cpb, &nseg);
         if (nseg > h->max_seg) return fail(EDS_ERR_INVALID, "reduction grid exceeds allocation");
         eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st);
         if (fetch)
@@ -152,7 +154,7 @@ int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bo
 // sums of a slot after run_pass (host side, fp64)
 void gather6(const eds_trk* h, int slot, edss::Sums6* S) {
     int cpb, nseg;
-    reduce_geometry(h->slots[slot].N, 1, &cpb, &nseg);
+    reduce_geometry(h->slots[slot].N, 1, 6, &cpb, &nseg);
     // NB: the grid was sized for the max N of the range; segments beyond this slot's own are all-zero
     double rec[EDS_RED_N6];
     for (int i = 0; i < EDS_RED_N6; ++i) rec[i] = 0.0;
@@ -164,7 +166,7 @@ void gather6(const eds_trk* h, int slot, edss::Sums6* S) {
 void gather12(const eds_trk* h, int slot, int range_max_N, edss::Sums12* S) {
     const int nb = effective_blocks(h);
     int cpb, nseg;
-    reduce_geometry(range_max_N, nb, &cpb, &nseg);
+    reduce_geometry(range_max_N, nb, 12, &cpb, &nseg);
     S->nb = nb;
     const double* base = h->h_part + (size_t)slot * h->max_seg * EDS_RED_K;
     for (int k = 0; k < nb; ++k)
@@ -1217,7 +1219,7 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
     const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
     int cpb, nseg;
-    reduce_geometry(N, nb_red, &cpb, &nseg);
+    reduce_geometry(N, nb_red, ncols, &cpb, &nseg);
     EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
     for (int i = 0; i < reps; ++i) {
         eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);

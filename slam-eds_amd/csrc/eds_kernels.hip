@@ -237,9 +237,12 @@ __global__ __launch_bounds__(EDS_TPB) void eds_nc_fix_kernel(EdsArrays A, int fi
 
 // ---------------------------------------------------------------------------------------
 // Reduction pass.  Segment s of a slot covers residual block k = s / cpb, points
-// [start_k + c*256, ...) with c = s % cpb, so records never straddle residual blocks
+// [start_k + c*256*PPL, ...) with c = s % cpb, so records never straddle residual blocks
 // (the reference applies its loss per block, Tracker.cpp:146-161,192).
-template <int NC>
+// PPL = 4 (the 6-column pass, one residual block): a lane folds FOUR consecutive points — one 16-byte load per plane and lane, seven
+// of them in flight before the first product — so the butterfly, the LDS hop and the fp64 record are paid once per 1 024 points instead
+// of once per 256.  A pure 28 B/point stream: round 3's one-point-per-lane form ran at 3.9 TB/s.
+template <int NC, int PPL>
 __global__ __launch_bounds__(EDS_TPB) void eds_reduce_kernel(EdsArrays A, int first, int count, int nseg, int nb_red, int cpb) {
     constexpr int NV = NC * (NC + 1) / 2 + NC + 1;
     constexpr int K = (NC == 6) ? EDS_RED_K6 : EDS_RED_K12;
@@ -255,25 +258,57 @@ __global__ __launch_bounds__(EDS_TPB) void eds_reduce_kernel(EdsArrays A, int fi
         start = k * ne;
         n = ne + ((k + 1 == nb_red) ? (N - (k + 1) * ne) : 0);
     }
-    const int li = c * EDS_TPB + threadIdx.x;
     float acc[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) acc[j] = 0.0f;
-    if (li < n) {
-        const size_t o = (size_t)slot * A.Np + start + li;
-        const size_t plane = (size_t)A.B * A.Np;
-        float J[NC];
+    const size_t plane = (size_t)A.B * A.Np;
+    const float tau = (float)pb[EDS_PB_HUBER];
+    if constexpr (PPL == 1) {
+        const int li = c * EDS_TPB + threadIdx.x;
+        if (li < n) {
+            const size_t o = (size_t)slot * A.Np + start + li;
+            float J[NC];
 #pragma unroll
-        for (int j = 0; j < NC; ++j) J[j] = A.J[o + j * plane];
-        const float r = A.r[o];
-        float hw = 1.0f, ct = r * r;
-        const float tau = (float)pb[EDS_PB_HUBER];
-        if (NC == 6 && tau > 0.0f) {           // per-point Huber (extension; cf. CoarseTracker.cpp:445)
-            const float ar = fabsf(r);
-            if (ar > tau) hw = tau / ar;
-            ct = hw * r * r * (2.0f - hw);
+            for (int j = 0; j < NC; ++j) J[j] = A.J[o + j * plane];
+            const float r = A.r[o];
+            float hw = 1.0f, ct = r * r;
+            if (NC == 6 && tau > 0.0f) {           // per-point Huber (extension; cf. CoarseTracker.cpp:445)
+                const float ar = fabsf(r);
+                if (ar > tau) hw = tau / ar;
+                ct = hw * r * r * (2.0f - hw);
+            }
+            accumulate_normal<NC>(acc, J, r, hw, ct);
         }
-        accumulate_normal<NC>(acc, J, r, hw, ct);
+    } else {
+        static_assert(PPL == 1 || PPL == 4, "one point per lane, or four consecutive ones (16-byte loads)");
+        // nb_red == 1 here (start = 0): element 4 * lane of a plane is 16-byte aligned (Np is a multiple of 256), and a group of
+        // four lies wholly inside or wholly outside the padded plane
+        const int li = (c * EDS_TPB + threadIdx.x) * 4;
+        if (li < n) {
+            const size_t o = (size_t)slot * A.Np + li;
+            float4 Jv[NC];
+#pragma unroll
+            for (int j = 0; j < NC; ++j) Jv[j] = *reinterpret_cast<const float4*>(A.J + o + j * plane);
+            const float4 rv = *reinterpret_cast<const float4*>(A.r + o);
+            const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float J[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) J[j] = e == 0 ? Jv[j].x : (e == 1 ? Jv[j].y : (e == 2 ? Jv[j].z : Jv[j].w));
+                const bool on = li + e < n;            // the padding behind N holds whatever was there
+                const float r = on ? r4[e] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) J[j] = on ? J[j] : 0.0f;
+                float hw = 1.0f, ct = r * r;
+                if (NC == 6 && tau > 0.0f) {
+                    const float ar = fabsf(r);
+                    if (ar > tau) hw = tau / ar;
+                    ct = hw * r * r * (2.0f - hw);
+                }
+                accumulate_normal<NC>(acc, J, r, hw, ct);
+            }
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     wave_reduce_scatter<K>(acc, lane);
@@ -314,6 +349,8 @@ void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, i
 }
 void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st) {
     const dim3 g(grid_for(count, nseg)), b(EDS_TPB);
-    if (ncols == 6) hipLaunchKernelGGL((eds_reduce_kernel<6>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
-    else hipLaunchKernelGGL((eds_reduce_kernel<12>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    // (the 6-column pass always reduces one block per slot: the four-points-per-lane form; eds_reduce_points_per_lane says so to the host)
+    if (ncols == 6 && nb_red == 1) hipLaunchKernelGGL((eds_reduce_kernel<6, 4>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    else if (ncols == 6) hipLaunchKernelGGL((eds_reduce_kernel<6, 1>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    else hipLaunchKernelGGL((eds_reduce_kernel<12, 1>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
 }
