@@ -616,8 +616,8 @@ def main():
                                                 "(csrc/eds_layout.hpp); it is paid once per event frame, not per solve"}
             if world == 1 and a.solver == "lm6":
                 # a frame that is solved ONCE (a live tracker's event frame): the library samples the tiles it was written in — the
-                # kernel a first solve launches (EDS_FUSED_LAYOUT=tiles forces it here; the knob is read per solve)
-                os.environ["EDS_FUSED_LAYOUT"] = "tiles"
+                # kernel a first solve launches (the handle's EDS_FUSED_LAYOUT knob forces it here)
+                h.set_knob("EDS_FUSED_LAYOUT", "tiles")
                 try:
                     n_ms, n_dev = [], []
                     for k in range(4):
@@ -626,7 +626,7 @@ def main():
                         n_dev.append(h.info(0)["device_time_us"] * 1e-3)
                     nt = h.results(0, B); nk = h.last_launch()["kernel"]
                 finally:
-                    os.environ.pop("EDS_FUSED_LAYOUT", None)
+                    h.set_knob("EDS_FUSED_LAYOUT", None)
                 its_n = float(np.mean(nt[:, 14]))
                 out["new_frame_per_solve"] = {
                     "iterations_per_s": B * its_n / (float(np.median(n_ms[1:])) * 1e-3), "kernel_ms": float(np.median(n_dev[1:])), "kernel": nk,
@@ -692,7 +692,7 @@ def main():
             k12 = h.last_launch()["kernel"]
             out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = k12
             # ... and on frames that are new for every solve (the tiles: what a first solve launches, as for new_frame_per_solve)
-            os.environ["EDS_FUSED_LAYOUT"] = "tiles"
+            h.set_knob("EDS_FUSED_LAYOUT", "tiles")
             try:
                 n_ms = []
                 for k in range(3):
@@ -701,7 +701,7 @@ def main():
                 out["reference_problem"]["new_frame_per_solve"] = {"lm_iterations_per_s": B * float(np.mean(h.results(0, B)[:, 14])) / (float(np.median(n_ms[1:])) * 1e-3),
                                                                    "kernel_ms": h.info(0)["device_time_us"] * 1e-3, "kernel": h.last_launch()["kernel"]}
             finally:
-                os.environ.pop("EDS_FUSED_LAYOUT", None)
+                h.set_knob("EDS_FUSED_LAYOUT", None)
             t = pmc_traffic(k12, a)
             if t:
                 out["reference_problem"]["roofline"]["traffic"] = t["bytes"]

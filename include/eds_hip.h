@@ -35,8 +35,12 @@ extern "C" {
 /* 3 (round 3): eds_trk_info.flags (was reserved), eds_kf_select.sobel_ksize, eds_event_times, eds_trk_launch_info; new entry points
  * eds_trk_last_launch, eds_trk_prepare_frames, eds_trk_residuals_and_loss, eds_event_times_aos, eds_trk_build_event_frames_aos_timed,
  * eds_pyr_*_batch / _slot, eds_trk_bench_live.  Nothing was removed or re-ordered; a caller built against 1 that zero-initialises
- * its structs keeps working except for eds_kf_select (one field longer: call eds_kf_select_default first, as the header always said). */
-#define EDS_HIP_ABI_VERSION 3
+ * its structs keeps working except for eds_kf_select (its `reserved` word became sobel_ksize — same size; 0 there now reads as "3", but
+ * call eds_kf_select_default first, as the header always said).
+ * 4 (round 4): tuning knobs are per HANDLE — read from the environment once, at eds_trk_create, and changed with eds_trk_set_knob; no
+ * entry point reads the environment afterwards.  New entry points: eds_trk_set_knob, eds_trk_get_strips_info, eds_gather_results*
+ * (RCCL gather of the result table for a C / C++ caller).  Nothing was removed or re-ordered. */
+#define EDS_HIP_ABI_VERSION 4
 #define EDS_MAX_LEVELS 8
 
 typedef enum eds_status {
@@ -396,6 +400,20 @@ int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const
  * re-solved, parameter sweeps, benchmarks over resident inputs), or (force != 0: convert even what is current) to measure the
  * conversion: elapsed_ms (optional) = HIP events around the conversion launches.  No-op for the row-major layout. */
 int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* elapsed_ms);
+
+/* Tuning knobs (A/B runs and tests; the defaults are the measured best).  They belong to the HANDLE: eds_trk_create reads the process
+ * environment once (variables of the same names), eds_trk_set_knob changes one knob of one handle afterwards — two handles with
+ * different knobs coexist, and no solve touches getenv().  value NULL or "" restores the default.  Names and values (csrc/eds_launch_rule.hpp
+ * holds the rule they steer): EDS_REF12_EXEC=device|host, EDS_FUSED_THREADS=64..1024, EDS_FUSED_PPT=0|1|2|4, EDS_LM6_SPEC=0|1,
+ * EDS_LM6_KERNEL=resident|paired|wide, EDS_FUSED_LAYOUT=tiles|strips, EDS_FUSED_GATHER=quad|lane, EDS_LM6_TEAM / EDS_REF12_TEAM=1|2|4|8|16,
+ * EDS_TEAM_WIDE=0|1, EDS_REF12_KERNEL=wide|paired, EDS_STRIPS_PHASES=1|2|4, EDS_STRIPS_POLICY=reuse|eager|never,
+ * EDS_STRIPS_BUDGET_PCT=1..95 (share of the FREE device memory the strip copies may take when they are first allocated; default 50),
+ * EDS_NO_SPIN, EDS_UPLOAD=bands, EDS_FUSED_REPORT, EDS_TEAM_TEST_DROP_MEMBER (test hook).  EDS_FRAME_LAYOUT=rowmajor decides the
+ * allocation and is honoured at create only (EDS_ERR_STATE here).  Unknown name: EDS_ERR_INVALID. */
+int eds_trk_set_knob(eds_trk* h, const char* name, const char* value);
+/* The strip copies of the frames (csrc/eds_layout.hpp): bytes allocated (0: none yet), their row phases, and whether they were refused
+ * because they did not fit the budget (the solves then sample the tiles; setting an EDS_STRIPS_* knob re-arms the allocation). */
+int eds_trk_get_strips_info(eds_trk* h, int64_t* bytes, int32_t* row_phases, int32_t* unavailable);
 
 typedef struct eds_trk_launch_info {
     char    kernel[96];             /* e.g. "eds_fused6_kernel<0, 4, 512, 3, 1>": name and template arguments as rocprofv3 prints them */

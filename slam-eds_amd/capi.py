@@ -41,6 +41,7 @@ EXPORTS = (
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_last_launch", "eds_trk_prepare_frames",
+    "eds_trk_set_knob", "eds_trk_get_strips_info",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
     "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
@@ -211,6 +212,8 @@ def lib():
         L.eds_pyr_set_event_frame_slot.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_pyr_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Info)]
         L.eds_trk_last_launch.argtypes = [C.c_void_p, C.POINTER(LaunchInfo)]
+        L.eds_trk_set_knob.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        L.eds_trk_get_strips_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), _ip, _ip]
         L.eds_pyr_get_residuals.argtypes = [C.c_void_p, C.c_int, _dp]
         if L.eds_trk_cfg_size() != C.sizeof(Cfg) or L.eds_trk_info_size() != C.sizeof(Info):
             raise EdsError(ERR_INVALID, "ctypes struct layout disagrees with include/eds_hip.h")
@@ -578,6 +581,16 @@ class Handle:
         ms = C.c_float(0.0)
         _check(lib().eds_trk_prepare_frames(self._h, int(first), int(count), int(bool(force)), C.byref(ms)))
         return ms.value
+
+    def set_knob(self, name: str, value=None) -> None:
+        """One tuning knob of THIS handle (``eds_trk_set_knob``): same names and values as the environment variables the handle read at
+        creation; ``None`` / ``""`` restores the default."""
+        _check(lib().eds_trk_set_knob(self._h, name.encode(), None if value is None else str(value).encode()))
+
+    def strips_info(self) -> dict:
+        b, ph, un = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        _check(lib().eds_trk_get_strips_info(self._h, C.byref(b), C.byref(ph), C.byref(un)))
+        return dict(bytes=int(b.value), row_phases=int(ph.value), unavailable=bool(un.value))
 
     def last_launch(self) -> dict:
         li = LaunchInfo()

@@ -115,10 +115,9 @@ static EdsArrays arrays_for_pass(eds_trk* h, int first, int count) {
     EdsArrays A = h->arrays();
     bool ok = false;
     if (h->tiled && h->cfg.sampling == EDS_SAMPLE_BICUBIC && h->H < 8000) {
-        const char* ev = getenv("EDS_FUSED_LAYOUT");
         // (a stand-alone pass never has the copies MADE: they cost ~60 passes' worth of what a pass gains from them — it uses the
         // ones a solve or eds_trk_prepare_frames left behind)
-        if (!(ev && std::strcmp(ev, "tiles") == 0)) ok = eds_strips_current(h, first, count);
+        if (!h->knobs.layout_tiles) ok = eds_strips_current(h, first, count);
     }
     A.strips = ok ? h->dstrips : nullptr;
     A.strip_phases = h->strip_phases;
@@ -417,7 +416,7 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
     { int rc_ = unshare_frames(h, slot, 1); if (rc_) return rc_; }     // a frame of its own again
     float* stage = h->h_fstage;
     if (h->stage_busy) { EDS_HIP_TRY(hipEventSynchronize(h->ev_stage)); h->stage_busy = false; }   // the previous frame's reads (long done)
-    static const bool banded = [] { const char* ev = getenv("EDS_UPLOAD"); return ev && std::strcmp(ev, "bands") == 0; }();     // A/B knob: one launch per band (round 2)
+    const bool banded = h->knobs.upload_bands != 0;     // A/B knob: one launch per band (round 2)
     if (h->d_fprog && !banded && h->H < (1 << 20)) {
         // ONE launch (round 3): k_store_follow's workgroups wait for the rows they move; the host publishes its progress after every
         // band in a pinned word (release store behind the band's plain stores: x86 keeps them in order for the device's reads).
@@ -507,7 +506,8 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->B = batch; h->Nmax = max_points_; h->H = H; h->W = W; h->dev = cfg->device;
     h->Hp = eds_frame_extent(H); h->Wp = eds_frame_extent(W);
     h->tiled = 1;
-    if (const char* e = getenv("EDS_FRAME_LAYOUT")) h->tiled = (std::strcmp(e, "rowmajor") != 0);   // tuning knob
+    eds_knobs_from_env(&h->knobs);       // the ONLY place the library reads tuning variables from the environment (eds_launch_rule.hpp)
+    h->tiled = h->knobs.frame_rowmajor ? 0 : 1;
     h->Np = ((max_points_ + EDS_POINT_ALIGN - 1) / EDS_POINT_ALIGN) * EDS_POINT_ALIGN;
     h->max_seg = h->Np / EDS_TPB + 2 * EDS_MAX_BLOCKS + 2;
     h->slots.resize(batch);
@@ -1016,7 +1016,7 @@ int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count) { return
 // it blocks.  Batches block right away: nobody should burn a core for milliseconds.
 #define EDS_SPIN_US 500.0
 static hipError_t wait_stream(eds_trk* h) {
-    const bool spin = h->cfg.exec == EDS_EXEC_DEVICE && h->fused.pending_count > 0 && h->fused.pending_count <= 64 && !getenv("EDS_NO_SPIN");
+    const bool spin = h->cfg.exec == EDS_EXEC_DEVICE && h->fused.pending_count > 0 && h->fused.pending_count <= 64 && !h->knobs.no_spin;
     if (spin) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
@@ -1150,6 +1150,22 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
         EDS_HIP_TRY(hipEventSynchronize(h->ev1));
         EDS_HIP_TRY(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     }
+    return EDS_OK;
+}
+
+int eds_trk_set_knob(eds_trk* h, const char* name, const char* value) {
+    if (!h || !name) return fail(EDS_ERR_INVALID, "null argument");
+    if (std::strcmp(name, "EDS_FRAME_LAYOUT") == 0) return fail(EDS_ERR_STATE, "EDS_FRAME_LAYOUT decides the allocation: environment at eds_trk_create only");
+    if (eds_knobs_set(&h->knobs, name, value) != 0) return fail(EDS_ERR_INVALID, std::string("unknown knob ") + name);
+    if (std::strncmp(name, "EDS_STRIPS_", 11) == 0) h->strips_unavailable = false;       // a new budget / phase count: ask again
+    return EDS_OK;
+}
+
+int eds_trk_get_strips_info(eds_trk* h, int64_t* bytes, int32_t* row_phases, int32_t* unavailable) {
+    if (!h) return fail(EDS_ERR_INVALID, "null handle");
+    if (bytes) *bytes = (int64_t)h->strips_bytes;
+    if (row_phases) *row_phases = h->dstrips ? h->strip_phases : 0;
+    if (unavailable) *unavailable = h->strips_unavailable ? 1 : 0;
     return EDS_OK;
 }
 

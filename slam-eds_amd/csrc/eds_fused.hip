@@ -28,6 +28,7 @@
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
 #include "eds_handle.hpp"
+#include "eds_launch_rule.hpp"
 #include "eds_math.hpp"
 #include "eds_solver.hpp"
 #include "eds_solver6_spec.hpp"
@@ -885,12 +886,12 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // the persistent kernels are compiled for the tiled frame only; the row-major layout exists for the layout comparison of
     // the streaming kernels (EDS_FRAME_LAYOUT=rowmajor, tools/bench_layout.py) and is solved by the host-driven loop
     if (!h->tiled) return eds_internal_solve_host(h, level, first, count);
+    const EdsKnobs& kn = h->knobs;                  // resolved at eds_trk_create / eds_trk_set_knob: no environment access on the solve path
     if (h->cfg.solver == EDS_SOLVER_REF12) {
         // The persistent REF12 kernels beat the host-driven loop at every batch size (one 2 000-point solve: 0.29 ms vs
         // 0.42 ms; B = 1024: 8.3 M vs 0.37 M LM iterations/s).  The host loop remains for what they do not cover
         // (more than 8 residual blocks).
-        const char* force = getenv("EDS_REF12_EXEC");                // tuning knob: "device" | "host"
-        const bool want_device = force ? (std::strcmp(force, "device") == 0) : true;
+        const bool want_device = kn.ref12_exec != 0;
         if (want_device && eds_fused12_supported(h, first, count)) return eds_fused12_solve(h, level, first, count);
         return eds_internal_solve_host(h, level, first, count);     // also: > 8 residual blocks
     }
@@ -910,182 +911,78 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     }
     hipError_t e = hipSuccess;
     EdsArrays A = h->arrays();
-    // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots;
-    // the points-per-lane variant is picked from the largest N of the range
-    // 8 wavefronts x 4 points per lane measured 12% faster than 16 x 2 at N = 2000 (fewer wavefronts to
-    // reduce across, all four gathers of a lane in flight at once, 256-VGPR budget)
-    int threads = maxN <= 2048 ? 512 : 1024;
-    if (const char* ev = getenv("EDS_FUSED_THREADS")) {              // tuning knob (multiple of 64, <= 1024)
-        const int v = atoi(ev);
-        if (v >= 64 && v <= 1024 && v % 64 == 0) threads = v;
-    }
-    while (threads > 64 && threads / 2 >= maxN) threads /= 2;
-    int ppt = (maxN + threads - 1) / threads;
-    ppt = ppt <= 1 ? 1 : (ppt <= 2 ? 2 : (ppt <= 4 ? 4 : 0));
-    if (const char* ev = getenv("EDS_FUSED_PPT")) ppt = atoi(ev) > 0 && atoi(ev) * threads >= maxN ? atoi(ev) : 0;   // tuning knob
     const double tau = h->cfg.huber_tau > 0 ? h->cfg.huber_tau : 0.0;
-    int damped = h->cfg.solver == EDS_SOLVER_LM6;
-    if (damped) { const char* ev = getenv("EDS_LM6_SPEC"); if (ev && ev[0] == '0') damped = 2; }   // tuning knob: prepared candidates off
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(fb.d_sv);
-    // Streaming variants (eds_stream6.hip: constants re-read per pass, any N).
-    //  * N <= 2 048: "paired" — two 256-thread workgroups per CU, reduction / solver overlapped with the other's points —
-    //    round 1's choice for large batches; no longer selected (see below), EDS_LM6_KERNEL=paired forces it.
-    //  * N > 2 048, where the resident kernel needs 1 024 threads at 128 registers: "wide" — one 512-thread workgroup
-    //    with the whole patch cache (N = 4 000: 0.21 vs 0.30 ms for one alignment, 4.1 M vs 2.5 M it/s at 256; N = 8 000:
-    //    2.1 M vs 1.7 M at 256); only a handful of very large alignments is still faster with 1 024 threads.
-    // (round 2: with the quad-cooperative gather and the prepared candidates the register-resident kernel — one alignment per CU,
-    // 256 frames in flight, whole patch cache — beats the paired streaming shape at every batch size: 13.2 M vs 10.5 M it/s at 4 096)
-    bool stream = maxN <= 2048 ? false : !(maxN > 4096 && count < 16);
-    bool wide = maxN > 2048;
-    if (const char* ev = getenv("EDS_LM6_KERNEL")) {                 // tuning knob: "resident" | "paired" | "wide"
-        stream = std::strcmp(ev, "paired") == 0 || std::strcmp(ev, "wide") == 0 || std::strcmp(ev, "stream") == 0;
-        wide = std::strcmp(ev, "wide") == 0;
-    }
-#define EDS_NOTE_LAUNCH(S, P, T, Q, K, WG) do { std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d>", S, P, T, Q, K); \
-        fb.last_workgroups = (WG); fb.last_team = (K); fb.last_layout = (Q) >= 3 ? 2 : 1; } while (0)
-#define EDS_LAUNCH_FUSED(S, P, T, Q) do {                                                                                         \
-    EDS_NOTE_LAUNCH(S, P, T, Q, 1, count);                                                                                        \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, T, Q, 1>), dim3(count), dim3(threads), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, (unsigned long long*)nullptr, (int*)nullptr, 0u, 0u); } while (0)
-#define EDS_LAUNCH_BILINEAR(P, K) do {                                                                                             \
-        EDS_NOTE_LAUNCH(1, P, (K) > 1 ? 512 : threads, 0, K, count * (K) - ((K) > 1 ? drop : 0));                                 \
-        const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, first, count, (K) > 1 ? 512 : threads, iters, damped, h->cfg.lambda0, tau, nb, \
-                                (K) > 1 ? fb.d_mail : nullptr, (K) > 1 ? fb.d_ticket : nullptr, (K) > 1 ? ticket_base : 0u,         \
-                                (K) > 1 ? fb.epoch : 0u, (K) > 1 ? drop : 0, h->st};                                                                   \
-        eds_fused6_launch_bilinear(L, P, K); } while (0)
-#define EDS_LAUNCH_TEAM(S, P, Q, K) do {                                                                                           \
-    EDS_NOTE_LAUNCH(S, P, 512, Q, K, count * K - drop);                                                                            \
-    hipLaunchKernelGGL((eds_fused6_kernel<S, P, 512, Q, K>), dim3(count * K - drop), dim3(512), 0, h->st, A, fb.d_in, fb.d_out, svp, first, \
-                       iters, damped, h->cfg.lambda0, tau, nb, fb.d_mail, fb.d_ticket, ticket_base, fb.epoch); } while (0)
-    // Teams: K CUs per alignment when the launch would leave most of the chip idle (the latency regime).  Prepared-candidate LM6
-    // solves with register-resident points only.  Up to 2 048 points: 4 CUs (512 points each) up to 64 alignments, 2 CUs up to 128.
-    // Beyond (the finer pyramid levels, configs[2..3]): 1 024 points per CU — 4, 8 or 16 CUs — instead of one CU streaming them all
-    // (16 000 points: 0.52 ms on one CU).
-    int team = 1;
-    bool want_strips = true;
-    if (const char* ev = getenv("EDS_FUSED_LAYOUT")) want_strips = std::strcmp(ev, "tiles") != 0;          // tuning knob: "strips" | "tiles"
+    // WHICH kernel: eds_launch_rule.hpp (pure; table-tested on the CPU).  Its two questions with side effects are asked here: the
+    // time-out policy of the teams (a cool-down is counted down when asked) and the strip copies (converted when a solve wants them).
+    const EdsLm6In rin{maxN, count, h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 1 : 0, iters, h->cfg.solver == EDS_SOLVER_LM6 ? 1 : 0, tau > 0 ? 1 : 0,
+                       h->H, fb.pending_retry ? 1 : 0};
+    EdsLm6Plan pl;
+    eds_lm6_plan_begin(kn, rin, pl);
+    const bool team_ok = pl.wants_team && eds_team_allowed(&fb);
+    fb.pending_paused = pl.wants_team && !team_ok && !fb.pending_retry;
+    eds_lm6_plan_team(kn, rin, team_ok ? 1 : 0, fb.team_cooldown > 0 ? 1 : 0, pl);
+    fb.pending_ticks = count <= 64 && !(pl.team <= 1 && pl.stream);   // the latency regime: time stamps from inside the kernel instead of event packets
+    if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);             // (a conversion of frames to strips that this solve asks for is inside the measured span)
+    const bool strips = pl.strips_eligible && eds_strips_for_solve(h, first, count);
+    eds_lm6_plan_finish(kn, rin, strips ? 1 : 0, pl);
+    A.strips = h->dstrips; A.strip_phases = h->strip_phases;
+    const int team = pl.kind == EDS_K6_TEAM ? pl.K : 1, damped = pl.damped, threads = pl.threads;
     // test hook for the time-out path: a team launch goes out one workgroup short, so its last team never completes, reports a time-out
     // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
-    const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;
-    unsigned ticket_base = 0;          // (team launches shadow it with their own stretch of tickets)
-    // (513 .. 1 024 points: a member's slice is PPT x 512 = 1 024 points, a team of two would leave its second member without a
-    // point — one CU per alignment there, as in round 1)
-    const bool team_eligible = damped == 1 && iters > 0 && maxN > 1024 && !fb.pending_retry;
-    const bool wants_team = team_eligible && (maxN > 2048 ? maxN <= 1024 * EDS_TEAM6_MAX : count <= EDS_TEAM_SLOTS);
-    const bool team_ok = wants_team && eds_team_allowed(&fb);
-    fb.pending_paused = wants_team && !team_ok && !fb.pending_retry;
-    if (team_ok && maxN <= 2048) {
-        if (count <= 64) team = 4;
-        else if (count <= EDS_TEAM_SLOTS) team = 2;
-    } else if (team_ok && maxN <= 1024 * EDS_TEAM6_MAX) {
-        // at ANY batch size: the alternative is the streaming kernel (lane-per-patch gather, constants re-read, a quarter of the
-        // points cached) — 8 000 points: 2.8 vs 2.0 M iterations/s at 256 alignments, 2.6 vs 1.1 M at 64
-        team = maxN <= 4096 ? 4 : (maxN <= 8192 ? 8 : 16);
-    }
-    if (const char* ev = getenv("EDS_LM6_TEAM")) {                    // tuning knob: 1 | 2 | 4 | 8 | 16
-        const int v = atoi(ev);
-        const bool feasible = damped == 1 && iters > 0 && (v == 2 || v == 4 || v == 8 || v == 16) && maxN <= (v == 2 ? 2048 : 1024 * v) &&
-                              !fb.pending_retry && fb.team_cooldown <= 0;          // the override does not reach past the time-out policy
-        if (v == 1 || feasible) team = v;
-    }
-    if (team > 1) { stream = false; wide = false; }
+    const int drop = kn.team_drop ? 1 : 0;
     // team launches (the latency regime) write the kept residuals into the pinned mirror themselves: one launch less behind the solve
     const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
     A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     fb.pending_team = team; fb.pending_level = level;
-    fb.pending_ticks = count <= 64 && !stream;       // the latency regime: time stamps from inside the kernel instead of event packets
-    if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
-    if (team > 1) {
-        const bool bic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-        const bool qany = count * team >= 128 && h->H < 8000;       // enough gathers in flight for the quad-cooperative form to pay
-        const bool q = bic && qany;                                 // (on tiles: the bicubic sampler only)
-        // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (even PPT only: the teams of 1 024 points per member);
-        // either sampler
-        const bool strips = qany && !(team == 4 && maxN <= 2048) && want_strips && eds_strips_for_solve(h, first, count);
-        A.strips = h->dstrips; A.strip_phases = h->strip_phases;
-        // Members of 2 048 points (4 per lane) instead of 1 024 once the members of 1 024 are more than one workgroup per CU: half the
-        // members, half the exchanges and solver runs per point.  Measured (tools/bench_large_n.py, 1280x720): 8 000 points x 256
-        // alignments 3.56 -> 4.73 M it/s, 16 000 x 256 1.87 -> 2.65 M, 4 000 x 256 6.4 -> 8.7 M; at exactly 256 members of 1 024 (64 x 4 000,
-        // 32 x 8 000, 16 x 16 000) the narrow form is 15-20 % faster, below it by more.  Knob: EDS_TEAM_WIDE=0|1.
-        const bool wide_ok = (q || (!bic && strips)) && maxN > 2048;       // bicubic on either layout, the bilinear sampler on the strips
-        bool wide_members = wide_ok && count * team > 256;
-        if (const char* ev = getenv("EDS_TEAM_WIDE")) wide_members = wide_ok && atoi(ev) != 0;
-        if (wide_members) { team = team / 2; fb.pending_team = team; }
+    if (pl.kind != EDS_K6_STREAM && !eds_fused6_instance_exists(pl.S, pl.P, pl.T, pl.Q, pl.K, pl.bilinear_tu))
+        return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
+    // one launch of the chosen instantiation over `cnt` alignments from slot `f0` (teams: cnt * K - drop workgroups of 512 threads)
+    auto launch = [&](int f0, int cnt, unsigned ticket_base) {
+        const int K = pl.K, wg = cnt * K - (K > 1 ? drop : 0), block = K > 1 ? 512 : threads;
+        std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d>", pl.S, pl.P, pl.note_T, pl.Q, K);
+        fb.last_workgroups = wg; fb.last_team = K; fb.last_layout = pl.Q >= 3 ? 2 : 1;
+        if (pl.bilinear_tu) {
+            const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, f0, cnt, block, iters, damped, h->cfg.lambda0, tau, nb,
+                                    K > 1 ? fb.d_mail : nullptr, K > 1 ? fb.d_ticket : nullptr, K > 1 ? ticket_base : 0u, K > 1 ? fb.epoch : 0u,
+                                    K > 1 ? drop : 0, h->st};
+            eds_fused6_launch_bilinear(L, pl.P, K);
+            return;
+        }
+        unsigned long long* mail = K > 1 ? fb.d_mail : nullptr;
+        int* ticket = K > 1 ? fb.d_ticket : nullptr;
+        const unsigned tb = K > 1 ? ticket_base : 0u, ep = K > 1 ? fb.epoch : 0u;
+#define EDS_INST_LAUNCH_(S_, P_, T_, Q_, K_)                                                                                          \
+        if (pl.S == S_ && pl.P == P_ && pl.T == T_ && pl.Q == Q_ && K == K_) {                                                       \
+            hipLaunchKernelGGL((eds_fused6_kernel<S_, P_, T_, Q_, K_>), dim3(wg), dim3(block), 0, h->st, A, fb.d_in, fb.d_out, svp, f0, \
+                               iters, damped, h->cfg.lambda0, tau, nb, mail, ticket, tb, ep);                                        \
+            return;                                                                                                                   \
+        }
+        EDS_FUSED6_MAIN_INSTANCES(EDS_INST_LAUNCH_)
+#undef EDS_INST_LAUNCH_
+    };
+    if (pl.kind == EDS_K6_TEAM) {
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
-        const int per_launch = EDS_TEAM_MEMBERS / team, whole_first = first, whole_count = count;
-        for (int c0 = 0; c0 < whole_count; c0 += per_launch) {
-        const int first = whole_first + c0, count = std::min(per_launch, whole_count - c0);      // (shadow the range: the launch macro reads these)
-        if (++fb.epoch >= (1u << 24)) {              // tags are (epoch << 8 | pass): start over with clean mailboxes
-            hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
-            fb.epoch = 1;
+        const int per_launch = EDS_TEAM_MEMBERS / team;
+        for (int c0 = 0; c0 < count; c0 += per_launch) {
+            const int f0 = first + c0, cnt = std::min(per_launch, count - c0);
+            if (++fb.epoch >= (1u << 24)) {              // tags are (epoch << 8 | pass): start over with clean mailboxes
+                hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
+                fb.epoch = 1;
+            }
+            const unsigned ticket_base = fb.ticket_base;
+            fb.ticket_base += (unsigned)(cnt * team);
+            for (int s = f0; s < f0 + cnt; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
+            launch(f0, cnt, ticket_base);
         }
-        const unsigned ticket_base = fb.ticket_base;
-        fb.ticket_base += (unsigned)(count * team);
-        for (int s = first; s < first + count; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
-        // (QUAD = 2: the pair-packed point phase with the per-point Huber weight compiled in; points in pairs need an even PPT)
-#define EDS_TEAM_Q2(K) do { if (!bic && strips) { if (tau > 0) EDS_LAUNCH_TEAM(1, 2, 4, K); else EDS_LAUNCH_TEAM(1, 2, 3, K); }            \
-                            else if (!bic) EDS_LAUNCH_BILINEAR(2, K); else if (!q) EDS_LAUNCH_TEAM(0, 2, 0, K);                      \
-                            else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 4, K); else EDS_LAUNCH_TEAM(0, 2, 3, K); }                 \
-                            else if (tau > 0) EDS_LAUNCH_TEAM(0, 2, 2, K); else EDS_LAUNCH_TEAM(0, 2, 1, K); } while (0)
-        if (wide_members) {                          // 2 048 points per member, four per lane (bicubic: strips, or tiles on a first solve; bilinear: strips)
-#define EDS_TEAM_Q4(K) do { if (!bic) { if (tau > 0) EDS_LAUNCH_TEAM(1, 4, 4, K); else EDS_LAUNCH_TEAM(1, 4, 3, K); }                      \
-                            else if (strips) { if (tau > 0) EDS_LAUNCH_TEAM(0, 4, 4, K); else EDS_LAUNCH_TEAM(0, 4, 3, K); }                \
-                            else if (tau > 0) EDS_LAUNCH_TEAM(0, 4, 2, K); else EDS_LAUNCH_TEAM(0, 4, 1, K); } while (0)
-            if (team == 2) EDS_TEAM_Q4(2); else if (team == 4) EDS_TEAM_Q4(4); else EDS_TEAM_Q4(8);
-#undef EDS_TEAM_Q4
-        } else if (team == 4 && maxN <= 2048) {      // 512 points per member, one per lane
-            if (bic) { if (q) EDS_LAUNCH_TEAM(0, 1, 1, 4); else EDS_LAUNCH_TEAM(0, 1, 0, 4); } else EDS_LAUNCH_BILINEAR(1, 4);
-        } else if (team == 2) {                      // 1 024 points per member, two per lane
-            EDS_TEAM_Q2(2);
-        } else if (team == 4) {                      // 1 024 points per member from here on
-            EDS_TEAM_Q2(4);
-        } else if (team == 8) {
-            EDS_TEAM_Q2(8);
-        } else {
-            EDS_TEAM_Q2(16);
-        }
-#undef EDS_TEAM_Q2
-        }
-    } else if (stream) {
-        std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_stream6_kernel<%d, %d, %d>", h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 0 : 1, wide ? 512 : 256, wide ? 2048 : 1024);
+    } else if (pl.kind == EDS_K6_STREAM) {
+        std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_stream6_kernel<%d, %d, %d>", pl.S, pl.T, pl.P);
         fb.last_workgroups = count; fb.last_team = 1; fb.last_layout = 1;
-        eds_stream6_launch(A, h->cfg.sampling, wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
+        eds_stream6_launch(A, h->cfg.sampling, pl.wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
     } else {
-    // MAXT = 512 instantiations may use 256 VGPRs (8 wavefronts = 2 per SIMD), which the 4-points-per-
-    // lane variant needs to keep 4 x 16 taps + constants in registers without spilling
-#define EDS_LAUNCH_FUSED_T(S, P, Q) do { if (threads > 512) EDS_LAUNCH_FUSED(S, P, 1024, Q); else EDS_LAUNCH_FUSED(S, P, 512, Q); } while (0)
-    const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-    // the quad-cooperative gather (bicubic, register-resident points) costs ~130 more instructions per point and wins once the
-    // gather, not the instruction stream, bounds the pass: 152 vs 184 us at 64 alignments, 114 vs 102 us for a lone one
-    bool quad = count >= 32;
-    if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = std::strcmp(ev, "lane") != 0;    // tuning knob: "quad" | "lane"
-    quad = quad && ppt > 0 && threads * ppt <= EDS_CACHE_CAP && h->H < 8000;     // every point's patch has a cache line of its own; 13-bit row field (pack_origin)
-    const bool hub = tau > 0;                        // QUAD = 2 / 4: the per-point Huber weight compiled into the pair-packed point phase
-    // QUAD = 3 / 4: the gather on the strip copies of the frames, landing in LDS (eds_layout.hpp) — the default wherever the pair-packed
-    // point phase runs; EDS_FUSED_LAYOUT=tiles keeps the 4x4 tiles (A/B runs, and the fallback when the copies cannot be allocated)
-    // Either sampler: the bilinear one reads the two middle rows / columns of the same 4 x 4 patch (its own kernels everywhere else).
-    const bool strips = quad && (ppt == 2 || ppt == 4) && want_strips && eds_strips_for_solve(h, first, count);
-    A.strips = h->dstrips; A.strip_phases = h->strip_phases;
-    if (strips && bicubic) {
-        if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(0, 2, 4); else EDS_LAUNCH_FUSED_T(0, 2, 3); }
-        else { if (hub) EDS_LAUNCH_FUSED(0, 4, 512, 4); else EDS_LAUNCH_FUSED(0, 4, 512, 3); }
-    } else if (strips) {
-        if (ppt == 2) { if (hub) EDS_LAUNCH_FUSED_T(1, 2, 4); else EDS_LAUNCH_FUSED_T(1, 2, 3); }
-        else { if (hub) EDS_LAUNCH_FUSED(1, 4, 512, 4); else EDS_LAUNCH_FUSED(1, 4, 512, 3); }
-    } else
-    switch (ppt) {
-        case 1: if (bicubic) { if (quad) EDS_LAUNCH_FUSED_T(0, 1, 1); else EDS_LAUNCH_FUSED_T(0, 1, 0); } else EDS_LAUNCH_BILINEAR(1, 1); break;
-        case 2: if (bicubic) { if (quad && hub) EDS_LAUNCH_FUSED_T(0, 2, 2); else if (quad) EDS_LAUNCH_FUSED_T(0, 2, 1); else EDS_LAUNCH_FUSED_T(0, 2, 0); } else EDS_LAUNCH_BILINEAR(2, 1); break;
-        case 4: if (bicubic) { if (quad && hub) EDS_LAUNCH_FUSED(0, 4, 512, 2); else if (quad) EDS_LAUNCH_FUSED(0, 4, 512, 1); else EDS_LAUNCH_FUSED_T(0, 4, 0); } else EDS_LAUNCH_BILINEAR(4, 1); break;
-        default: if (bicubic) EDS_LAUNCH_FUSED_T(0, 0, 0); else EDS_LAUNCH_BILINEAR(0, 1); break;
+        launch(first, count, 0u);
     }
-    }
-#undef EDS_LAUNCH_FUSED_T
-#undef EDS_LAUNCH_FUSED
-#undef EDS_NOTE_LAUNCH
-#undef EDS_LAUNCH_TEAM
-#undef EDS_LAUNCH_BILINEAR
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
     e = hipGetLastError();
@@ -1111,7 +1008,7 @@ int eds_fused_collect(eds_trk* h) {
     } else {
         hipEventElapsedTime(&dev_ms, h->ev0, h->ev1);
     }
-    if (fb.pending_team == 1 && getenv("EDS_FUSED_REPORT")) {     // diagnostic: what the workgroups' own begin / end stamps say about the launch
+    if (fb.pending_team == 1 && h->knobs.report) {     // diagnostic: what the workgroups' own begin / end stamps say about the launch
         std::vector<unsigned long long> te;
         unsigned long long t0 = ~0ull, t1 = 0; double busy = 0.0;
         for (int s = fb.pending_first; s < fb.pending_first + fb.pending_count; ++s) {

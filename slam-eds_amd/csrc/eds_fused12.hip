@@ -34,6 +34,7 @@
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
 #include "eds_handle.hpp"
+#include "eds_launch_rule.hpp"
 #include "eds_math.hpp"
 #include "eds_solver.hpp"
 #include "eds_solver12_coop.hpp"
@@ -562,40 +563,24 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     }
     hipError_t e = hipSuccess;           // (start states and results: pinned host memory the kernel accesses directly, eds_fused_alloc)
     EdsArrays A = h->arrays();
-    // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads,
-    // 96 KB patch cache — the lower latency (0.28 ms for one 2 000-point alignment, 7.0 M LM iterations/s at 256).
-    // Beyond that, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase
-    // overlaps the other's point phase (8.3 M at 1 024, 9.2 M at 4 096 against 6.2 M for the wide shape).
-    bool wide = count <= 256;
-    if (const char* e = getenv("EDS_REF12_KERNEL")) {                 // tuning knob: "wide" | "paired"
-        if (std::strcmp(e, "wide") == 0) wide = true;
-        else if (std::strcmp(e, "paired") == 0) wide = false;
-    }
-    const bool bicubic = h->cfg.sampling == EDS_SAMPLE_BICUBIC;
-    // Teams (eds_fused.hip): K CUs per alignment while the launch leaves most of the chip idle — the plain residual only
+    // WHICH kernel: eds_launch_rule.hpp (pure; table-tested on the CPU) — shape (one or two alignments per CU), team size, gather form.
+    const EdsKnobs& kn = h->knobs;
     int maxN = 0;
     for (int s = first; s < first + count; ++s) maxN = std::max(maxN, h->slots[s].N);
-    int team = 1;
-    const bool wants_team = wide && !h->cfg.nc && maxN > 512 && count <= EDS_TEAM12_SLOTS && !fb.pending_retry;
-    const bool team_ok = wants_team && eds_team_allowed(&fb);         // the time-out policy of eds_fused.hpp
-    fb.pending_paused = wants_team && !team_ok;
-    if (team_ok) {
-        team = (count <= 64 && maxN > 1024) ? 4 : 2;
-        if (count <= 16 && maxN > 1024) team = 8;                                   // a handful of alignments: 8 CUs each (2 000 points: 152 vs 159 us; equal from 32 alignments on)
-        if (maxN > 8192 && count * 16 <= EDS_TEAM12_MEMBERS) team = 16;          // the finer pyramid levels (configs[2..3]): ~1 000 points per CU
-        else if (maxN > 4096 && count * 8 <= EDS_TEAM12_MEMBERS) team = 8;
+    const EdsRef12In rin{maxN, count, h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 1 : 0, h->cfg.nc ? 1 : 0, h->H, fb.pending_retry ? 1 : 0};
+    EdsRef12Plan pl;
+    eds_ref12_plan_begin(kn, rin, pl);
+    const bool team_ok = pl.wants_team && eds_team_allowed(&fb);         // the time-out policy of eds_fused.hpp
+    fb.pending_paused = pl.wants_team && !team_ok;
+    eds_ref12_plan_team(kn, rin, team_ok ? 1 : 0, fb.team_cooldown > 0 ? 1 : 0, pl);
+    if (pl.team > 1 && !fb.d_mail12) {
+        if (hipMalloc((void**)&fb.d_mail12, EDS_TEAM12_MAIL_BYTES) != hipSuccess) {       // no mailboxes: one CU per alignment
+            (void)hipGetLastError();
+            EdsKnobs k1 = kn; k1.ref12_team = 1;
+            eds_ref12_plan_team(k1, rin, 0, 1, pl);
+        } else hipMemsetAsync(fb.d_mail12, 0, EDS_TEAM12_MAIL_BYTES, h->st);
     }
-    if (const char* ev = getenv("EDS_REF12_TEAM")) {                  // tuning knob: 1 | 2 | 4 | 8 | 16
-        const int v = atoi(ev);
-        if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && wide && !h->cfg.nc && count <= EDS_TEAM12_SLOTS && count * v <= EDS_TEAM12_MEMBERS &&
-                       !fb.pending_retry && fb.team_cooldown <= 0)) team = v;
-    }
-    if (team > 1) {
-        if (!fb.d_mail12) {
-            if (hipMalloc((void**)&fb.d_mail12, EDS_TEAM12_MAIL_BYTES) != hipSuccess) team = 1;
-            else hipMemsetAsync(fb.d_mail12, 0, EDS_TEAM12_MAIL_BYTES, h->st);
-        }
-    }
+    const int team = pl.team;
     if (team > 1) {
         if (++fb.epoch >= (1u << 24)) {
             hipMemsetAsync(fb.d_mail, 0, EDS_TEAM_MAIL_BYTES, h->st);
@@ -611,36 +596,27 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         fb.ticket_base += (unsigned)(count * team);
         for (int s = first; s < first + count; ++s) fb.h_out12[s].failed = 2;    // "no result yet" reads as a time-out (eds_fused_solve)
     }
-    const int drop = getenv("EDS_TEAM_TEST_DROP_MEMBER") ? 1 : 0;     // test hook for the time-out path (see eds_fused_solve)
+    const int drop = kn.team_drop ? 1 : 0;            // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
-#define EDS_LAUNCH12_(S, T, C, NCM, K, Q) do {                                                                                        \
-    std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", S, T, C, (NCM) ? "true" : "false", K, Q);   \
-    fb.last_workgroups = count * K - ((K) > 1 ? drop : 0); fb.last_team = (K); fb.last_layout = (Q) == 2 ? 2 : 1;                     \
-    hipLaunchKernelGGL((eds_fused12_kernel<S, T, C, NCM, K, Q>), dim3(count * K - ((K) > 1 ? drop : 0)), dim3(T), 0, h->st, A, fb.d_in, fb.d_out12, first, iters, \
-                       h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance,                \
-                       h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch); } while (0)
-#define EDS_LAUNCH12(S, T, C, Q) do { if (h->cfg.nc) EDS_LAUNCH12_(S, T, C, true, 1, Q); else EDS_LAUNCH12_(S, T, C, false, 1, Q); } while (0)
-    // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase (as in eds_fused.hip)
-    // on the tiles: +6 % at 4 096 alignments, +0.5 % at 1 024, -2 ... -8 % below; on the strips (one load per row, no shift) it wins
-    // from 64 alignments on: 3.61 vs 3.47 M LM iterations/s at 64, 9.97 vs 9.18 at 256, 11.06 vs 9.60 at 1 024, 13.30 vs 10.76 at 4 096
-    bool want_strips = !h->cfg.nc;
-    if (const char* ev = getenv("EDS_FUSED_LAYOUT")) want_strips = want_strips && std::strcmp(ev, "tiles") != 0;
-    bool quad = bicubic && count >= (want_strips ? 64 : 1024);
-    if (const char* ev = getenv("EDS_FUSED_GATHER")) quad = bicubic && std::strcmp(ev, "lane") != 0;     // tuning knob: "quad" | "lane"
-    quad = quad && h->H < 8000;                   // 13-bit row field of the packed origins (pack_origin)
-    // QUAD = 2: the same gather on the strip copies of the frames (EDS_FUSED_LAYOUT=tiles keeps the tiles; so does a failed allocation)
-    const bool strips = quad && want_strips && eds_strips_for_solve(h, first, count);
-    if (want_strips && !strips && count < 1024) quad = false;         // (no room for the copies: the tiles' rule)
+    // the strip copies of the frames: asked for only where an instantiation reads them (teams of up to 4, both one-CU shapes)
+    const bool strips = pl.strips_eligible && eds_strips_for_solve(h, first, count);
+    eds_ref12_plan_finish(kn, rin, strips ? 1 : 0, pl);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
-    if (team == 16) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 16, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 16, 0); }
-    else if (team == 8) { if (bicubic) EDS_LAUNCH12_(0, 512, 1408, false, 8, 0); else EDS_LAUNCH12_(1, 512, 1408, false, 8, 0); }
-    else if (team == 4) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 4, 2); else if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 4, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 4, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 4, 0); }
-    else if (team == 2) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 2, 2); else if (quad) EDS_LAUNCH12_(0, 512, 1408, false, 2, 1); else EDS_LAUNCH12_(0, 512, 1408, false, 2, 0); } else EDS_LAUNCH12_(1, 512, 1408, false, 2, 0); }
-    else if (wide) { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 512, 1408, false, 1, 2); else if (quad) EDS_LAUNCH12(0, 512, 1408, 1); else EDS_LAUNCH12(0, 512, 1408, 0); } else EDS_LAUNCH12(1, 512, 1408, 0); }
-    else { if (bicubic) { if (strips) EDS_LAUNCH12_(0, 256, 320, false, 1, 2); else if (quad) EDS_LAUNCH12(0, 256, 320, 1); else EDS_LAUNCH12(0, 256, 320, 0); } else EDS_LAUNCH12(1, 256, 320, 0); }
-#undef EDS_LAUNCH12
-#undef EDS_LAUNCH12_
+    if (!eds_fused12_instance_exists(pl.S, pl.T, pl.CAP, pl.NC, pl.K, pl.Q))
+        return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
+    std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q);
+    fb.last_workgroups = count * pl.K - (pl.K > 1 ? drop : 0); fb.last_team = pl.K; fb.last_layout = pl.Q == 2 ? 2 : 1;
+    bool launched = false;
+#define EDS_INST_LAUNCH12_(S_, T_, C_, N_, K_, Q_)                                                                                    \
+    if (!launched && pl.S == S_ && pl.T == T_ && pl.CAP == C_ && (pl.NC != 0) == N_ && pl.K == K_ && pl.Q == Q_) {                   \
+        launched = true;                                                                                                              \
+        hipLaunchKernelGGL((eds_fused12_kernel<S_, T_, C_, N_, K_, Q_>), dim3(count * K_ - ((K_) > 1 ? drop : 0)), dim3(T_), 0, h->st, A, fb.d_in, \
+                           fb.d_out12, first, iters, h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance, \
+                           h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch);                         \
+    }
+    EDS_FUSED12_INSTANCES(EDS_INST_LAUNCH12_)
+#undef EDS_INST_LAUNCH12_
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
     e = hipGetLastError();

@@ -7,6 +7,10 @@
 #include "../../include/eds_hip.h"
 #include "eds_fused.hpp"
 #include "eds_kernels.hpp"
+#include "eds_launch_rule.hpp"
+
+static_assert(EDS_RULE_TEAM6_MAX == EDS_TEAM6_MAX && EDS_RULE_TEAM_SLOTS == EDS_TEAM_SLOTS && EDS_RULE_TEAM12_SLOTS == EDS_TEAM12_SLOTS &&
+              EDS_RULE_TEAM12_MEMBERS == EDS_TEAM12_MEMBERS, "eds_launch_rule.hpp repeats these constants of eds_fused.hpp");
 
 // Host-side state of one alignment slot: what the reference keeps in Tracker members
 // px,qx,vx,info (Tracker.hpp:46-52) and in kf->residuals (KeyFrame.hpp:88).
@@ -34,6 +38,9 @@ struct Slot {
 
 struct eds_trk {
     eds_trk_cfg cfg;
+    EdsKnobs knobs;                     // tuning knobs (eds_launch_rule.hpp): the environment as it was at eds_trk_create, then eds_trk_set_knob
+    bool strips_unavailable = false;    // the strip copies did not fit the memory budget: remembered, not retried on every solve
+    size_t strips_bytes = 0;            // what they take (eds_trk_strips_bytes)
     int B = 0, Nmax = 0, Np = 0, H = 0, W = 0, max_seg = 0, dev = 0;
     int Hp = 0, Wp = 0, tiled = 1;      // frame allocation (eds_device.hpp FrameView)
     hipStream_t st = nullptr;

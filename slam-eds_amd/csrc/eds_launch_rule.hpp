@@ -1,0 +1,343 @@
+// Which kernel does a solve launch?  The rule, as PURE functions of the handle's tuning knobs and of the shape of the range —
+// no HIP, no handle, no environment access on the solve path — so that tests/host_logic can table-test it on the CPU
+// (tests/test_host_logic.py::test_launch_rule_*), and so that two handles with different knobs coexist in one process.
+//
+// Knobs (EdsKnobs): every former per-solve getenv() of eds_fused.hip / eds_fused12.hip / eds_strips.hip / eds_capi.hip.  They are
+// resolved ONCE, at eds_trk_create (eds_knobs_from_env), live in the handle, and can be changed per handle with eds_trk_set_knob
+// (include/eds_hip.h) — same names, same values as the environment variables.  Defaults are the measured best; the knobs exist for
+// A/B runs and tests.
+//
+// The pose-only rule runs in three steps because two of its inputs have side effects the launcher owns: the time-out policy of the
+// teams counts a cool-down down when it is asked (eds_team_allowed), and the strip copies of the frames are converted when a solve
+// asks for them (eds_strips_for_solve).  So:   begin (shape, does it want teams?)  ->  team (given the policy's answer: team size,
+// would it gather from strips?)  ->  finish (given the copies' answer: the template arguments).
+#pragma once
+#include <stdlib.h>
+#include <string.h>
+
+#define EDS_RULE_TEAM6_MAX 16          // = EDS_TEAM6_MAX (eds_fused.hpp; static_assert there)
+#define EDS_RULE_TEAM_SLOTS 128        // = EDS_TEAM_SLOTS
+#define EDS_RULE_TEAM12_SLOTS 64       // = EDS_TEAM12_SLOTS
+#define EDS_RULE_TEAM12_MEMBERS 512    // = EDS_TEAM12_MEMBERS
+#define EDS_RULE_CACHE_CAP 2048        // = EDS_CACHE_CAP (eds_fused.hip)
+
+struct EdsKnobs {
+    int ref12_exec = -1;        // EDS_REF12_EXEC      device | host            -1: the rule (device wherever the kernel covers the problem)
+    int fused_threads = 0;      // EDS_FUSED_THREADS   64 .. 1024, multiple of 64   0: the rule
+    int fused_ppt_set = 0;      // EDS_FUSED_PPT       points per lane; set but infeasible -> 0 (constants re-read per pass)
+    int fused_ppt = 0;
+    int lm6_spec = 1;           // EDS_LM6_SPEC        0: the serial solver lane of round 1
+    int lm6_kernel = 0;         // EDS_LM6_KERNEL      0: the rule, 1 resident (or any other word), 2 paired / stream, 3 wide
+    int layout_tiles = 0;       // EDS_FUSED_LAYOUT    tiles: never gather from the strip copies
+    int team_drop = 0;          // EDS_TEAM_TEST_DROP_MEMBER   test hook: a team launch goes out one workgroup short
+    int lm6_team = 0;           // EDS_LM6_TEAM        1 | 2 | 4 | 8 | 16          0: the rule
+    int team_wide = -1;         // EDS_TEAM_WIDE       0 | 1                      -1: the rule
+    int gather = 0;             // EDS_FUSED_GATHER    0: the rule, 1 quad (any word but "lane"), 2 lane
+    int report = 0;             // EDS_FUSED_REPORT    per-launch digest of the workgroups' stamps on stderr
+    int ref12_kernel = 0;       // EDS_REF12_KERNEL    0: the rule, 1 wide, 2 paired
+    int ref12_team = 0;         // EDS_REF12_TEAM      1 | 2 | 4 | 8 | 16          0: the rule
+    int strips_phases = 0;      // EDS_STRIPS_PHASES   1 | 2 | 4                   0: the rule (4 for batch handles, 1 below 32 slots)
+    int strips_policy = 0;      // EDS_STRIPS_POLICY   0 reuse, 1 eager, 2 never
+    int strips_budget_pct = 50; // EDS_STRIPS_BUDGET_PCT  the strip copies may take at most this share of the device memory that is FREE when
+                                //                     they are first allocated (1 .. 95); fewer row phases, or none, beyond it
+    int no_spin = 0;            // EDS_NO_SPIN         block in the stream wait from the start
+    int upload_bands = 0;       // EDS_UPLOAD=bands    one launch per band of a host frame (round 2's upload)
+    int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
+};
+
+// returns 0, or -1 for a name that is not a knob.  value == nullptr or "" resets the knob to its default.
+static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value) {
+    const EdsKnobs d;
+    const bool unset = !value || !value[0];
+    const int iv = unset ? 0 : atoi(value);
+    auto is = [&](const char* w) { return !unset && strcmp(value, w) == 0; };
+    if (!strcmp(name, "EDS_REF12_EXEC")) k->ref12_exec = unset ? d.ref12_exec : (is("device") ? 1 : 0);
+    else if (!strcmp(name, "EDS_FUSED_THREADS")) k->fused_threads = unset ? 0 : iv;
+    else if (!strcmp(name, "EDS_FUSED_PPT")) { k->fused_ppt_set = unset ? 0 : 1; k->fused_ppt = iv; }
+    else if (!strcmp(name, "EDS_LM6_SPEC")) k->lm6_spec = unset ? 1 : (value[0] == '0' ? 0 : 1);
+    else if (!strcmp(name, "EDS_LM6_KERNEL")) k->lm6_kernel = unset ? 0 : (is("wide") ? 3 : ((is("paired") || is("stream")) ? 2 : 1));
+    else if (!strcmp(name, "EDS_FUSED_LAYOUT")) k->layout_tiles = is("tiles") ? 1 : 0;
+    else if (!strcmp(name, "EDS_TEAM_TEST_DROP_MEMBER")) k->team_drop = unset ? 0 : 1;
+    else if (!strcmp(name, "EDS_LM6_TEAM")) k->lm6_team = unset ? 0 : iv;
+    else if (!strcmp(name, "EDS_TEAM_WIDE")) k->team_wide = unset ? -1 : (iv != 0);
+    else if (!strcmp(name, "EDS_FUSED_GATHER")) k->gather = unset ? 0 : (is("lane") ? 2 : 1);
+    else if (!strcmp(name, "EDS_FUSED_REPORT")) k->report = unset ? 0 : 1;
+    else if (!strcmp(name, "EDS_REF12_KERNEL")) k->ref12_kernel = is("wide") ? 1 : (is("paired") ? 2 : 0);
+    else if (!strcmp(name, "EDS_REF12_TEAM")) k->ref12_team = unset ? 0 : iv;
+    else if (!strcmp(name, "EDS_STRIPS_PHASES")) k->strips_phases = (iv == 1 || iv == 2 || iv == 4) ? iv : 0;
+    else if (!strcmp(name, "EDS_STRIPS_POLICY")) k->strips_policy = is("eager") ? 1 : (is("never") ? 2 : 0);
+    else if (!strcmp(name, "EDS_STRIPS_BUDGET_PCT")) k->strips_budget_pct = (iv >= 1 && iv <= 95) ? iv : d.strips_budget_pct;
+    else if (!strcmp(name, "EDS_NO_SPIN")) k->no_spin = unset ? 0 : 1;
+    else if (!strcmp(name, "EDS_UPLOAD")) k->upload_bands = is("bands") ? 1 : 0;
+    else if (!strcmp(name, "EDS_FRAME_LAYOUT")) k->frame_rowmajor = is("rowmajor") ? 1 : 0;
+    else return -1;
+    return 0;
+}
+
+#define EDS_KNOB_NAMES(X)                                                                                                              \
+    X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
+    X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
+    X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT")
+
+// the process environment, read once per handle (eds_trk_create)
+static inline void eds_knobs_from_env(EdsKnobs* k) {
+#define EDS_KNOB_ENV_(N) if (const char* v_ = getenv(N)) eds_knobs_set(k, N, v_);
+    EDS_KNOB_NAMES(EDS_KNOB_ENV_)
+#undef EDS_KNOB_ENV_
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// pose-only solvers (GN6 / LM6): eds_fused6_kernel<S, P, T, Q, K>, eds_stream6_kernel
+// ---------------------------------------------------------------------------------------------------------------------------------
+enum { EDS_K6_FUSED = 0, EDS_K6_TEAM = 1, EDS_K6_STREAM = 2 };
+
+struct EdsLm6In {
+    int maxN, count;        // most points of a slot in the range, alignments in the range
+    int bicubic;            // cfg.sampling == EDS_SAMPLE_BICUBIC
+    int iters;              // cfg.max_num_iterations[level]
+    int lm6;                // cfg.solver == EDS_SOLVER_LM6 (else GN6)
+    int huber;              // cfg.huber_tau > 0
+    int H;                  // frame height
+    int retry;              // this launch is the one-CU re-run of a timed-out team launch
+};
+
+struct EdsLm6Plan {
+    // begin
+    int threads, ppt, damped, stream, wide;
+    int team_eligible, wants_team;
+    // team
+    int team, q, qany, quad, strips_eligible;
+    // finish: the launch
+    int kind;               // EDS_K6_*
+    int S, P, T, Q, K;      // template arguments of eds_fused6_kernel (kind != STREAM); T is MAXT, the block has `threads` threads
+    int bilinear_tu;        // the instantiation lives in eds_fused_bilinear.o (eds_fused6_launch_bilinear)
+    int wide_members;       // teams with members of 2 048 points
+    int note_T;             // the T eds_trk_last_launch prints (the lane kernel of the bilinear sampler prints the block size)
+};
+
+static inline void eds_lm6_plan_begin(const EdsKnobs& kn, const EdsLm6In& in, EdsLm6Plan& p) {
+    memset(&p, 0, sizeof(p));
+    // geometry: one alignment owns a CU's LDS (patch cache), so it also gets all 16 wave slots; the points-per-lane variant is picked
+    // from the largest N of the range.  8 wavefronts x 4 points per lane measured 12 % faster than 16 x 2 at N = 2 000
+    int threads = in.maxN <= 2048 ? 512 : 1024;
+    if (kn.fused_threads >= 64 && kn.fused_threads <= 1024 && kn.fused_threads % 64 == 0) threads = kn.fused_threads;
+    while (threads > 64 && threads / 2 >= in.maxN) threads /= 2;
+    int ppt = (in.maxN + threads - 1) / threads;
+    ppt = ppt <= 1 ? 1 : (ppt <= 2 ? 2 : (ppt <= 4 ? 4 : 0));
+    if (kn.fused_ppt_set) ppt = (kn.fused_ppt > 0 && kn.fused_ppt * threads >= in.maxN) ? kn.fused_ppt : 0;
+    int damped = in.lm6 ? 1 : 0;
+    if (damped && !kn.lm6_spec) damped = 2;
+    // Streaming variants (eds_stream6.hip: constants re-read per pass, any N): beyond 2 048 points, unless a handful of very large
+    // alignments (the 1 024-thread resident kernel is faster there); teams replace them wherever prepared-candidate LM6 runs
+    bool stream = in.maxN <= 2048 ? false : !(in.maxN > 4096 && in.count < 16);
+    bool wide = in.maxN > 2048;
+    if (kn.lm6_kernel) { stream = kn.lm6_kernel >= 2; wide = kn.lm6_kernel == 3; }
+    p.threads = threads; p.ppt = ppt; p.damped = damped; p.stream = stream; p.wide = wide;
+    // (513 .. 1 024 points: a member's slice is PPT x 512 = 1 024 points, a team of two would leave its second member without a point)
+    p.team_eligible = damped == 1 && in.iters > 0 && in.maxN > 1024 && !in.retry;
+    p.wants_team = p.team_eligible && (in.maxN > 2048 ? in.maxN <= 1024 * EDS_RULE_TEAM6_MAX : in.count <= EDS_RULE_TEAM_SLOTS);
+}
+
+// team_ok: wants_team and the handle's time-out policy allows teams now; cooldown_active: a cool-down is running (after the policy was asked)
+static inline void eds_lm6_plan_team(const EdsKnobs& kn, const EdsLm6In& in, int team_ok, int cooldown_active, EdsLm6Plan& p) {
+    int team = 1;
+    if (team_ok && in.maxN <= 2048) {
+        if (in.count <= 64) team = 4;
+        else if (in.count <= EDS_RULE_TEAM_SLOTS) team = 2;
+    } else if (team_ok && in.maxN <= 1024 * EDS_RULE_TEAM6_MAX) {
+        team = in.maxN <= 4096 ? 4 : (in.maxN <= 8192 ? 8 : 16);      // 1 024 points per CU, at ANY batch size (the alternative streams)
+    }
+    if (kn.lm6_team) {
+        const int v = kn.lm6_team;
+        const bool feasible = p.damped == 1 && in.iters > 0 && (v == 2 || v == 4 || v == 8 || v == 16) && in.maxN <= (v == 2 ? 2048 : 1024 * v) &&
+                              !in.retry && !cooldown_active;          // the override does not reach past the time-out policy
+        if (v == 1 || feasible) team = v;
+    }
+    if (team > 1) { p.stream = 0; p.wide = 0; }
+    p.team = team;
+    const bool want_strips = !kn.layout_tiles;
+    if (team > 1) {
+        p.qany = in.count * team >= 128 && in.H < 8000;              // enough gathers in flight for the quad-cooperative form to pay
+        p.q = in.bicubic && p.qany;                                  // (on tiles: the bicubic sampler only)
+        p.strips_eligible = p.qany && !(team == 4 && in.maxN <= 2048) && want_strips;
+    } else if (!p.stream) {
+        bool quad = in.count >= 32;
+        if (kn.gather) quad = kn.gather == 1;
+        quad = quad && p.ppt > 0 && p.threads * p.ppt <= EDS_RULE_CACHE_CAP && in.H < 8000;     // every point's patch has a cache line of its own; 13-bit row field
+        p.quad = quad;
+        p.strips_eligible = quad && (p.ppt == 2 || p.ppt == 4) && want_strips;
+    }
+}
+
+// strips: the copies of the range are current (asked only when strips_eligible)
+static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, int strips, EdsLm6Plan& p) {
+    strips = strips && p.strips_eligible;
+    const int bic = in.bicubic, hub = in.huber;
+    p.bilinear_tu = 0; p.wide_members = 0;
+    if (p.team > 1) {
+        p.kind = EDS_K6_TEAM; p.T = 512;
+        // Members of 2 048 points (4 per lane) once the members of 1 024 are more than one workgroup per CU
+        const bool wide_ok = (p.q || (!bic && strips)) && in.maxN > 2048;
+        bool wide_members = wide_ok && in.count * p.team > 256;
+        if (kn.team_wide >= 0) wide_members = wide_ok && kn.team_wide != 0;
+        if (wide_members) { p.team /= 2; p.wide_members = 1; }
+        p.K = p.team;
+        if (wide_members) {
+            p.P = 4; p.S = bic ? 0 : 1;
+            if (!bic || strips) p.Q = hub ? 4 : 3; else p.Q = hub ? 2 : 1;
+        } else if (p.team == 4 && in.maxN <= 2048) {                 // 512 points per member, one per lane
+            p.P = 1;
+            if (bic) { p.S = 0; p.Q = p.q ? 1 : 0; } else { p.S = 1; p.Q = 0; p.bilinear_tu = 1; }
+        } else {                                                     // 1 024 points per member, two per lane
+            p.P = 2;
+            if (!bic && strips) { p.S = 1; p.Q = hub ? 4 : 3; }
+            else if (!bic) { p.S = 1; p.Q = 0; p.bilinear_tu = 1; }
+            else if (!p.q) { p.S = 0; p.Q = 0; }
+            else if (strips) { p.S = 0; p.Q = hub ? 4 : 3; }
+            else { p.S = 0; p.Q = hub ? 2 : 1; }
+        }
+        p.note_T = 512;
+        return;
+    }
+    if (p.stream) { p.kind = EDS_K6_STREAM; p.S = bic ? 0 : 1; p.T = p.wide ? 512 : 256; p.P = p.wide ? 2048 : 1024; p.K = 1; p.note_T = p.T; return; }
+    p.kind = EDS_K6_FUSED; p.K = 1;
+    const int Tt = p.threads > 512 ? 1024 : 512;
+    p.P = (p.ppt == 1 || p.ppt == 2 || p.ppt == 4) ? p.ppt : 0; p.T = Tt;     // any other count: constants re-read per pass (PPT = 0)
+    if (strips) {
+        p.S = bic ? 0 : 1; p.Q = hub ? 4 : 3;
+        if (p.ppt == 4) p.T = 512;
+    } else if (!bic) {
+        p.S = 1; p.Q = 0; p.bilinear_tu = 1;
+    } else {
+        p.S = 0;
+        switch (p.ppt) {
+            case 1: p.Q = p.quad ? 1 : 0; break;
+            case 2: p.Q = p.quad ? (hub ? 2 : 1) : 0; break;
+            case 4: p.Q = p.quad ? (hub ? 2 : 1) : 0; if (p.quad) p.T = 512; break;
+            default: p.P = 0; p.Q = 0; break;
+        }
+    }
+    p.note_T = p.bilinear_tu ? p.threads : p.T;
+}
+
+// every instantiation of eds_fused6_kernel the library holds: X(S, P, T, Q, K).  The launcher dispatches over this list and the
+// CPU test checks that the rule never leaves it.
+#define EDS_FUSED6_MAIN_INSTANCES(X)                                                                                                  \
+    X(0, 2, 512, 4, 1) X(0, 2, 512, 3, 1) X(0, 2, 1024, 4, 1) X(0, 2, 1024, 3, 1) X(0, 4, 512, 4, 1) X(0, 4, 512, 3, 1)             \
+    X(1, 2, 512, 4, 1) X(1, 2, 512, 3, 1) X(1, 2, 1024, 4, 1) X(1, 2, 1024, 3, 1) X(1, 4, 512, 4, 1) X(1, 4, 512, 3, 1)             \
+    X(0, 1, 512, 1, 1) X(0, 1, 512, 0, 1) X(0, 1, 1024, 1, 1) X(0, 1, 1024, 0, 1)                                                   \
+    X(0, 2, 512, 2, 1) X(0, 2, 512, 1, 1) X(0, 2, 512, 0, 1) X(0, 2, 1024, 2, 1) X(0, 2, 1024, 1, 1) X(0, 2, 1024, 0, 1)             \
+    X(0, 4, 512, 2, 1) X(0, 4, 512, 1, 1) X(0, 4, 512, 0, 1) X(0, 4, 1024, 0, 1) X(0, 0, 512, 0, 1) X(0, 0, 1024, 0, 1)             \
+    X(1, 4, 512, 4, 2) X(1, 4, 512, 3, 2) X(0, 4, 512, 4, 2) X(0, 4, 512, 3, 2) X(0, 4, 512, 2, 2) X(0, 4, 512, 1, 2)               \
+    X(1, 4, 512, 4, 4) X(1, 4, 512, 3, 4) X(0, 4, 512, 4, 4) X(0, 4, 512, 3, 4) X(0, 4, 512, 2, 4) X(0, 4, 512, 1, 4)               \
+    X(1, 4, 512, 4, 8) X(1, 4, 512, 3, 8) X(0, 4, 512, 4, 8) X(0, 4, 512, 3, 8) X(0, 4, 512, 2, 8) X(0, 4, 512, 1, 8)               \
+    X(0, 1, 512, 1, 4) X(0, 1, 512, 0, 4)                                                                                             \
+    X(1, 2, 512, 4, 2) X(1, 2, 512, 3, 2) X(0, 2, 512, 0, 2) X(0, 2, 512, 4, 2) X(0, 2, 512, 3, 2) X(0, 2, 512, 2, 2) X(0, 2, 512, 1, 2) \
+    X(1, 2, 512, 4, 4) X(1, 2, 512, 3, 4) X(0, 2, 512, 0, 4) X(0, 2, 512, 4, 4) X(0, 2, 512, 3, 4) X(0, 2, 512, 2, 4) X(0, 2, 512, 1, 4) \
+    X(1, 2, 512, 4, 8) X(1, 2, 512, 3, 8) X(0, 2, 512, 0, 8) X(0, 2, 512, 4, 8) X(0, 2, 512, 3, 8) X(0, 2, 512, 2, 8) X(0, 2, 512, 1, 8) \
+    X(1, 2, 512, 4, 16) X(1, 2, 512, 3, 16) X(0, 2, 512, 0, 16) X(0, 2, 512, 4, 16) X(0, 2, 512, 3, 16) X(0, 2, 512, 2, 16) X(0, 2, 512, 1, 16)
+// ... and the lane kernels of the bilinear sampler, compiled into eds_fused_bilinear.o
+#define EDS_FUSED6_BILINEAR_INSTANCES(X)                                                                                              \
+    X(1, 1, 512, 0, 1) X(1, 1, 1024, 0, 1) X(1, 2, 512, 0, 1) X(1, 2, 1024, 0, 1) X(1, 4, 512, 0, 1) X(1, 4, 1024, 0, 1)             \
+    X(1, 0, 512, 0, 1) X(1, 0, 1024, 0, 1) X(1, 1, 512, 0, 4) X(1, 2, 512, 0, 2) X(1, 2, 512, 0, 4) X(1, 2, 512, 0, 8) X(1, 2, 512, 0, 16)
+
+static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu) {
+#define EDS_INST_EQ_(s, p, t, q, k) if (S == s && P == p && T == t && Q == q && K == k) return true;
+    if (bilinear_tu) { EDS_FUSED6_BILINEAR_INSTANCES(EDS_INST_EQ_) }
+    else { EDS_FUSED6_MAIN_INSTANCES(EDS_INST_EQ_) }
+#undef EDS_INST_EQ_
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// the reference problem (REF12): eds_fused12_kernel<S, T, CAP, NC, K, Q>
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct EdsRef12In {
+    int maxN, count;
+    int bicubic, nc;        // cfg.sampling == bicubic; cfg.nc (the PhotometricErrorNC residual)
+    int H;
+    int retry;
+};
+struct EdsRef12Plan {
+    int wide, wants_team;               // begin
+    int team, quad, strips_eligible;    // team
+    int S, T, CAP, NC, K, Q;            // finish
+};
+
+static inline void eds_ref12_plan_begin(const EdsKnobs& kn, const EdsRef12In& in, EdsRef12Plan& p) {
+    memset(&p, 0, sizeof(p));
+    // Two shapes of the same kernel.  Up to one workgroup per CU (count <= 256) an alignment gets the whole CU: 512 threads, 88 KB
+    // patch cache; beyond, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase overlaps
+    // the other's point phase
+    bool wide = in.count <= 256;
+    if (kn.ref12_kernel == 1) wide = true; else if (kn.ref12_kernel == 2) wide = false;
+    p.wide = wide;
+    p.wants_team = wide && !in.nc && in.maxN > 512 && in.count <= EDS_RULE_TEAM12_SLOTS && !in.retry;
+}
+
+static inline void eds_ref12_plan_team(const EdsKnobs& kn, const EdsRef12In& in, int team_ok, int cooldown_active, EdsRef12Plan& p) {
+    int team = 1;
+    if (team_ok) {
+        team = (in.count <= 64 && in.maxN > 1024) ? 4 : 2;
+        if (in.count <= 16 && in.maxN > 1024) team = 8;                                           // a handful of alignments: 8 CUs each
+        if (in.maxN > 8192 && in.count * 16 <= EDS_RULE_TEAM12_MEMBERS) team = 16;                // the finer pyramid levels: ~1 000 points per CU
+        else if (in.maxN > 4096 && in.count * 8 <= EDS_RULE_TEAM12_MEMBERS) team = 8;
+    }
+    if (kn.ref12_team) {
+        const int v = kn.ref12_team;
+        if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && p.wide && !in.nc && in.count <= EDS_RULE_TEAM12_SLOTS &&
+                       in.count * v <= EDS_RULE_TEAM12_MEMBERS && !in.retry && !cooldown_active)) team = v;
+    }
+    p.team = team;
+    // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase: on the tiles from 1 024
+    // alignments, on the strips (one load per row, no shift) from 64
+    const bool want_strips = !in.nc && !kn.layout_tiles;
+    bool quad = in.bicubic && in.count >= (want_strips ? 64 : 1024);
+    if (kn.gather) quad = in.bicubic && kn.gather == 1;
+    quad = quad && in.H < 8000;                                       // 13-bit row field of the packed origins
+    p.quad = quad;
+    // teams of 8 and 16 have no strip instantiation: their frames are neither converted nor marked as solved-on-strips
+    p.strips_eligible = quad && want_strips && team <= 4;
+}
+
+static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& in, int strips, EdsRef12Plan& p) {
+    strips = strips && p.strips_eligible;
+    const bool want_strips = !in.nc && !kn.layout_tiles;
+    bool quad = p.quad;
+    if (want_strips && !strips && in.count < 1024) quad = false;     // (no copies to read: the tiles' rule)
+    p.K = p.team; p.NC = 0;
+    p.S = in.bicubic ? 0 : 1;
+    if (p.team > 1 || p.wide) { p.T = 512; p.CAP = 1408; } else { p.T = 256; p.CAP = 320; }
+    if (p.team >= 8 || !in.bicubic) p.Q = 0;
+    else p.Q = strips ? 2 : (quad ? 1 : 0);
+    if (p.team == 1 && !(in.bicubic && strips)) p.NC = in.nc ? 1 : 0;
+}
+
+#define EDS_FUSED12_INSTANCES(X)                                                                                                      \
+    X(0, 512, 1408, false, 16, 0) X(1, 512, 1408, false, 16, 0) X(0, 512, 1408, false, 8, 0) X(1, 512, 1408, false, 8, 0)           \
+    X(0, 512, 1408, false, 4, 2) X(0, 512, 1408, false, 4, 1) X(0, 512, 1408, false, 4, 0) X(1, 512, 1408, false, 4, 0)             \
+    X(0, 512, 1408, false, 2, 2) X(0, 512, 1408, false, 2, 1) X(0, 512, 1408, false, 2, 0) X(1, 512, 1408, false, 2, 0)             \
+    X(0, 512, 1408, false, 1, 2) X(0, 512, 1408, false, 1, 1) X(0, 512, 1408, true, 1, 1) X(0, 512, 1408, false, 1, 0)              \
+    X(0, 512, 1408, true, 1, 0) X(1, 512, 1408, false, 1, 0) X(1, 512, 1408, true, 1, 0)                                            \
+    X(0, 256, 320, false, 1, 2) X(0, 256, 320, false, 1, 1) X(0, 256, 320, true, 1, 1) X(0, 256, 320, false, 1, 0)                  \
+    X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)
+
+static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q) {
+#define EDS_INST_EQ_(s, t, c, n, k, q) if (S == s && T == t && CAP == c && (NC != 0) == n && K == k && Q == q) return true;
+    EDS_FUSED12_INSTANCES(EDS_INST_EQ_)
+#undef EDS_INST_EQ_
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// strip copies: how many row phases fit the budget (eds_strips.hip).  copy_bytes_per_slot = 2 x one copy of one frame.
+// returns 4, 2, 1, or 0 (none: remembered on the handle, not retried on every solve)
+// ---------------------------------------------------------------------------------------------------------------------------------
+static inline int eds_strips_phases_for_budget(int wanted_phases, unsigned long long slots, unsigned long long two_copies_bytes,
+                                               unsigned long long free_bytes, int budget_pct) {
+    const unsigned long long budget = free_bytes / 100ull * (unsigned long long)budget_pct;
+    for (int ph = wanted_phases; ph >= 1; ph >>= 1)
+        if (slots * (unsigned long long)ph * two_copies_bytes <= budget) return ph;
+    return 0;
+}

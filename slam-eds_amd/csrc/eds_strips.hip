@@ -35,18 +35,26 @@ __global__ __launch_bounds__(256) void k_tiles_to_strips(const float* __restrict
 
 bool eds_strips_prepare(eds_trk* h, int first, int count) {
     if (!h->tiled) return false;
+    if (h->strips_unavailable) return false;       // they did not fit the budget when they were asked for: remembered (eds_trk_set_knob re-arms)
     if (!h->dstrips) {
         // row phases (eds_layout.hpp): 4 — one 128-byte line per patch — for handles that hold batches, whose solves are bound by the
         // fabric's line fills; 1 for the handles of the latency regime (a lone alignment is not bandwidth-bound, and its frame changes
-        // with every call: 2.5 MB of copies to write instead of 10).  EDS_STRIPS_PHASES=1|2|4 overrides; less memory -> fewer phases.
+        // with every call: 2.5 MB of copies to write instead of 10).  EDS_STRIPS_PHASES=1|2|4 overrides.
+        // The copies are 8x the tiled frames with 4 phases (41 GB for 4 096 VGA slots, 124 GB at 1280x720): they may take at most
+        // EDS_STRIPS_BUDGET_PCT (50) percent of the memory that is free NOW — fewer phases beyond that, none if even one does not fit —
+        // so that a second handle, the team mailboxes or the caller's own buffers are not starved by a grab that happened to succeed.
         int phases = h->B >= 32 ? 4 : 1;
-        if (const char* ev = getenv("EDS_STRIPS_PHASES")) { const int v = atoi(ev); if (v == 1 || v == 2 || v == 4) phases = v; }
+        if (h->knobs.strips_phases) phases = h->knobs.strips_phases;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        const size_t two_copies = (size_t)2 * eds_strips_copy_elems(h->Hp, h->Wp) * sizeof(float);
+        phases = eds_strips_phases_for_budget(phases, (unsigned long long)h->B, two_copies, free_b, h->knobs.strips_budget_pct);
         for (; phases >= 1; phases >>= 1) {
-            const size_t bytes = (size_t)h->B * 2 * phases * eds_strips_copy_elems(h->Hp, h->Wp) * sizeof(float);
-            if (hipMalloc((void**)&h->dstrips, bytes) == hipSuccess) break;
+            const size_t bytes = (size_t)h->B * phases * two_copies;
+            if (hipMalloc((void**)&h->dstrips, bytes) == hipSuccess) { h->strips_bytes = bytes; break; }
             (void)hipGetLastError(); h->dstrips = nullptr;
         }
-        if (!h->dstrips) return false;
+        if (!h->dstrips) { h->strips_unavailable = true; return false; }
         h->strip_phases = phases;
     }
     // the slots whose storage is sampled: a slot's own, or the one it shares (eds_trk_share_event_frame)
@@ -91,10 +99,7 @@ bool eds_strips_current(const eds_trk* h, int first, int count) {
 // the whole range would cost more than their copies).  EDS_STRIPS_POLICY = reuse (default) | eager (convert at the first solve:
 // round 3's first rule) | never.
 bool eds_strips_for_solve(eds_trk* h, int first, int count) {
-    static const int policy = [] {
-        const char* ev = getenv("EDS_STRIPS_POLICY");
-        return !ev ? 0 : (std::strcmp(ev, "eager") == 0 ? 1 : (std::strcmp(ev, "never") == 0 ? 2 : 0));
-    }();
+    const int policy = h->knobs.strips_policy;         // 0 reuse | 1 eager | 2 never (per handle: eds_launch_rule.hpp)
     if (!h->tiled) return false;
     int stale = 0, fresh = 0;
     for (int s = first; s < first + count; ++s) {
@@ -116,4 +121,5 @@ bool eds_strips_for_solve(eds_trk* h, int first, int count) {
 void eds_strips_free(eds_trk* h) {
     if (h->dstrips) hipFree(h->dstrips);
     h->dstrips = nullptr;
+    h->strips_bytes = 0;
 }

@@ -2,11 +2,13 @@
 // the state machines are fed with reduced sums computed by the oracle's evaluator, so that the
 // solver logic can be checked against the oracle's own solvers without a GPU.  Test-only code.
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../oracle/eds_oracle.hpp"
 #include "../../slam-eds_amd/csrc/eds_math.hpp"
 #include "../../slam-eds_amd/csrc/eds_layout.hpp"
+#include "../../slam-eds_amd/csrc/eds_launch_rule.hpp"
 #include "../../slam-eds_amd/csrc/eds_solver.hpp"
 
 using namespace eds_oracle;
@@ -143,6 +145,57 @@ int hl_strips_layout(int Hp, int Wp, int phases, long long* stats) {
         }
     stats[0] = patches; stats[1] = aligned; stats[2] = one_line;
     return (int)(bad > 2000000000ll ? 2000000000ll : bad);
+}
+
+// The launch rule of the product (eds_launch_rule.hpp).  knobs: "NAME=value;NAME=value" (the names of the environment variables).
+// in7 = {maxN, count, bicubic, iters, lm6, huber, H}; flags: bit 0 retry, bit 1 the time-out policy allows teams, bit 2 a cool-down is
+// running, bit 3 the strip copies are (or can be made) current.
+// out = {kind, S, P, T, Q, K, bilinear_tu, wide_members, threads, ppt, strips_eligible, wants_team, instance_exists, note_T}
+static int parse_knobs(const char* spec, EdsKnobs* kn) {
+    std::string s(spec ? spec : "");
+    size_t a = 0;
+    while (a < s.size()) {
+        size_t b = s.find(';', a); if (b == std::string::npos) b = s.size();
+        const std::string item = s.substr(a, b - a);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos && eds_knobs_set(kn, item.substr(0, eq).c_str(), item.substr(eq + 1).c_str()) != 0) return -1;
+        a = b + 1;
+    }
+    return 0;
+}
+int hl_lm6_rule(const char* knobs, const int32_t* in7, int flags, int32_t* out) {
+    EdsKnobs kn;
+    if (parse_knobs(knobs, &kn)) return -1;
+    const EdsLm6In in{in7[0], in7[1], in7[2], in7[3], in7[4], in7[5], in7[6], (flags & 1) ? 1 : 0};
+    EdsLm6Plan p;
+    eds_lm6_plan_begin(kn, in, p);
+    const int team_ok = p.wants_team && (flags & 2);
+    eds_lm6_plan_team(kn, in, team_ok, (flags & 4) ? 1 : 0, p);
+    const int strips = p.strips_eligible && (flags & 8);
+    eds_lm6_plan_finish(kn, in, strips, p);
+    const int exists = p.kind == EDS_K6_STREAM ? 1 : (eds_fused6_instance_exists(p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu) ? 1 : 0);
+    const int32_t o[14] = {p.kind, p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, p.wide_members, p.threads, p.ppt, p.strips_eligible, p.wants_team, exists, p.note_T};
+    std::memcpy(out, o, sizeof(o));
+    return 0;
+}
+// in5 = {maxN, count, bicubic, nc, H}; flags as above.  out = {S, T, CAP, NC, K, Q, strips_eligible, wants_team, instance_exists}
+int hl_ref12_rule(const char* knobs, const int32_t* in5, int flags, int32_t* out) {
+    EdsKnobs kn;
+    if (parse_knobs(knobs, &kn)) return -1;
+    const EdsRef12In in{in5[0], in5[1], in5[2], in5[3], in5[4], (flags & 1) ? 1 : 0};
+    EdsRef12Plan p;
+    eds_ref12_plan_begin(kn, in, p);
+    const int team_ok = p.wants_team && (flags & 2);
+    eds_ref12_plan_team(kn, in, team_ok, (flags & 4) ? 1 : 0, p);
+    const int strips = p.strips_eligible && (flags & 8);
+    eds_ref12_plan_finish(kn, in, strips, p);
+    const int32_t o[9] = {p.S, p.T, p.CAP, p.NC, p.K, p.Q, p.strips_eligible, p.wants_team, eds_fused12_instance_exists(p.S, p.T, p.CAP, p.NC, p.K, p.Q) ? 1 : 0};
+    std::memcpy(out, o, sizeof(o));
+    return 0;
+}
+int hl_knob_set(const char* name, const char* value) { EdsKnobs kn; return eds_knobs_set(&kn, name, value); }
+int hl_strips_phases_for_budget(int wanted, long long slots, long long two_copies_bytes, long long free_bytes, int pct) {
+    return eds_strips_phases_for_budget(wanted, (unsigned long long)slots, (unsigned long long)two_copies_bytes, (unsigned long long)free_bytes, pct);
 }
 
 }  // extern "C"

@@ -27,7 +27,8 @@ class _Pb(C.Structure):
 @pytest.fixture(scope="module")
 def hl():
     deps = [SRC] + [os.path.join(HERE, "..", p) for p in ("oracle/eds_oracle.hpp", "slam-eds_amd/csrc/eds_math.hpp",
-                                                         "slam-eds_amd/csrc/eds_solver.hpp", "slam-eds_amd/csrc/eds_layout.hpp")]
+                                                         "slam-eds_amd/csrc/eds_solver.hpp", "slam-eds_amd/csrc/eds_layout.hpp",
+                                                         "slam-eds_amd/csrc/eds_launch_rule.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-misleading-indentation", "-o", LIB, SRC])
     return C.CDLL(LIB)
@@ -202,3 +203,147 @@ def test_strip_copy_rule(hl):
     assert d(1, 4096, 4096, 4096) == 2 and d(1, 0, 0, 8) == 1       # eager
     assert d(2, 0, 0, 8) == 0 and d(2, 8, 0, 8) == 0                # never
 
+
+
+# ---- the launch rule (slam-eds_amd/csrc/eds_launch_rule.hpp): which kernel a solve launches, as a pure function -------------------
+TEAM_OK, COOLDOWN, STRIPS, RETRY = 2, 4, 8, 1
+
+
+def _lm6(hl, knobs="", maxN=2000, count=4096, bicubic=1, iters=10, lm6=1, huber=0, H=480, flags=TEAM_OK | STRIPS):
+    out = np.zeros(14, dtype=np.int32)
+    rc = hl.hl_lm6_rule(knobs.encode(), np.array([maxN, count, bicubic, iters, lm6, huber, H], dtype=np.int32).ctypes.data_as(_ip), int(flags),
+                        out.ctypes.data_as(_ip))
+    assert rc == 0
+    keys = ("kind", "S", "P", "T", "Q", "K", "bilinear_tu", "wide_members", "threads", "ppt", "strips_eligible", "wants_team", "exists", "note_T")
+    return dict(zip(keys, (int(x) for x in out)))
+
+
+def _ref12(hl, knobs="", maxN=2000, count=4096, bicubic=1, nc=0, H=480, flags=TEAM_OK | STRIPS):
+    out = np.zeros(9, dtype=np.int32)
+    rc = hl.hl_ref12_rule(knobs.encode(), np.array([maxN, count, bicubic, nc, H], dtype=np.int32).ctypes.data_as(_ip), int(flags), out.ctypes.data_as(_ip))
+    assert rc == 0
+    return dict(zip(("S", "T", "CAP", "NC", "K", "Q", "strips_eligible", "wants_team", "exists"), (int(x) for x in out)))
+
+
+def _k6(d):
+    return (d["kind"], d["S"], d["P"], d["T"], d["Q"], d["K"])
+
+
+def test_launch_rule_pose_only_table(hl):
+    """DESIGN.md 3.7, row by row: the kernel eds_fused_solve launches is a pure function of the shape of the range, the handle's knobs,
+    the teams' time-out policy and whether the strip copies of the frames are current."""
+    FUSED, TEAM, STREAM = 0, 1, 2
+    # the headline: 4 096 x 2 000 points, bicubic — strips when the copies are there, the tile kernel on a frame's first solve
+    assert _k6(_lm6(hl)) == (FUSED, 0, 4, 512, 3, 1)
+    assert _k6(_lm6(hl, flags=TEAM_OK)) == (FUSED, 0, 4, 512, 1, 1)
+    assert _k6(_lm6(hl, huber=1)) == (FUSED, 0, 4, 512, 4, 1) and _k6(_lm6(hl, huber=1, flags=TEAM_OK)) == (FUSED, 0, 4, 512, 2, 1)
+    assert _k6(_lm6(hl, "EDS_FUSED_LAYOUT=tiles")) == (FUSED, 0, 4, 512, 1, 1)
+    # the bilinear sampler: its strip kernel on copies, its lane kernel (second translation unit) otherwise
+    d = _lm6(hl, bicubic=0)
+    assert _k6(d) == (FUSED, 1, 4, 512, 3, 1) and not d["bilinear_tu"]
+    d = _lm6(hl, bicubic=0, flags=TEAM_OK)
+    assert _k6(d) == (FUSED, 1, 4, 512, 0, 1) and d["bilinear_tu"] and d["note_T"] == 512
+    # below 32 alignments without teams (GN6 forms none): the lane-per-patch gather
+    assert _k6(_lm6(hl, count=8, lm6=0)) == (FUSED, 0, 4, 512, 0, 1)
+    assert _k6(_lm6(hl, "EDS_FUSED_GATHER=lane")) == (FUSED, 0, 4, 512, 0, 1)
+    # small keyframes: fewer threads, one point per lane
+    d = _lm6(hl, maxN=256, count=4096)
+    assert d["threads"] == 256 and _k6(d) == (FUSED, 0, 1, 512, 1, 1)
+    d = _lm6(hl, maxN=700, count=40)
+    assert d["threads"] == 512 and d["ppt"] == 2 and _k6(d) == (FUSED, 0, 2, 512, 3, 1)
+    # the latency regime: 4 CUs up to 64 alignments of more than 1 024 points, 2 up to 128; never for 513 .. 1 024 points, GN6, a retry,
+    # a running cool-down
+    assert _k6(_lm6(hl, count=1)) == (TEAM, 0, 1, 512, 0, 4) and _k6(_lm6(hl, count=64)) == (TEAM, 0, 1, 512, 1, 4)
+    assert _k6(_lm6(hl, count=65)) == (TEAM, 0, 2, 512, 3, 2) and _k6(_lm6(hl, count=128, flags=TEAM_OK)) == (TEAM, 0, 2, 512, 1, 2)
+    assert _k6(_lm6(hl, count=129)) == (FUSED, 0, 4, 512, 3, 1)
+    assert _lm6(hl, maxN=1024, count=1)["K"] == 1 and _lm6(hl, count=1, lm6=0)["K"] == 1 and _lm6(hl, count=1, iters=0)["K"] == 1
+    assert _lm6(hl, count=1, flags=STRIPS)["K"] == 1 and _lm6(hl, count=1, flags=RETRY | TEAM_OK | STRIPS)["K"] == 1
+    d = _lm6(hl, count=1, bicubic=0)
+    assert _k6(d) == (TEAM, 1, 1, 512, 0, 4) and d["bilinear_tu"]
+    # beyond 2 048 points: teams of 1 024 points per member at any batch size while at most one workgroup per CU, members of 2 048 beyond
+    assert _k6(_lm6(hl, maxN=8000, count=1, H=720)) == (TEAM, 0, 2, 512, 0, 8)
+    assert _k6(_lm6(hl, maxN=8000, count=32, H=720)) == (TEAM, 0, 2, 512, 3, 8)
+    d = _lm6(hl, maxN=8000, count=256, H=720, huber=1)
+    assert _k6(d) == (TEAM, 0, 4, 512, 4, 4) and d["wide_members"]
+    assert _k6(_lm6(hl, maxN=8000, count=256, H=720, flags=TEAM_OK)) == (TEAM, 0, 4, 512, 1, 4)
+    assert _k6(_lm6(hl, "EDS_TEAM_WIDE=0", maxN=8000, count=256, H=720)) == (TEAM, 0, 2, 512, 3, 8)
+    assert _k6(_lm6(hl, maxN=16000, count=64)) == (TEAM, 0, 4, 512, 3, 8) and _k6(_lm6(hl, maxN=16000, count=16)) == (TEAM, 0, 2, 512, 3, 16)
+    assert _k6(_lm6(hl, maxN=4000, count=64)) == (TEAM, 0, 2, 512, 3, 4) and _k6(_lm6(hl, maxN=4000, count=65)) == (TEAM, 0, 4, 512, 3, 2)
+    d = _lm6(hl, maxN=8000, count=256, H=720, bicubic=0)          # the bilinear sampler: wide members on the strips only
+    assert _k6(d) == (TEAM, 1, 4, 512, 3, 4)
+    d = _lm6(hl, maxN=8000, count=256, H=720, bicubic=0, flags=TEAM_OK)
+    assert _k6(d) == (TEAM, 1, 2, 512, 0, 8) and d["bilinear_tu"]
+    # ... the streaming kernel where no team can form: GN6, more than 16 384 points, teams paused; a handful of very large ones resident
+    assert _k6(_lm6(hl, maxN=8000, count=256, lm6=0)) == (STREAM, 0, 2048, 512, 0, 1)
+    assert _k6(_lm6(hl, maxN=20000, count=64)) == (STREAM, 0, 2048, 512, 0, 1)
+    assert _k6(_lm6(hl, maxN=8000, count=8, lm6=0)) == (FUSED, 0, 0, 1024, 0, 1)
+    assert _k6(_lm6(hl, maxN=3000, count=8, lm6=0)) == (STREAM, 0, 2048, 512, 0, 1)
+    assert _k6(_lm6(hl, "EDS_LM6_KERNEL=paired", lm6=0)) == (STREAM, 0, 1024, 256, 0, 1)
+    # knobs that override the team size stay inside what is feasible and never reach past the time-out policy
+    assert _lm6(hl, "EDS_LM6_TEAM=2", count=16)["K"] == 2 and _lm6(hl, "EDS_LM6_TEAM=1", count=16)["K"] == 1
+    assert _lm6(hl, "EDS_LM6_TEAM=8", count=16)["K"] == 8 and _lm6(hl, "EDS_LM6_TEAM=2", maxN=4000, count=16)["K"] == 4
+    assert _lm6(hl, "EDS_LM6_TEAM=4", count=16, flags=COOLDOWN | STRIPS)["K"] == 1
+    assert _lm6(hl, "EDS_LM6_SPEC=0", count=16)["K"] == 1
+
+
+def test_launch_rule_ref12_table(hl):
+    K = lambda d: (d["S"], d["T"], d["CAP"], d["NC"], d["K"], d["Q"])
+    assert K(_ref12(hl)) == (0, 256, 320, 0, 1, 2) and K(_ref12(hl, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 1)       # the batch: two alignments per CU
+    assert K(_ref12(hl, count=512, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 0)                                       # tiles: the quad gather from 1 024 on
+    assert K(_ref12(hl, count=256)) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, count=65, flags=TEAM_OK)) == (0, 512, 1408, 0, 1, 0)
+    assert K(_ref12(hl, count=1)) == (0, 512, 1408, 0, 8, 0) and K(_ref12(hl, count=16)) == (0, 512, 1408, 0, 8, 0)
+    assert K(_ref12(hl, count=17)) == (0, 512, 1408, 0, 4, 0) and K(_ref12(hl, count=64)) == (0, 512, 1408, 0, 4, 2)
+    assert K(_ref12(hl, maxN=1000, count=8)) == (0, 512, 1408, 0, 2, 0) and K(_ref12(hl, maxN=500, count=8))[4] == 1
+    assert K(_ref12(hl, maxN=16000, count=4)) == (0, 512, 1408, 0, 16, 0) and K(_ref12(hl, maxN=8000, count=64)) == (0, 512, 1408, 0, 8, 0)
+    # teams of 8 / 16 have no strip instantiation: their frames are not converted (ADVICE r3)
+    assert not _ref12(hl, "EDS_REF12_TEAM=8", count=64)["strips_eligible"] and _ref12(hl, count=64)["strips_eligible"]
+    # the NC residual: no teams, no strips; the bilinear sampler: the lane gather
+    assert K(_ref12(hl, nc=1)) == (0, 256, 320, 1, 1, 1) and K(_ref12(hl, nc=1, count=8)) == (0, 512, 1408, 1, 1, 0)
+    assert K(_ref12(hl, bicubic=0)) == (1, 256, 320, 0, 1, 0) and K(_ref12(hl, bicubic=0, count=4)) == (1, 512, 1408, 0, 8, 0)
+    assert K(_ref12(hl, "EDS_REF12_KERNEL=wide")) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, "EDS_REF12_KERNEL=paired", count=8)) == (0, 256, 320, 0, 1, 0)
+    assert K(_ref12(hl, "EDS_REF12_TEAM=4", count=8, flags=COOLDOWN))[4] == 1 and K(_ref12(hl, count=8, flags=RETRY | TEAM_OK))[4] == 1
+
+
+def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
+    """Closure: over a sweep of shapes, samplers, policies and knob settings the rule always names a kernel that was compiled."""
+    rng = np.random.default_rng(7)
+    knobs = ["", "EDS_FUSED_LAYOUT=tiles", "EDS_FUSED_GATHER=lane", "EDS_FUSED_GATHER=quad", "EDS_LM6_TEAM=1", "EDS_LM6_TEAM=2", "EDS_LM6_TEAM=4",
+             "EDS_LM6_TEAM=8", "EDS_LM6_TEAM=16", "EDS_TEAM_WIDE=1", "EDS_TEAM_WIDE=0", "EDS_LM6_KERNEL=resident", "EDS_LM6_KERNEL=wide",
+             "EDS_LM6_KERNEL=paired", "EDS_FUSED_THREADS=256", "EDS_FUSED_THREADS=1024", "EDS_FUSED_PPT=2", "EDS_FUSED_PPT=3", "EDS_FUSED_PPT=0",
+             "EDS_LM6_SPEC=0", "EDS_FUSED_THREADS=1024;EDS_FUSED_PPT=2;EDS_LM6_KERNEL=resident"]
+    n = 0
+    for kn in knobs:
+        for _ in range(300):
+            maxN = int(rng.choice([1, 63, 64, 200, 512, 513, 1024, 1025, 2000, 2048, 2049, 4000, 4096, 4097, 8000, 8192, 8722, 16000, 16384, 16385, 30000]))
+            count = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 4096, 5000]))
+            d = _lm6(hl, kn, maxN=maxN, count=count, bicubic=int(rng.integers(2)), iters=int(rng.choice([0, 1, 10])), lm6=int(rng.integers(2)),
+                     huber=int(rng.integers(2)), H=int(rng.choice([120, 480, 720, 9000])), flags=int(rng.integers(16)))
+            assert d["exists"], (kn, maxN, count, d)
+            assert d["kind"] == 2 or d["K"] == 1 or d["P"] * 512 * d["K"] >= min(maxN, 16384) or d["K"] in (2, 4, 8, 16), d
+            if d["kind"] != 2 and d["P"] > 0 and d["kind"] == 0:
+                assert d["P"] * d["threads"] >= maxN, (kn, maxN, count, d)       # register-resident points: every point has a lane slot
+            n += 1
+    for kn in ["", "EDS_FUSED_LAYOUT=tiles", "EDS_FUSED_GATHER=lane", "EDS_FUSED_GATHER=quad", "EDS_REF12_TEAM=1", "EDS_REF12_TEAM=2", "EDS_REF12_TEAM=4",
+               "EDS_REF12_TEAM=8", "EDS_REF12_TEAM=16", "EDS_REF12_KERNEL=wide", "EDS_REF12_KERNEL=paired"]:
+        for _ in range(300):
+            d = _ref12(hl, kn, maxN=int(rng.choice([64, 512, 513, 1024, 1025, 2000, 4096, 4097, 8192, 8193, 16000])),
+                       count=int(rng.choice([1, 16, 17, 32, 33, 64, 65, 256, 257, 1023, 1024, 4096])), bicubic=int(rng.integers(2)), nc=int(rng.integers(2)),
+                       H=int(rng.choice([480, 9000])), flags=int(rng.integers(16)))
+            assert d["exists"], (kn, d)
+            assert not (d["NC"] and d["K"] > 1) and not (d["Q"] == 2 and d["NC"])
+    assert n == len(knobs) * 300
+
+
+def test_knob_names_and_strip_budget(hl):
+    for name in ("EDS_REF12_EXEC", "EDS_FUSED_THREADS", "EDS_FUSED_PPT", "EDS_LM6_SPEC", "EDS_LM6_KERNEL", "EDS_FUSED_LAYOUT", "EDS_TEAM_TEST_DROP_MEMBER",
+                 "EDS_LM6_TEAM", "EDS_TEAM_WIDE", "EDS_FUSED_GATHER", "EDS_FUSED_REPORT", "EDS_REF12_KERNEL", "EDS_REF12_TEAM", "EDS_STRIPS_PHASES",
+                 "EDS_STRIPS_POLICY", "EDS_STRIPS_BUDGET_PCT", "EDS_NO_SPIN", "EDS_UPLOAD", "EDS_FRAME_LAYOUT"):
+        assert hl.hl_knob_set(name.encode(), b"1") == 0 and hl.hl_knob_set(name.encode(), None) == 0
+    assert hl.hl_knob_set(b"EDS_NO_SUCH_KNOB", b"1") == -1
+    f = hl.hl_strips_phases_for_budget
+    f.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
+    two = 2 * 1264128                                       # two column copies of one 640x480 frame (488 x 648 floats)
+    GB = 1 << 30
+    assert f(4, 4096, two, 240 * GB, 50) == 4               # the bench's batch: 41 GB of 120 GB allowed
+    assert f(4, 4096, two, 60 * GB, 50) == 2 and f(4, 4096, two, 30 * GB, 50) == 1 and f(4, 4096, two, 10 * GB, 50) == 0
+    assert f(4, 4096, two, 60 * GB, 95) == 4 and f(1, 1, two, 1 * GB, 50) == 1 and f(4, 100000, two, 250 * GB, 50) == 0

@@ -65,15 +65,14 @@ def test_strip_copies_follow_the_frames(gpu, capi, synth):
     fresh.prepare_frames(0, B)
     fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
     assert np.array_equal(fresh.results(0, B), second)
-    # and the tile kernels (EDS_FUSED_LAYOUT=tiles is read per solve) agree with the strip kernels to the last bits of the fp32 sums
-    import os
-    os.environ["EDS_FUSED_LAYOUT"] = "tiles"
-    try:
-        fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
-        assert fresh.last_launch()["layout"] == 1
-        tiles = fresh.results(0, B)
-    finally:
-        os.environ.pop("EDS_FUSED_LAYOUT", None)
+    # and the tile kernels (the handle's EDS_FUSED_LAYOUT knob) agree with the strip kernels to the last bits of the fp32 sums
+    fresh.set_knob("EDS_FUSED_LAYOUT", "tiles")
+    fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
+    assert fresh.last_launch()["layout"] == 1
+    tiles = fresh.results(0, B)
+    fresh.set_knob("EDS_FUSED_LAYOUT", None)
+    fresh.set_states(0, P, Q, V); fresh.optimize_batch(0, 0, B)
+    assert np.array_equal(fresh.results(0, B), second)          # (64 x 2 000 points run on teams of 512 points per member: the tiles either way)
     assert np.abs(tiles[:, :7] - second[:, :7]).max() < 1e-6 and np.array_equal(tiles[:, 14], second[:, 14])
     h.close(); fresh.close()
 
@@ -149,3 +148,52 @@ def test_live_sequence_timed_inside_the_library(gpu, capi, synth, po):
     with pytest.raises(capi.EdsError):
         h.bench_live(3, al.p0, al.q0, al.v0)
     h.close()
+
+
+def test_two_handles_with_different_knobs_coexist(gpu, capi, synth, monkeypatch):
+    """Tuning knobs belong to the handle (eds_trk_set_knob; the environment is read once, at eds_trk_create): two handles of one process
+    keep different settings, changing the environment after creation changes nothing, unknown names are refused."""
+    import os
+    B = 40
+    als = [synth.make_alignment(8100 + k, H=120, W=160, N=700) for k in range(4)]
+    monkeypatch.setenv("EDS_LM6_TEAM", "1")
+    monkeypatch.setenv("EDS_FUSED_GATHER", "lane")
+    ha = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=6), B, 700, 120, 160)     # reads lane + no teams
+    monkeypatch.delenv("EDS_FUSED_GATHER")
+    monkeypatch.delenv("EDS_LM6_TEAM")
+    hb = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=6), B, 700, 120, 160)     # the rule
+    hb.set_knob("EDS_STRIPS_POLICY", "eager")
+    for h in (ha, hb):
+        for b in range(B):
+            h.set_alignment(b, als[b % 4])
+    S = (np.stack([als[b % 4].p0 for b in range(B)]), np.stack([als[b % 4].q0 for b in range(B)]), np.stack([als[b % 4].v0 for b in range(B)]))
+    os.environ["EDS_FUSED_LAYOUT"] = "tiles"             # after creation: nobody reads it
+    try:
+        for rep in range(2):
+            for h in (ha, hb):
+                h.set_states(0, *S); h.optimize_batch(0, 0, B)
+            la, lb = ha.last_launch(), hb.last_launch()
+            assert la["kernel"] == "eds_fused6_kernel<0, 2, 512, 0, 1>" and la["layout"] == 1, la      # lane gather: never strips
+            assert lb["kernel"] == "eds_fused6_kernel<0, 2, 512, 3, 1>" and lb["layout"] == 2, lb      # eager: strips from the first solve
+            assert np.abs(ha.results(0, B)[:, :7] - hb.results(0, B)[:, :7]).max() < 1e-6
+    finally:
+        os.environ.pop("EDS_FUSED_LAYOUT", None)
+    assert ha.strips_info()["bytes"] == 0 and hb.strips_info()["bytes"] > 0 and hb.strips_info()["row_phases"] == 4
+    with pytest.raises(capi.EdsError):
+        ha.set_knob("EDS_NO_SUCH_KNOB", "1")
+    with pytest.raises(capi.EdsError):
+        ha.set_knob("EDS_FRAME_LAYOUT", "rowmajor")
+    # a budget the copies do not fit: refused once, remembered (no allocation attempt per solve), the tiles serve; a new budget re-arms
+    hc = capi.Handle(capi.default_config(exec=capi.EXEC_DEVICE, solver=capi.SOLVER_LM6, max_num_iterations=6), B, 700, 120, 160)
+    for b in range(B):
+        hc.set_alignment(b, als[b % 4])
+    hc.set_knob("EDS_STRIPS_POLICY", "eager")
+    hc.set_knob("EDS_STRIPS_BUDGET_PCT", "1")
+    hc.set_states(0, *S); hc.optimize_batch(0, 0, B)
+    info = hc.strips_info()
+    if info["unavailable"]:                               # (only on a box whose free memory makes 1 % too little: not the case on 288 GB)
+        assert hc.last_launch()["layout"] == 1
+    else:
+        assert info["bytes"] > 0 and hc.last_launch()["layout"] == 2
+    assert np.abs(hc.results(0, B)[:, :7] - hb.results(0, B)[:, :7]).max() < 1e-6
+    ha.close(); hb.close(); hc.close()

@@ -26,12 +26,12 @@ def _solve(solver, B, drop, seeds):
     for rep in range(3):
         h.set_states(0, p0, q0, v0)
         if drop and rep == 0:
-            os.environ["EDS_TEAM_TEST_DROP_MEMBER"] = "1"
+            h.set_knob("EDS_TEAM_TEST_DROP_MEMBER", "1")       # (a knob of THIS handle: the library reads no environment after create)
         t = time.perf_counter()
         try:
             h.optimize_batch(0, 0, B)
         finally:
-            os.environ.pop("EDS_TEAM_TEST_DROP_MEMBER", None)
+            h.set_knob("EDS_TEAM_TEST_DROP_MEMBER", None)
         walls.append(time.perf_counter() - t)
         tables.append(np.array(h.results(0, B)))
     infos = [h.info(b) for b in range(B)]
@@ -78,11 +78,11 @@ def test_teams_pause_then_come_back(solver):
     def call(drop=False):
         h.set_states(0, p0, q0, v0)
         if drop:
-            os.environ["EDS_TEAM_TEST_DROP_MEMBER"] = "1"
+            h.set_knob("EDS_TEAM_TEST_DROP_MEMBER", "1")
         try:
             t = time.perf_counter(); h.optimize_batch(0, 0, B); w = time.perf_counter() - t
         finally:
-            os.environ.pop("EDS_TEAM_TEST_DROP_MEMBER", None)
+            h.set_knob("EDS_TEAM_TEST_DROP_MEMBER", None)
         return w, np.array(h.results(0, B)), h.info(0)
 
     for _ in range(3):
