@@ -13,9 +13,19 @@
 //   set :71   optimize x3 :73-81   getTransform() :83   getTransform(bool&) :85   getVelocity() -> Matrix<double,6,1>& :87
 //   linearVelocity :89   angularVelocity :91   getLossParams :93   getCoord :96   getInfo :109   needNewKeyframe :113
 //   public `config` :40; private kf, px, qx, vx, info, poses, squared_norm_flow :44-58
-// Not mirrored (outside the hot path, reference Tracker.cpp:378-648): trackPoints*, getEMatrix, getFMatrix and the public
-// getFilteredPose overload — keep the reference implementation for those (the mean filter that getTransform(bool&) needs is
-// restated privately below on plain arrays).
+// Outside the hot path (reference Tracker.cpp:378-648): trackPoints, trackPointsPyr, trackPointsAlongEpiline, getEMatrix, getFMatrix and
+// the public getFilteredPose.  They are KLT / epipolar helpers on cv::Mat and Sophus types and stay the REFERENCE's code:
+//   * define EDS_HIP_REFERENCE_MEMBERS (with EDS_HIP_WITH_EDS_TYPES) and this class DECLARES the six with the reference's exact
+//     signatures (Tracker.hpp:98-111), keeps `poses` as std::vector<eds::SE3> (:55) and lets getTransform(bool&) call the reference's
+//     getFilteredPose (Tracker.cpp:251-260) — an EDS tree then compiles its own Tracker.cpp:378-648 definitions of those six in a
+//     translation unit of its own against THIS header, unchanged (they only touch kf, px, qx, vx, poses, squared_norm_flow and public
+//     members: all present under the reference's names), and every caller of the class relinks unchanged;
+//     tests/cpp/shim_eds_types_check.cpp pins the six signatures and tests/cpp/shim_reference_members.cpp is such a translation unit
+//     (against mock types);
+//   * without it the six are absent and the mean filter that getTransform(bool&) needs is restated privately on plain arrays.
+// Error convention: the reference path has no exceptions — optimize returns false, getCoord an empty vector; the shim does the same for
+// every failure of the library underneath (no device, out of memory, a HIP error) and keeps the status and message for the caller who
+// wants to know why: hipLastStatus() / hipLastError().
 #pragma once
 #include <algorithm>
 #include <array>
@@ -23,12 +33,14 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
-#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/eds_hip.h"
 
+#if defined(EDS_HIP_REFERENCE_MEMBERS) && !defined(EDS_HIP_WITH_EDS_TYPES)
+#error "EDS_HIP_REFERENCE_MEMBERS declares members on cv::Mat and eds::SE3: it needs EDS_HIP_WITH_EDS_TYPES"
+#endif
 #ifdef EDS_HIP_WITH_EDS_TYPES
 #include <eds/tracking/Config.hpp>
 #include <eds/tracking/KeyFrame.hpp>
@@ -191,8 +203,16 @@ class Tracker {
     Eigen::Quaterniond qx;                                                          // :48
     Eigen::Matrix<double, 6, 1> vx;                                                 // :49
     eds::tracking::TrackerInfo info;                                                // :52
+#ifdef EDS_HIP_REFERENCE_MEMBERS
+    std::vector<eds::SE3> poses;                                                    // :55 — what the reference's getFilteredPose reads
+#else
     std::vector<std::array<double, 7>> poses;   // :55 (eds::SE3 there): t[3], q xyzw[4] of every getTransform(bool&) call
+#endif
     double squared_norm_flow = 0.0;                                                 // :58
+
+    int last_status = EDS_OK;                   // of the last call that reached the library (hipLastStatus / hipLastError)
+    std::string last_error;
+    bool fail_(int rc, const char* where) { last_status = rc; last_error = std::string(where) + ": " + eds_last_error(); return false; }
 
     eds_trk* h = nullptr;
     int h_cap = 0, h_rows = 0, h_cols = 0;
@@ -216,23 +236,25 @@ class Tracker {
         c.function_tolerance = config.options.function_tolerance;
         return c;
     }
-    void ensure_handle(int N, int rows, int cols) {
+    bool ensure_handle(int N, int rows, int cols) {
         eds_trk_cfg c = make_cfg();
+        int rc;
         if (h && (h_cap < N || h_rows != rows || h_cols != cols)) { eds_trk_destroy(h); h = nullptr; }
         if (!h) {
             h_cap = std::max(N, 2048); h_rows = rows; h_cols = cols; device_kf_valid = false;
-            if (eds_trk_create(&c, 1, h_cap, rows, cols, &h) != EDS_OK) throw std::runtime_error(std::string("eds_trk_create: ") + eds_last_error());
+            if ((rc = eds_trk_create(&c, 1, h_cap, rows, cols, &h)) != EDS_OK) { h = nullptr; return fail_(rc, "eds_trk_create"); }
         } else {
             eds_trk_cfg cur;
             if (eds_trk_get_config(h, &cur) != EDS_OK || std::memcmp(&cur, &c, sizeof(c)) != 0)
-                if (eds_trk_set_config(h, &c) != EDS_OK) throw std::runtime_error(std::string("eds_trk_set_config: ") + eds_last_error());
+                if ((rc = eds_trk_set_config(h, &c)) != EDS_OK) return fail_(rc, "eds_trk_set_config");
         }
+        return true;
     }
     // The reference hands raw pointers to the functor on every call (Tracker.cpp:189-191) and re-reads the inverse depths
     // (Tracker.cpp:167).  Uploading 9 planes per call is the dominant cost of a live call, so the device copy is kept while the
     // KeyFrame vectors are byte-identical to what it was made from (one 100 KB memcmp); when only the inverse depths moved
     // (DepthPoints update between slices) only that plane goes up.
-    void upload_keyframe(int N, const std::vector<double>& idp, double fx, double fy, double cx, double cy) {
+    bool upload_keyframe(int N, const std::vector<double>& idp, double fx, double fy, double cx, double cy) {
         const size_t n2 = 2 * (size_t)N;
         const double K[4] = {fx, fy, cx, cy};
         const double* nc = &kf->norm_coord[0].x; const double* gr = &kf->grad[0].x; const double* w = kf->weights.data();
@@ -251,7 +273,7 @@ class Tracker {
             up_idp = idp;
         }
         device_kf_valid = (rc == EDS_OK);
-        if (rc != EDS_OK) throw std::runtime_error(std::string("libeds_hip: ") + eds_last_error());
+        return rc == EDS_OK ? true : fail_(rc, "eds_trk_set_keyframe");
     }
     void current_pose(double* t, double* q) const {
         const double n = std::sqrt(qx.x() * qx.x() + qx.y() * qx.y() + qx.z() * qx.z() + qx.w() * qx.w());   // Sophus::SE3(q, t) normalises
@@ -267,6 +289,7 @@ class Tracker {
         for (int i = 0; i < 3; ++i) T(i, 3) = t[i];
         return T;
     }
+#ifndef EDS_HIP_REFERENCE_MEMBERS
     // Tracker::getFilteredPose (Tracker.cpp:592-648) on the pose history, mean_filter_size = 3 (its default): the mean of the last
     // poses in the Lie algebra relative to the oldest rotation.  The reference accumulates into a function-static Vector6d that
     // is never reset (Tracker.cpp:611) — every call adds to what all earlier calls (of every Tracker) left there; the same
@@ -291,6 +314,7 @@ class Tracker {
         hipshim::quat_mul(q0, tq, q);
         return true;
     }
+#endif
 
   public:
     /** @brief Default constructor */
@@ -351,17 +375,21 @@ class Tracker {
 #endif
         if (N < 1 || (int)idp.size() != N || (int)kf->grad.size() != N || (int)kf->weights.size() != N ||
             event_frame->size() != (size_t)rows * cols) return false;                                                           // asserts at PhotometricError.hpp:70-73
-        ensure_handle(N, rows, cols);
-        upload_keyframe(N, idp, fx, fy, cx, cy);
-        if (eds_trk_set_event_frame(h, 0, event_frame->data()) != EDS_OK) throw std::runtime_error(std::string("libeds_hip: ") + eds_last_error());
+        // (a failure of the library underneath — no device, no memory, a HIP error — is reported the way the reference reports an
+        // unusable solution: false, nothing updated; hipLastStatus() / hipLastError() say what it was)
+        last_status = EDS_OK; last_error.clear();
+        if (!ensure_handle(N, rows, cols) || !upload_keyframe(N, idp, fx, fy, cx, cy)) return false;
+        int rc;
+        if ((rc = eds_trk_set_event_frame(h, 0, event_frame->data())) != EDS_OK) return fail_(rc, "eds_trk_set_event_frame");
         double p[3] = {px[0], px[1], px[2]}, q[4] = {qx.x(), qx.y(), qx.z(), qx.w()}, v[6];
         for (int i = 0; i < 6; ++i) v[i] = vx[i];
         eds_trk_info ti;
-        const int rc = eds_trk_optimize(h, 0, id, p, q, v, &ti);
+        std::memset(&ti, 0, sizeof(ti));
+        rc = eds_trk_optimize(h, 0, id, p, q, v, &ti);
         info.meas_time_us = ti.meas_time_us; info.num_points = ti.num_points; info.num_iterations = ti.num_iterations;           // Tracker.cpp:209-213
         info.time_seconds = ti.time_seconds; info.success = ti.success;
-        if (rc == EDS_ERR_NOT_USABLE) return false;                                                                             // Tracker.cpp:236-239
-        if (rc != EDS_OK) throw std::runtime_error(std::string("eds_trk_optimize: ") + eds_last_error());
+        if (rc == EDS_ERR_NOT_USABLE) { last_status = rc; last_error = "solution not usable"; return false; }                   // Tracker.cpp:236-239
+        if (rc != EDS_OK) return fail_(rc, "eds_trk_optimize");
         for (int i = 0; i < 3; ++i) px[i] = p[i];
         for (int i = 0; i < 4; ++i) qx.coeffs()[i] = q[i];
         for (int i = 0; i < 6; ++i) vx[i] = v[i];
@@ -381,6 +409,25 @@ class Tracker {
         return to_transform(t, q);
     }
     /** Tracker.cpp:251-260: records the pose, returns the mean-filtered one once 3 poses are in the history, identity before. */
+#ifdef EDS_HIP_REFERENCE_MEMBERS
+    ::base::Transform3d getTransform(bool& result) {        // the reference's own lines (Tracker.cpp:251-260), on its getFilteredPose
+        ::eds::SE3 se3(this->qx, this->px);
+        this->poses.push_back(se3);
+        result = this->getFilteredPose(se3);
+        base::Transform3d pose = base::Transform3d::Identity();
+        if (result) pose.matrix() = se3.matrix();
+        return pose;
+    }
+    // Declared here with the reference's signatures (Tracker.hpp:98-111), DEFINED by the EDS tree's own Tracker.cpp:378-648
+    // (header comment; tests/cpp/shim_reference_members.cpp is the compile-checked example of such a translation unit)
+    void trackPoints(const cv::Mat& event_frame, const uint16_t& patch_radius = 7);                                              // :98
+    void trackPointsPyr(const cv::Mat& event_frame, const size_t num_level = 3);                                                 // :100
+    std::vector<cv::Point2d> trackPointsAlongEpiline(const cv::Mat& event_frame, const uint16_t& patch_radius = 7,
+                                                     const int& border_type = cv::BORDER_DEFAULT, const uint8_t& border_value = 255);   // :102-103
+    cv::Mat getEMatrix();                                                                                                        // :105
+    cv::Mat getFMatrix();                                                                                                        // :107
+    bool getFilteredPose(eds::SE3& pose, const size_t& mean_filter_size = 3);                                                    // :111
+#else
     ::base::Transform3d getTransform(bool& result) {
         std::array<double, 7> cur;
         current_pose(cur.data(), cur.data() + 3);
@@ -389,6 +436,7 @@ class Tracker {
         result = filtered_pose(t, q);
         return result ? to_transform(t, q) : base::Transform3d::Identity();
     }
+#endif
     Eigen::Matrix<double, 6, 1>& getVelocity() { return vx; }                                                                    // Tracker.cpp:262-265
     const Eigen::Vector3d linearVelocity() { Eigen::Vector3d o; for (int i = 0; i < 3; ++i) o[i] = vx[i]; return o; }
     const Eigen::Vector3d angularVelocity() { Eigen::Vector3d o; for (int i = 0; i < 3; ++i) o[i] = vx[3 + i]; return o; }
@@ -421,17 +469,19 @@ class Tracker {
         const std::vector<double>& idp = kf->inv_depth;
 #endif
         if ((int)idp.size() != N || (int)kf->grad.size() != N || (int)kf->weights.size() != N) return coord;
-        ensure_handle(N, rows, cols);
-        upload_keyframe(N, idp, fx, fy, cx, cy);
+        last_status = EDS_OK; last_error.clear();
+        if (!ensure_handle(N, rows, cols) || !upload_keyframe(N, idp, fx, fy, cx, cy)) return coord;     // (empty: see the header's error convention)
         double p[3] = {px[0], px[1], px[2]}, q[4] = {qx.x(), qx.y(), qx.z(), qx.w()}, v[6];
         for (int i = 0; i < 6; ++i) v[i] = vx[i];
-        if (eds_trk_set_state(h, 0, p, q, v) != EDS_OK) throw std::runtime_error(std::string("eds_trk_set_state: ") + eds_last_error());
+        int rc;
+        if ((rc = eds_trk_set_state(h, 0, p, q, v)) != EDS_OK) { fail_(rc, "eds_trk_set_state"); return coord; }
         coord.resize(N);
         std::vector<double> tracks(2 * (size_t)N);
         std::vector<int32_t> kept(N);
         int n = 0;
-        if (eds_trk_update_points(h, 0, delete_out_point ? 1 : 0, &coord[0].x, tracks.data(), kept.data(), &n, &squared_norm_flow) != EDS_OK)
-            throw std::runtime_error(std::string("eds_trk_update_points: ") + eds_last_error());
+        if ((rc = eds_trk_update_points(h, 0, delete_out_point ? 1 : 0, &coord[0].x, tracks.data(), kept.data(), &n, &squared_norm_flow)) != EDS_OK) {
+            fail_(rc, "eds_trk_update_points"); coord.clear(); return coord;
+        }
         coord.resize(n);
         if (n != N) {                        // what repeated KeyFrame::erasePoint does (KeyFrame.cpp:1060-1106), in one sweep
 #ifdef EDS_HIP_WITH_EDS_TYPES
@@ -477,6 +527,9 @@ class Tracker {
         const double image_weight = (cols + rows) * weight_factor;
         return (image_weight * std::sqrt((float)squared_norm_flow) / (cols + rows)) > 1;
     }
+    /** Extensions: why the last optimize / getCoord returned false / nothing (EDS_OK and "" after a success). */
+    int hipLastStatus() const { return last_status; }
+    const std::string& hipLastError() const { return last_error; }
     /** Extension (the reference keeps it private, Tracker.hpp:58): the mean squared flow of the last getCoord. */
     double hipSquaredNormFlow() const { return squared_norm_flow; }
 };

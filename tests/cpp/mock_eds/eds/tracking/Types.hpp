@@ -38,6 +38,8 @@ struct Transform3d {
     static Transform3d Identity() { Transform3d t; for (int i = 0; i < 16; ++i) t.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return t; }
     double& operator()(int r, int c) { return m[4 * c + r]; }
     double operator()(int r, int c) const { return m[4 * c + r]; }
+    Transform3d& matrix() { return *this; }                         // Eigen::Transform::matrix(): the 4x4 it wraps
+    const Transform3d& matrix() const { return *this; }
     Transform3d inverse() const {           // rigid inverse
         Transform3d o = Identity();
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) o(r, c) = (*this)(c, r);
@@ -46,7 +48,7 @@ struct Transform3d {
     }
 };
 }  // namespace base
-namespace cv { struct Point2d { double x, y; }; }
+namespace cv { struct Point2d { double x, y; }; enum { BORDER_DEFAULT = 4 }; }
 namespace cv {
 struct Mat {                                 // kf->img.rows / cols, kf->K_ref.at<double>(r, c)
     int rows = 0, cols = 0;
@@ -54,3 +56,24 @@ struct Mat {                                 // kf->img.rows / cols, kf->K_ref.a
     template <class T> T& at(int r, int c) { return reinterpret_cast<T&>(d[(size_t)r * cols + c]); }
 };
 }
+// Sophus::SE3d as the reference uses it (tracking/Types.hpp:76 `typedef Sophus::SE3d SE3`): built from (quaternion, translation),
+// read back through unit_quaternion() / translation() / matrix()
+namespace eds {
+struct SE3 {
+    Eigen::Quaterniond q_ = Eigen::Quaterniond::Identity();
+    Eigen::Vector3d t_ = Eigen::Vector3d::Zero();
+    SE3() {}
+    SE3(const Eigen::Quaterniond& q, const Eigen::Vector3d& t) : q_(q), t_(t) {}
+    const Eigen::Quaterniond& unit_quaternion() const { return q_; }
+    const Eigen::Vector3d& translation() const { return t_; }
+    base::Transform3d matrix() const {
+        base::Transform3d T = base::Transform3d::Identity();
+        const double x = q_.x(), y = q_.y(), z = q_.z(), w = q_.w();
+        T(0, 0) = 1 - 2 * (y * y + z * z); T(0, 1) = 2 * (x * y - z * w);     T(0, 2) = 2 * (x * z + y * w);
+        T(1, 0) = 2 * (x * y + z * w);     T(1, 1) = 1 - 2 * (x * x + z * z); T(1, 2) = 2 * (y * z - x * w);
+        T(2, 0) = 2 * (x * z - y * w);     T(2, 1) = 2 * (y * z + x * w);     T(2, 2) = 1 - 2 * (x * x + y * y);
+        for (int i = 0; i < 3; ++i) T(i, 3) = t_[i];
+        return T;
+    }
+};
+}  // namespace eds

@@ -3,11 +3,38 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../slam-eds_amd/csrc/Tracker.hpp"
 
+// `shim_demo --no-device`: the error convention.  A tracker pointed at a device that does not exist must behave like the reference's
+// class, which has no exceptions on this path: optimize returns false and leaves its outputs alone, getCoord returns nothing — and
+// hipLastStatus() / hipLastError() say why.  Runs anywhere (no GPU needed).
+static int no_device_mode() {
+    auto kf = std::make_shared<eds::tracking::KeyFrame>();
+    const int N = 300, H = 48, W = 64;
+    kf->norm_coord.assign(N, cv::Point2d{0.01, -0.02}); kf->grad.assign(N, cv::Point2d{1.0, 0.5}); kf->weights.assign(N, 1.0); kf->inv_depth.assign(N, 0.5);
+    kf->rows = H; kf->cols = W; kf->K_ref[0] = kf->K_ref[4] = 50.0; kf->K_ref[2] = 31.5; kf->K_ref[5] = 23.5;
+    std::vector<double> frame((size_t)H * W, 0.01);
+    eds::tracking::Config cfg;
+    eds::tracking::Tracker tracker(kf, cfg);
+    tracker.hip.device = 1 << 20;                                       // no such device
+    base::Transform3d T = base::Transform3d::Identity();
+    T(0, 3) = 42.0;
+    bool threw = false, good = true;
+    size_t ncoord = 1;
+    try {
+        good = tracker.optimize(0, &frame, T, eds::tracking::MAD);
+        ncoord = tracker.getCoord(false).size();
+    } catch (...) { threw = true; }
+    std::printf("{\"threw\": %d, \"good\": %d, \"status\": %d, \"T_untouched\": %d, \"coords\": %zu, \"message\": \"%s\"}\n", threw ? 1 : 0,
+                good ? 1 : 0, tracker.hipLastStatus(), T(0, 3) == 42.0 ? 1 : 0, ncoord, tracker.hipLastError().empty() ? "" : "set");
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--no-device") return no_device_mode();
     if (argc < 2) { std::fprintf(stderr, "usage: shim_demo <alignment.bin> [num_threads] [loss 0|1|2] [iters]\n"); return 2; }
     FILE* f = std::fopen(argv[1], "rb");
     if (!f) return 2;

@@ -6,6 +6,7 @@
 // signature drifts (value instead of reference, a const member, base::Vector6d where the reference has Eigen::Matrix<double,6,1>)
 // no longer converts and the build breaks.
 #define EDS_HIP_WITH_EDS_TYPES
+#define EDS_HIP_REFERENCE_MEMBERS          // the six out-of-path members declared with the reference's signatures (Tracker.hpp:98-111)
 #include <type_traits>
 
 #include "../../slam-eds_amd/csrc/Tracker.hpp"
@@ -52,6 +53,15 @@ std::vector<cv::Point2d> (T::*p_coord)(const bool&) = &T::getCoord;
 // :113
 bool (T::*p_need)(const double&) = &T::needNewKeyframe;
 
+// :98-111 — the members OUTSIDE the hot path, declared by the shim so that the reference's own definitions (Tracker.cpp:378-648) compile
+// against it unchanged and callers relink unchanged; tests/cpp/shim_reference_members.cpp is such a translation unit
+void (T::*p_track)(const cv::Mat&, const uint16_t&) = &T::trackPoints;                                                     // :98
+void (T::*p_track_pyr)(const cv::Mat&, const size_t) = &T::trackPointsPyr;                                                 // :100
+std::vector<cv::Point2d> (T::*p_track_epi)(const cv::Mat&, const uint16_t&, const int&, const uint8_t&) = &T::trackPointsAlongEpiline;   // :102-103
+cv::Mat (T::*p_emat)() = &T::getEMatrix;                                                                                   // :105
+cv::Mat (T::*p_fmat)() = &T::getFMatrix;                                                                                   // :107
+bool (T::*p_filt)(eds::SE3&, const size_t&) = &T::getFilteredPose;                                                         // :111
+
 // :58 squared_norm_flow is private in the reference: it must not be reachable as a public data member here either
 template <class U, class = void> struct has_public_sq_flow : std::false_type {};
 template <class U> struct has_public_sq_flow<U, decltype(void(std::declval<U&>().squared_norm_flow))> : std::true_type {};
@@ -80,5 +90,11 @@ int shim_eds_types_check(std::shared_ptr<eds::tracking::KeyFrame> kf, const std:
     const eds::tracking::TrackerInfo info = a.getInfo();
     (void)p_reset1; (void)p_reset2; (void)p_set; (void)p_opt1; (void)p_opt2; (void)p_opt3; (void)p_gt0; (void)p_gt1; (void)p_vel; (void)p_lin;
     (void)p_ang; (void)p_lp; (void)p_coord; (void)p_info; (void)p_need;
+    (void)p_track; (void)p_track_pyr; (void)p_track_epi; (void)p_emat; (void)p_fmat; (void)p_filt;
+    cv::Mat ef;
+    a.trackPoints(ef); a.trackPointsPyr(ef); (void)a.trackPointsAlongEpiline(ef);       // the reference's default arguments (:98-103)
+    eds::SE3 fp;
+    filtered = a.getFilteredPose(fp) || filtered;                                       // default mean_filter_size = 3 (:111)
+    (void)a.getEMatrix(); (void)a.getFMatrix();
     return (int)ok + (int)filtered + (int)a.needNewKeyframe() + (int)lp.size() + (int)c.size() + info.num_iterations + (int)(lv[0] + av[0]);
 }

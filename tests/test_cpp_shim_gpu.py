@@ -95,3 +95,43 @@ def test_shim_eds_types_branch_compiles_against_mock_headers():
     res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(HERE, "cpp", "mock_eds"), src],
                          capture_output=True, text=True)
     assert res.returncode == 0, res.stderr
+
+
+def test_shim_reports_failures_as_false_not_as_exceptions(capi):
+    """Reference path: no exceptions (Tracker.cpp:104-241 returns bool).  The shim maps every failure of the library underneath to
+    `false` / an empty vector and keeps status + message (hipLastStatus / hipLastError).  Runs without a GPU: the device does not exist."""
+    exe = build_demo(capi)
+    res = subprocess.run([exe, "--no-device"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    r = json.loads(res.stdout.strip().splitlines()[-1])
+    status = r.pop("status")
+    assert status in (capi.ERR_NO_DEVICE, capi.ERR_INVALID)           # no device at all (this container) / ordinal out of range (a GPU box)
+    assert r == {"threw": 0, "good": 0, "T_untouched": 1, "coords": 0, "message": "set"}
+    assert "throw" not in open(os.path.join(ROOT, "slam-eds_amd", "csrc", "Tracker.hpp")).read().split("#pragma once")[1]
+
+
+def test_reference_members_unit_links_against_the_shim(tmp_path, capi):
+    """EDS_HIP_REFERENCE_MEMBERS: the shim declares trackPoints, trackPointsPyr, trackPointsAlongEpiline, getEMatrix, getFMatrix and
+    getFilteredPose with the reference's signatures (pinned in shim_eds_types_check.cpp) and a translation unit of the EDS tree defines
+    them (tests/cpp/shim_reference_members.cpp stands in for the reference's Tracker.cpp:378-648): both compile against the mock EDS
+    types and link into one object — every member declared is defined exactly once, the private members the reference bodies touch are
+    reachable under the reference's names."""
+    inc = os.path.join(HERE, "cpp", "mock_eds")
+    objs = []
+    for name in ("shim_eds_types_check", "shim_reference_members"):
+        o = str(tmp_path / (name + ".o"))
+        res = subprocess.run(["g++", "-std=c++17", "-fPIC", "-Wall", "-c", "-I", inc, os.path.join(HERE, "cpp", name + ".cpp"), "-o", o], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        objs.append(o)
+    so = str(tmp_path / "libshim_check.so")
+    res = subprocess.run(["g++", "-shared", "-Wl,--no-undefined", "-o", so] + objs + ["-L", capi.CSRC, "-leds_hip", "-Wl,-rpath," + capi.CSRC], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    syms = subprocess.run(["nm", "-C", "--defined-only", so], capture_output=True, text=True).stdout
+    for m in ("trackPoints(", "trackPointsPyr(", "trackPointsAlongEpiline(", "getEMatrix()", "getFMatrix()", "getFilteredPose("):
+        assert f"eds::tracking::Tracker::{m}" in syms, m
+    # without the switch the six are not declared at all (an EDS tree that calls them must opt in)
+    probe = tmp_path / "probe.cpp"
+    probe.write_text('#define EDS_HIP_WITH_EDS_TYPES\n#include "' + os.path.join(ROOT, "slam-eds_amd", "csrc", "Tracker.hpp") +
+                     '"\ncv::Mat f(eds::tracking::Tracker& t) { return t.getEMatrix(); }\n')
+    res = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", inc, str(probe)], capture_output=True, text=True)
+    assert res.returncode != 0 and "getEMatrix" in res.stderr
