@@ -1,0 +1,52 @@
+/* eds_hip_rccl.h — the ONE collective of the path for a C / C++ caller: all-gather of the per-alignment result rows over RCCL / xGMI.
+ *
+ * Independent (keyframe, event-frame) alignments shard across GPUs with no data-path collective (the reference has no
+ * distributed layer: one eds::tracking::Tracker per (keyframe, frame) pair, src/tracking/Tracker.hpp:40-58, driven from src/EDS.h:24-69):
+ * alignment b of `total` belongs to rank b / ceil(total / nranks), every rank solves its shard through include/eds_hip.h, and the
+ * 16-double rows eds_trk_get_results hands out (p[3] q[4] v[6] cost iterations status) are gathered ONCE into the table every rank
+ * holds.  This header is that gather — no Python, no torch: a separate small library, libeds_hip_rccl.so, so that libeds_hip.so itself
+ * keeps no RCCL dependency (RCCL is 570 MB to load and an integrator without a second GPU never needs it).
+ *
+ *   the Python side of the same step: slam-eds_amd/batch.py ResultGatherer (torch.distributed, backend "nccl" = RCCL) — same
+ *   partition (eds_gather_shard == batch.shard_range), same padding to the common shard size, same table.
+ *
+ * The communicator is the CALLER's (ncclCommInitRank / ncclCommInitAll: the component that owns the process layout owns the
+ * rendezvous) and is passed as an opaque pointer, as is the stream the collective is queued on (hipStream_t; NULL: a stream the
+ * context creates for itself).  Plain pointers and sizes otherwise; every function returns 0 or a negative eds_status-like code
+ * (-1 invalid argument, -2 HIP or RCCL failure: eds_gather_last_error()).
+ */
+#ifndef EDS_HIP_RCCL_H_
+#define EDS_HIP_RCCL_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDS_GATHER_ROW 16          /* doubles per alignment: eds_trk_get_results' row */
+
+typedef struct eds_gather eds_gather;       /* opaque: staging buffers, device buffers, a stream and an event, allocated once */
+
+const char* eds_gather_last_error(void);    /* thread-local message of the last failure of this library */
+
+/* contiguous shard [first, first + count) of `total` alignments for `rank` of `nranks` (the same rule everywhere: batch.py shard_range) */
+void eds_gather_shard(int total, int nranks, int rank, int* first, int* count);
+
+/* One-shot form (Next #3c): all-gather this rank's `count` rows (HOST memory, row-major [count][16]) into `table`
+ * (HOST memory, [total][16]; every rank receives all rows, in alignment order).  nccl_comm: ncclComm_t; hip_stream: hipStream_t or
+ * NULL.  Blocks until the table is complete.  `count` must be this rank's shard size by eds_gather_shard. */
+int eds_gather_results(void* nccl_comm, void* hip_stream, const double* local, int count, double* table, int total);
+
+/* The same with everything it needs allocated ONCE, and split so that the collective of step k overlaps the solve of step k + 1
+ * (what bench.py's sharded step does through torch): start queues copy-in -> ncclAllGather -> copy-out on the context's stream and
+ * returns; finish waits for it and copies the table out (table may be NULL on ranks that only take part). */
+int  eds_gather_create(void* nccl_comm, void* hip_stream, int total, eds_gather** out);
+int  eds_gather_start(eds_gather* g, const double* local, int count);
+int  eds_gather_finish(eds_gather* g, double* table);
+void eds_gather_destroy(eds_gather* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EDS_HIP_RCCL_H_ */

@@ -56,6 +56,7 @@ class ResultGatherer:
             self.d_in = torch.zeros((self.per, RESULT_WIDTH), dtype=torch.float64, device=device)
             self.d_out = torch.zeros((self.world * self.per, RESULT_WIDTH), dtype=torch.float64, device=device)
             self.stream = torch.cuda.Stream(device=device)
+            self.stream.wait_stream(torch.cuda.current_stream(device))      # the zero-fills above ran on the current stream: order them first
             self.event = torch.cuda.Event()
         self._in_np = self.h_in.numpy()
 

@@ -117,8 +117,13 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
     srcs.append(os.path.join(_HERE, "..", "include", "eds_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    rccl_lib = os.path.join(CSRC, "libeds_hip_rccl.so")       # include/eds_hip_rccl.h: the RCCL gather for a C / C++ caller (its own library)
+    rccl_src = [os.path.join(CSRC, "eds_gather.hip"), os.path.join(_HERE, "..", "include", "eds_hip_rccl.h")]
+    stale_rccl = (not os.path.exists(rccl_lib)) or any(os.path.getmtime(s) > os.path.getmtime(rccl_lib) for s in rccl_src)
     if force or stale:
         subprocess.check_call(["make", "-C", CSRC, "-j4", "-s", "libeds_hip.so"])
+    if force or stale_rccl:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "libeds_hip_rccl.so"])
     return LIB_PATH
 
 
