@@ -50,6 +50,18 @@ BYTES_REF12 = {"credited": {"bicubic": 196, "bilinear": 148},      # §8d 12-DoF
 PARITY_TOL = 1e-4                                    # SE(3) distance to the oracle's solved pose
 
 
+def _gen_alignment(args):
+    """Pool worker (spawned interpreter, never touches the GPU): one synthetic alignment reduced to what the bench keeps — the keyframe,
+    the start, the truth, and the frame as fp32 (the first KEEP_WHOLE also keep the fp64 frame: parity rows and CPU baselines)."""
+    seed, H, W, N, keep_frame = args
+    synth = importlib.import_module("slam-eds_amd.synth")
+    x = synth.make_alignment(seed, H=H, W=W, N=N)
+    f32 = np.ascontiguousarray(x.frame, dtype=np.float32)
+    if not keep_frame:
+        x.frame = None
+    return x, f32
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +77,8 @@ def parse():
     ap.add_argument("--no-ref12", dest="no_ref12", action="store_true", help="skip the informational REF12 measurement")
     ap.add_argument("--lambda0", type=float, default=0.01, help="initial LM6 damping (DSO template: 0.01)")
     ap.add_argument("--exec", dest="exec_", choices=["device", "host"], default="device")
-    ap.add_argument("--distinct", type=int, default=256, help="distinct synthetic alignments (replicated to fill the batch)")
+    ap.add_argument("--distinct", type=int, default=4096, help="distinct synthetic alignments (replicated to fill the batch); the default makes every "
+                    "alignment of the 4 096-slot batch its own (seeds 5000 + b)")
     ap.add_argument("--no-configs", dest="no_configs", action="store_true", help="skip the block of the other BASELINE.json configs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -400,6 +413,62 @@ def configs_block(capi, synth, a):
     return out
 
 
+def strong_scaling_config4(capi, synth, batchmod, a, rank, world, local_rank, dev, forced, dist, torch, steps=20, warmup=3):
+    """BASELINE.json configs[4] LITERALLY, as a strong-scaling figure beside the weak-scaling `value` (Next #3b): 64 alignments
+    in all (seeds 5000 + b), 64 / N per GPU, one launch per rank and step, then the all-gather of the 64 rows — ms per step including the
+    gather, MAX over ranks, bracketed by barrier + synchronize like the headline.  With 8 GPUs every rank holds 8 alignments: the
+    latency regime (4 CUs per alignment), so the curve is expected to be nearly flat — the step is one ~60-70 us solve whatever N."""
+    TOTAL = 64
+    first, count = batchmod.shard_range(TOTAL, world, rank)
+    als = [synth.make_alignment(5000 + b, H=a.height, W=a.width, N=a.points) for b in range(first, first + count)]
+    cfg = capi.default_config(device=local_rank if world > 1 else 0, solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0,
+                              sampling=capi.SAMPLE_BICUBIC if a.sampling == "bicubic" else capi.SAMPLE_BILINEAR)
+    h = capi.Handle(cfg, max(1, count), a.points, a.height, a.width)
+    for i, x in enumerate(als):
+        h.set_alignment(i, x)
+    P0 = np.stack([x.p0 for x in als]) if count else np.zeros((0, 3))
+    Q0 = np.stack([x.q0 for x in als]) if count else np.zeros((0, 4))
+    V0 = np.stack([x.v0 for x in als]) if count else np.zeros((0, 6))
+    g = batchmod.ResultGatherer(TOTAL, device=dev, to_host=(rank == 0), force=forced)
+
+    def step():
+        if count:
+            h.set_states(0, P0, Q0, V0)
+            h.optimize_batch(0, 0, count, sync=True)
+        g.start(h.results(0, count) if count else np.zeros((0, batchmod.RESULT_WIDTH)))
+        return g.finish()
+
+    for _ in range(warmup):
+        table = step()
+    if world > 1 or forced:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        table = step()
+    torch.cuda.synchronize()
+    if world > 1 or forced:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1 or forced:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    launch = h.last_launch() if count else None
+    k_us = h.info(0)["device_time_us"] if count else 0.0
+    h.close()
+    if rank != 0:
+        return None
+    its = float(np.mean(table[:, 14]))
+    return {"workload": f"BASELINE.json configs[4]: {TOTAL} alignments in all (seeds 5000..5063) x {a.points} points on {a.width}x{a.height}, {a.iters} LM6 iterations, "
+                        f"{-(-TOTAL // world)} per GPU, one all-gather of 16 doubles per alignment per step",
+            "scaling": "strong", "n_gpus": world, "alignments_total": TOTAL, "alignments_per_gpu": -(-TOTAL // world), "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * el / steps, "iterations_per_s": TOTAL * its / (el / steps), "alignments_per_s": TOTAL / (el / steps),
+            "kernel": launch["kernel"] if launch else None, "cus_per_alignment": launch["cus_per_alignment"] if launch else None, "kernel_ms_rank0": k_us * 1e-3,
+            "success_fraction": float(np.mean(table[:, 15])), "rows_gathered": int(table.shape[0]),
+            "note": "strong scaling (total work fixed): informational beside `value`, which is weak scaling at 4 096 alignments per GPU"}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N ranks as CHILD processes (torch.distributed.run) before this
     process has made any HIP / torch.cuda call — a process that has initialised the GPU must never exec or be re-used as a
@@ -436,6 +505,19 @@ def main():
     # torch stream's all-gather with the library stream's solve and all_gather_into_tensor on a device tensor run on the hardware
     # before the multi-GPU node sees them.  Same workload, same metric; the JSON line says "forced_dist": true.
     forced = world == 1 and os.environ.get("EDS_BENCH_FORCE_DIST") == "1"
+    if world > 1 and backend == "nccl" and torch.cuda.device_count() < world:      # device_count() does not initialise the GPU
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         f"(one rank per GPU: RCCL refuses two ranks on one device)")
+    # Input generation starts HERE, in spawned worker processes, before this process touches the GPU (a process that has initialised
+    # HIP starts no children): 4 096 distinct alignments are ~10 minutes of numpy on one core, seconds on the host's cores.
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    KEEP_WHOLE = 64
+    distinct = min(a.distinct, a.batch)
+    t_gen = time.perf_counter()
+    gen_pool = ProcessPoolExecutor(max_workers=max(4, min(64, (os.cpu_count() or 8) // max(world, 1))), mp_context=multiprocessing.get_context("spawn"))
+    gen_jobs = [gen_pool.submit(_gen_alignment, (5000 + ((rank * a.batch + i) % max(distinct * world, 1)), a.height, a.width, a.points, i < KEEP_WHOLE))
+                for i in range(distinct)]
     if forced:
         import socket
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
@@ -443,9 +525,6 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1:
-        if backend == "nccl" and torch.cuda.device_count() < world:      # device_count() does not initialise the GPU
-            raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
-                             f"(one rank per GPU: RCCL refuses two ranks on one device)")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -458,27 +537,30 @@ def main():
     synth = importlib.import_module("slam-eds_amd.synth")
     batchmod = importlib.import_module("slam-eds_amd.batch")
     if capi.device_count() < 1:
+        gen_pool.shutdown(wait=False, cancel_futures=True)
         raise SystemExit("bench.py needs a GPU: libeds_hip has no CPU fallback")
 
     B, N, H, W = a.batch, a.points, a.height, a.width
     total = B * world
     # BASELINE.json configs[4] seeds: 5000 + b for alignment b; `distinct` of them, replicated
-    first_global = rank * B
-    distinct = min(a.distinct, B)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(min(32, os.cpu_count() or 1)) as ex:        # numpy releases the GIL in the heavy parts (splat, blur, noise)
-        als = list(ex.map(lambda i: synth.make_alignment(5000 + ((first_global + i) % max(distinct * world, 1)), H=H, W=W, N=N), range(distinct)))
     cfg = capi.default_config(device=local_rank if world > 1 else 0,
                               sampling=capi.SAMPLE_BICUBIC if a.sampling == "bicubic" else capi.SAMPLE_BILINEAR,
                               solver=capi.SOLVER_LM6 if a.solver == "lm6" else capi.SOLVER_GN6,
                               exec=capi.EXEC_DEVICE if a.exec_ == "device" else capi.EXEC_HOST,
                               max_num_iterations=a.iters, lambda0=a.lambda0)
     h = capi.Handle(cfg, B, N, H, W)
-    frames32 = [np.ascontiguousarray(x.frame, dtype=np.float32) for x in als]
-    for b in range(B):                               # every slot owns its copy in HBM
-        x = als[b % distinct]
-        h.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy)
-        h.set_event_frame(b, frames32[b % distinct])
+    # Every distinct alignment arrives from the generation pool (started before the GPU was touched), is handed to its slot(s) and kept
+    # as keyframe + fp32 frame: 4 096 distinct ones would otherwise hold 15 GB of fp64 frames on the host.
+    als, frames32 = [], []
+    for i, job in enumerate(gen_jobs):
+        x, f32 = job.result()
+        for b in range(i, B, distinct):              # every slot owns its copy in HBM
+            h.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy)
+            h.set_event_frame(b, f32)
+        als.append(x); frames32.append(f32)
+    gen_pool.shutdown()
+    t_gen = time.perf_counter() - t_gen
     # the contract's timed region starts with the inputs resident: the frames' strip copies (csrc/eds_layout.hpp) are part of that.  Left
     # to itself the library makes them when a frame is solved a SECOND time (they cost more than one solve gains: eds_strips.hip), which
     # the warm-up steps would trigger as well; made explicitly here so that no --warmup value moves them into the timed steps.  Their
@@ -547,6 +629,10 @@ def main():
     ms_per_step = 1e3 * elapsed / a.steps
     iters_done = float(np.mean(table[:, 14])) if rank == 0 else 0.0      # only rank 0 holds the gathered table
     value = total * iters_done / (ms_per_step * 1e-3)
+
+    strong = None
+    if a.exec_ == "device" and a.solver == "lm6" and not a.no_configs:           # every rank takes part
+        strong = strong_scaling_config4(capi, synth, batchmod, a, rank, world, local_rank, dev, forced, dist, torch)
 
     out = None
     if rank == 0:
@@ -636,6 +722,21 @@ def main():
                     "note": "NOT the headline (whose inputs are resident, strip copies included): every solve on a frame the GPU has not solved before. "
                             "The library's own rule (eds_strips.hip) uses the 4x4 tiles for such a solve — the copies pay from the ~12th solve of a frame — "
                             "so this is the rate a stream of new event frames gets; the second figure is what making the copies for every frame would give"}
+                # ... promoted next to `value` (Next #1): the reference's own call pattern is ONE optimize per event frame
+                # (Tracker.cpp:104), so this — not the resident-input headline — is the rate a stream of new event frames gets
+                nf_ms = float(np.median(n_dev[1:]))
+                nf_ach = B * N * passes * per_pt / (nf_ms * 1e-3) / 1e9
+                nf_mm = B * N * passes * BYTES_MUST_MOVE[a.sampling] / (nf_ms * 1e-3) / 1e9
+                out["value_new_frame_per_solve"] = out["new_frame_per_solve"]["iterations_per_s"]
+                out["roofline_new_frame_per_solve"] = {"kernel": nk, "bound": "hbm", "achieved": nf_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nf_ach / HBM_PEAK_GBS,
+                                                       "achieved_must_move": nf_mm, "frac_must_move": nf_mm / HBM_PEAK_GBS, "traffic": None, "kernel_ms": nf_ms,
+                                                       "frame_layout": "4x4 tiles", "algorithmic_bytes_per_launch": B * N * passes * per_pt}
+                t_nf = pmc_traffic(nk, a)
+                if t_nf:
+                    out["roofline_new_frame_per_solve"]["traffic"], out["roofline_new_frame_per_solve"]["traffic_source"] = t_nf["bytes"], t_nf["source"]
+        if strong is not None:
+            out["strong_scaling_config4"] = strong
+        out["input_generation_s"] = t_gen
         if a.exec_ == "device":
             out["launch_digest"] = dict(launch_digest, note="the timed kernel's last launch, from its workgroups' own begin / end stamps: covered = sum of "
                                         "workgroup durations / (256 CUs x span); tail_idle_us = mean idle time of a CU behind its last workgroup")
@@ -698,8 +799,14 @@ def main():
                 for k in range(3):
                     h.set_states(0, p0, q0, v0)
                     t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); n_ms.append(1e3 * (time.perf_counter() - t1))
+                nk_ms = h.info(0)["device_time_us"] * 1e-3
                 out["reference_problem"]["new_frame_per_solve"] = {"lm_iterations_per_s": B * float(np.mean(h.results(0, B)[:, 14])) / (float(np.median(n_ms[1:])) * 1e-3),
-                                                                   "kernel_ms": h.info(0)["device_time_us"] * 1e-3, "kernel": h.last_launch()["kernel"]}
+                                                                   "kernel_ms": nk_ms, "kernel": h.last_launch()["kernel"],
+                                                                   "frac": B * N * r_evals * r_cred / (nk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                                   "frac_must_move": B * N * r_evals * r_mm / (nk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                tn = pmc_traffic(h.last_launch()["kernel"], a)
+                if tn:
+                    out["reference_problem"]["new_frame_per_solve"]["traffic"] = tn["bytes"]
             finally:
                 h.set_knob("EDS_FUSED_LAYOUT", None)
             t = pmc_traffic(k12, a)

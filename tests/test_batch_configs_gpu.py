@@ -96,30 +96,82 @@ def test_bench_shape_kernel_selected_by_optimize(gpu, capi, synth, po, als64):
         a = als64[b % D]
         h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
         h.set_event_frame(b, fr[b % D])
-    h.set_states(0, np.stack([als64[b % D].p0 for b in range(B)]), np.stack([als64[b % D].q0 for b in range(B)]),
-                 np.stack([als64[b % D].v0 for b in range(B)]))
-    h.optimize_batch(0, 0, B)
-    table = h.results(0, B)
-    assert np.all(table[:, 15] == 1.0)
-    worst = 0.0
+    S0 = (np.stack([als64[b % D].p0 for b in range(B)]), np.stack([als64[b % D].q0 for b in range(B)]), np.stack([als64[b % D].v0 for b in range(B)]))
+    refs = []
     for d in range(D):
         a = als64[d]
         # the frame was handed over as fp32 (bench.py does the same): the oracle sees the same fp32-rounded frame
         a32 = synth.Alignment(**{**a.__dict__, "frame": fr[d].astype(np.float64)})
         ref = po.Oracle(a32).pose6_lm(a.p0, a.q0, a.v0, iters=10, lambda0=cfg.lambda0)
-        for slot in (d, d + B - D):                                        # first and last replica of this alignment
-            dist = po.se3_distance(table[slot, 0:3], table[slot, 3:7], ref["p"], ref["q"])
-            worst = max(worst, dist)
-            assert dist <= TOL_POSE, (slot, dist)
-            assert np.array_equal(h.trace(slot)["accepted"], ref["accepted"]), slot
-            assert table[slot, 14] == ref["iterations"]
-        r = h.residuals(d)
-        e = po.Oracle(a32).pose6_eval(ref["p"], ref["q"], a.v0)
-        assert np.abs(r - e["r"]).max() <= 2e-5 * np.abs(e["r"]).max()      # residuals at the solution (Tracker.cpp:223-230)
-    # replicas of one alignment must agree bit for bit (same inputs, same kernel, no cross-slot state)
-    for slot in range(D, B):
-        assert np.array_equal(table[slot, 0:7], table[slot % D, 0:7]), slot
+        refs.append((a32, ref, po.Oracle(a32).pose6_eval(ref["p"], ref["q"], a.v0)))
+    worst = 0.0
+    tables = []
+    # the FIRST solve of these frames samples the tiles they were written in (what a live tracker runs), the SECOND one — the same
+    # frames again — their strip copies: the headline instantiation <0, 4, 512, 3, 1>.  Both against the oracle, row by row.
+    for kernel, layout in (("eds_fused6_kernel<0, 4, 512, 1, 1>", 1), ("eds_fused6_kernel<0, 4, 512, 3, 1>", 2)):
+        h.set_states(0, *S0)
+        h.optimize_batch(0, 0, B)
+        li = h.last_launch()
+        assert li["kernel"] == kernel and li["layout"] == layout and li["cus_per_alignment"] == 1, li
+        table = h.results(0, B)
+        tables.append(table.copy())
+        assert np.all(table[:, 15] == 1.0)
+        for d in range(D):
+            a = als64[d]
+            a32, ref, e = refs[d]
+            for slot in (d, d + B - D):                                        # first and last replica of this alignment
+                dist = po.se3_distance(table[slot, 0:3], table[slot, 3:7], ref["p"], ref["q"])
+                worst = max(worst, dist)
+                assert dist <= TOL_POSE, (kernel, slot, dist)
+                assert np.array_equal(h.trace(slot)["accepted"], ref["accepted"]), (kernel, slot)
+                assert table[slot, 14] == ref["iterations"]
+            r = h.residuals(d)
+            assert np.abs(r - e["r"]).max() <= 2e-5 * np.abs(e["r"]).max()      # residuals at the solution (Tracker.cpp:223-230)
+        # replicas of one alignment must agree bit for bit (same inputs, same kernel, no cross-slot state)
+        for slot in range(D, B):
+            assert np.array_equal(table[slot, 0:7], table[slot % D, 0:7]), (kernel, slot)
+    assert np.abs(tables[0][:, :7] - tables[1][:, :7]).max() < 1e-6 and np.array_equal(tables[0][:, 14], tables[1][:, 14])
     print(f"bench shape, {B} alignments in one launch: worst SE(3) distance to the oracle {worst:.2e}")
+    h.close()
+
+
+def test_ref12_batch_kernels_at_the_bench_shape_vs_oracle(gpu, capi, synth, po, als64):
+    """The reference problem on a batch (two alignments per CU: eds_fused12_kernel<0, 256, 320, false, 1, Q>) at 640x480 / 2 000 points,
+    320 alignments in one launch: a first solve on new frames (the lane gather on the tiles below 1 024 alignments), the same frames again
+    (Q = 2: the quad gather on their strip copies — the instantiation bench.py's REF12 leg times).  Iteration counts, successful steps,
+    termination, pose, velocity and cost of 16 distinct alignments in two slots each against the oracle's Ceres-LM restatement."""
+    B, D = 320, 16
+    cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=1)
+    h = capi.Handle(cfg, B, 2000, 480, 640)
+    fr = [np.ascontiguousarray(a.frame, dtype=np.float32) for a in als64[:D]]
+    for b in range(B):
+        a = als64[b % D]
+        h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+        h.set_event_frame(b, fr[b % D])
+    S0 = (np.stack([als64[b % D].p0 for b in range(B)]), np.stack([als64[b % D].q0 for b in range(B)]), np.stack([als64[b % D].v0 for b in range(B)]))
+    refs = []
+    for d in range(D):
+        a = als64[d]
+        a32 = synth.Alignment(**{**a.__dict__, "frame": fr[d].astype(np.float64)})
+        refs.append(po.Oracle(a32, num_blocks=1, max_num_iterations=10).solve_lm(a.p0, a.q0, a.v0))
+    tabs = []
+    for kernel, layout in (("eds_fused12_kernel<0, 256, 320, false, 1, 0>", 1), ("eds_fused12_kernel<0, 256, 320, false, 1, 2>", 2)):
+        h.set_states(0, *S0)
+        h.optimize_batch(0, 0, B)
+        li = h.last_launch()
+        assert li["kernel"] == kernel and li["layout"] == layout, li
+        tab = h.results(0, B)
+        tabs.append(tab.copy())
+        for d in range(D):
+            ref = refs[d]
+            for slot in (d, d + B - D):
+                info = h.info(slot)
+                assert info["num_iterations"] == ref["num_iterations"] and info["num_successful_steps"] == ref["num_successful_steps"], (kernel, slot)
+                assert info["termination"] == ref["termination"] and bool(info["success"]) == ref["usable"]
+                assert po.se3_distance(tab[slot, 0:3], tab[slot, 3:7], ref["p"], ref["q"]) <= TOL_POSE, (kernel, slot)
+                assert np.abs(tab[slot, 7:13] - ref["v"]).max() <= 1e-4
+                assert info["final_cost"] == pytest.approx(ref["final_cost"], rel=1e-4)
+    assert np.abs(tabs[0][:, :13] - tabs[1][:, :13]).max() < 1e-5
     h.close()
 
 
