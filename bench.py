@@ -515,9 +515,16 @@ def main():
     KEEP_WHOLE = 64
     distinct = min(a.distinct, a.batch)
     t_gen = time.perf_counter()
-    gen_pool = ProcessPoolExecutor(max_workers=max(4, min(64, (os.cpu_count() or 8) // max(world, 1))), mp_context=multiprocessing.get_context("spawn"))
+    # (the workers inherit the environment at spawn: ONE BLAS / OpenMP thread each — 64 interpreters with a 256-thread OpenBLAS pool apiece
+    # spend their time spinning: 158 s instead of seconds on the 256-thread host)
+    saved_env = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
+    os.environ.update({k: "1" for k in saved_env})
+    gen_pool = ProcessPoolExecutor(max_workers=max(4, min(96, (os.cpu_count() or 8) // max(world, 1))), mp_context=multiprocessing.get_context("spawn"))
     gen_jobs = [gen_pool.submit(_gen_alignment, (5000 + ((rank * a.batch + i) % max(distinct * world, 1)), a.height, a.width, a.points, i < KEEP_WHOLE))
                 for i in range(distinct)]
+    for k, v in saved_env.items():
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     if forced:
         import socket
         s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
