@@ -192,11 +192,13 @@ int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, i
                                    int off_y, int off_polarity, int sensor_H, int sensor_W, double blur_sigma, int use_exp_weights,
                                    double* norms);
 /* The time bookkeeping EventFrame::create does on the same container before it draws the frame (EventFrame.cpp:313-335): first_time =
- * events[0].ts, last_time = events[n-1].ts (set in the `else if` branch of the loop: a single event leaves it where clear() put it —
- * reported here as `last_valid` = 0), time = events[n/2].ts (the "median" is the middle ELEMENT of the time-ordered slice), delta_time =
- * last - first; all in the unit of the records' ts field (base::Time: int64 microseconds at byte offset off_ts).  A slice whose first
- * time stamp is later than its last is the reference's `throw std::runtime_error("[EVENT_FRAME] FATAL ERROR Event time[0] > event
- * time [N-1]")`: EDS_ERR_INVALID, and nothing is built. */
+ * events[0].ts, last_time = events[n-1].ts, time = events[n/2].ts (the "median" is the middle ELEMENT of the time-ordered slice), delta_time =
+ * last - first; all in the unit of the records' ts field (base::Time: int64 microseconds at byte offset off_ts).  The reference object is
+ * stateful here: last_time is assigned only in the `else if` branch of its loop, which a single event never reaches, and clear() does not
+ * reset it — a one-event slice keeps the PREVIOUS slice's last_time, and the order check and delta_time use that.  So `last_time` is
+ * IN/OUT: pass the previous slice's value (0 for a fresh EventFrame; a zero-initialised struct), get this slice's back (`last_valid` = 0
+ * says it was carried over).  A slice whose first time stamp is later than that last is the reference's `throw
+ * std::runtime_error("[EVENT_FRAME] FATAL ERROR Event time[0] > event time [N-1]")`: EDS_ERR_INVALID, and nothing is built. */
 typedef struct eds_event_times {
     int64_t first_time, last_time, time, delta_time;
     int32_t last_valid, reserved;

@@ -86,11 +86,13 @@ class EventTimes(C.Structure):
                 ("last_valid", C.c_int32), ("reserved", C.c_int32)]
 
 
-def event_times(events) -> dict:
+def event_times(events, prev_last_time: int = 0) -> dict:
     """first / last / middle-element time stamp and their difference of a structured event array with an int64 field `ts`;
-    raises EdsError(ERR_INVALID) when events[0].ts > events[-1].ts, like the reference's throw."""
+    raises EdsError(ERR_INVALID) when events[0].ts > the last time stamp, like the reference's throw.  `prev_last_time`: the previous
+    slice's last_time (the reference object keeps it: a one-event slice carries it over — include/eds_hip.h)."""
     ev = np.ascontiguousarray(events)
     t = EventTimes()
+    t.last_time = int(prev_last_time)
     _check(lib().eds_event_times_aos(int(ev.shape[0]), ev.ctypes.data_as(C.c_void_p), int(ev.dtype.itemsize), int(ev.dtype.fields["ts"][1]), C.byref(t)))
     return {k: getattr(t, k) for k, _ in t._fields_ if k != "reserved"}
 

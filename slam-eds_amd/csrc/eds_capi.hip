@@ -426,12 +426,24 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
         const int rows_per = 32 * std::max(1, (h->H + 32 * 16 - 1) / (32 * 16)), nbands = (h->H + rows_per - 1) / rows_per;
         const unsigned seq = (++h->upload_seq) & 0xfffu;
         __atomic_store_n(&h->h_fprog[0], seq << 20, __ATOMIC_RELEASE);
+        const auto t_host = std::chrono::steady_clock::now();
         eds_frame_store_follow(h, slot, seq, rows_per);
         for (int k = 0; k < nbands; ++k) {
             const int rb = rows_per * k, re = std::min(h->H, rows_per * (k + 1));
             const size_t b = (size_t)rb * h->W, e = (size_t)re * h->W;
             narrow_band(frame + b, stage + b, e - b);
             __atomic_store_n(&h->h_fprog[0], (seq << 20) | (unsigned)re, __ATOMIC_RELEASE);
+        }
+        // A workgroup of the follower gives up after 2 s without progress (a host thread that was descheduled mid-frame).  Only then can
+        // the slot be half-written, and only if this loop took that long: in that case wait, and store the frame again from the (now
+        // complete) staging buffer with plain launches — a slot is never left holding a partial frame, has_frame stays truthful, and a
+        // pyramid built on it (k_pyr_down) sees whole levels.
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_host).count() > 1.0) {
+            EDS_HIP_TRY(hipStreamSynchronize(h->st));
+            if (h->h_fprog[1] & 0x80000000u) {
+                h->h_fprog[1] = 0;
+                for (int k = 0; k < nbands; ++k) eds_frame_store_rowmajor(h, slot, h->d_fstage, rows_per * k, std::min(h->H, rows_per * (k + 1)));
+            }
         }
     } else
     for (int k = 0; k < EDS_UPLOAD_BANDS; ++k) {
@@ -791,17 +803,23 @@ int eds_trk_build_event_frames_aos(eds_trk* h, int first_slot, int num_levels, i
                                   norms, &aos);
 }
 
-// EventFrame::create's time bookkeeping (EventFrame.cpp:313-335), host only
+// EventFrame::create's time bookkeeping (EventFrame.cpp:313-335), host only.  The reference object is STATEFUL: clear() (called at the head
+// of create) does not touch first_time / last_time, and last_time is only assigned in the `else if ((it + 1) == events.end())` branch — so a
+// slice of ONE event keeps the PREVIOUS slice's last_time, and both the order check and delta_time use that.  `out->last_time` is therefore
+// in/out: on entry the previous slice's last_time (0 on a fresh object), on return this slice's — unchanged for a single event
+// (last_valid = 0) and for an empty slice.
 int eds_event_times_aos(int n_events, const void* events, int stride, int off_ts, eds_event_times* out) {
     if (!out) return fail(EDS_ERR_INVALID, "null output");
+    const int64_t prev_last = out->last_time;
     std::memset(out, 0, sizeof(*out));
+    out->last_time = prev_last;
     if (n_events < 0 || (n_events > 0 && !events)) return fail(EDS_ERR_INVALID, "bad event array");
     if (stride < 8 || off_ts < 0 || off_ts + 8 > stride) return fail(EDS_ERR_INVALID, "bad event layout (ts: int64 field inside the stride)");
-    if (n_events == 0) return EDS_OK;                       // (the reference's loop does not run; everything stays where clear() put it)
+    if (n_events == 0) { out->delta_time = out->last_time; return EDS_OK; }   // (the loop does not run: first_time stays as well — reported as 0 here, the caller holds the state)
     auto ts = [&](int i) { int64_t t; std::memcpy(&t, static_cast<const char*>(events) + (size_t)i * stride + off_ts, 8); return t; };
     out->first_time = ts(0);
     if (n_events > 1) { out->last_time = ts(n_events - 1); out->last_valid = 1; }     // `else if ((it + 1) == events.end())`: never for a single event
-    if (out->last_valid && out->first_time > out->last_time)
+    if (out->first_time > out->last_time)
         return fail(EDS_ERR_INVALID, "[EVENT_FRAME] Event time[0] > event time [N-1] (EventFrame.cpp:325-329)");
     out->time = ts(n_events / 2);
     out->delta_time = out->last_time - out->first_time;
@@ -812,6 +830,7 @@ int eds_trk_build_event_frames_aos_timed(eds_trk* h, int first_slot, int num_lev
                                          int off_y, int off_polarity, int off_ts, int sensor_H, int sensor_W, double blur_sigma,
                                          int use_exp_weights, double* norms, eds_event_times* times) {
     eds_event_times local;
+    std::memset(&local, 0, sizeof(local));           // (last_time is in/out: a caller without a struct of its own has no history)
     int rc = eds_event_times_aos(n_events, events, stride, off_ts, times ? times : &local);
     if (rc) return rc;
     return eds_trk_build_event_frames_aos(h, first_slot, num_levels, n_events, events, stride, off_x, off_y, off_polarity, sensor_H, sensor_W,

@@ -269,6 +269,10 @@ __global__ __launch_bounds__(EDS_FOLLOW_THREADS) void k_store_follow(const float
             // (every poll is a PCIe read of the host's cache line: workgroups whose band is far away ask rarely)
             if ((v >> 20) == seq && (int)(v & 0xfffffu) + rows_per < rb) __builtin_amdgcn_s_sleep(100); else __builtin_amdgcn_s_sleep(6);
         }
+        // the staging rows the host wrote before it published `re` must be the ones read below: acquire at system scope (invalidates this
+        // CU's vector cache, which every wavefront of the workgroup shares) — the buffer is re-used for every frame, so "first touched
+        // here" was an argument about THIS upload only
+        if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         s_ok = ok;
     }
     __syncthreads();

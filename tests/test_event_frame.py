@@ -306,9 +306,13 @@ def test_event_time_bookkeeping_like_eventframe_create():
     with pytest.raises(capi.EdsError) as e:
         capi.event_times(bad)
     assert e.value.code == capi.ERR_INVALID and "time[0]" in str(e.value)
-    one = capi.event_times(ev[:1])
-    assert one["first_time"] == 1000 and one["last_valid"] == 0 and one["time"] == 1000
-    assert capi.event_times(ev[:0])["first_time"] == 0
+    # a single event never reaches the branch that assigns last_time, and clear() does not reset it: the PREVIOUS slice's value stays, and
+    # the order check and delta_time use it (the stateful reference, EventFrame.cpp:313-336)
+    one = capi.event_times(ev[:1], prev_last_time=2000)
+    assert (one["first_time"], one["last_time"], one["last_valid"], one["time"], one["delta_time"]) == (1000, 2000, 0, 1000, 1000)
+    with pytest.raises(capi.EdsError):                                 # on a fresh object last_time is 0: events[0].ts = 1000 > 0 is the throw
+        capi.event_times(ev[:1])
+    assert capi.event_times(ev[:0])["first_time"] == 0 and capi.event_times(ev[:0], prev_last_time=77)["last_time"] == 77
 
 
 @pytest.mark.gpu
