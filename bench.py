@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--exec", dest="exec_", choices=["device", "host"], default="device")
     ap.add_argument("--distinct", type=int, default=4096, help="distinct synthetic alignments (replicated to fill the batch); the default makes every "
                     "alignment of the 4 096-slot batch its own (seeds 5000 + b)")
+    ap.add_argument("--gen-workers", dest="gen_workers", type=int, default=-1, help="worker PROCESSES that generate the synthetic inputs (default: one per core, "
+                    "up to 96); 0 = threads inside this process — required under rocprofv3, whose preloaded library initialises the GPU before Python starts: "
+                    "such a process must not start children")
     ap.add_argument("--no-configs", dest="no_configs", action="store_true", help="skip the block of the other BASELINE.json configs")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU-baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -519,7 +522,12 @@ def main():
     # spend their time spinning: 158 s instead of seconds on the 256-thread host)
     saved_env = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     os.environ.update({k: "1" for k in saved_env})
-    gen_pool = ProcessPoolExecutor(max_workers=max(4, min(96, (os.cpu_count() or 8) // max(world, 1))), mp_context=multiprocessing.get_context("spawn"))
+    if a.gen_workers == 0:
+        from concurrent.futures import ThreadPoolExecutor
+        gen_pool = ThreadPoolExecutor(min(32, os.cpu_count() or 1))
+    else:
+        nw = a.gen_workers if a.gen_workers > 0 else max(4, min(96, (os.cpu_count() or 8) // max(world, 1)))
+        gen_pool = ProcessPoolExecutor(max_workers=nw, mp_context=multiprocessing.get_context("spawn"))
     gen_jobs = [gen_pool.submit(_gen_alignment, (5000 + ((rank * a.batch + i) % max(distinct * world, 1)), a.height, a.width, a.points, i < KEEP_WHOLE))
                 for i in range(distinct)]
     for k, v in saved_env.items():

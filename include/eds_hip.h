@@ -410,7 +410,8 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
  * EDS_LM6_KERNEL=resident|paired|wide, EDS_FUSED_LAYOUT=tiles|strips, EDS_FUSED_GATHER=quad|lane, EDS_LM6_TEAM / EDS_REF12_TEAM=1|2|4|8|16,
  * EDS_TEAM_WIDE=0|1, EDS_REF12_KERNEL=wide|paired, EDS_STRIPS_PHASES=1|2|4, EDS_STRIPS_POLICY=reuse|eager|never,
  * EDS_STRIPS_BUDGET_PCT=1..95 (share of the FREE device memory the strip copies may take when they are first allocated; default 50),
- * EDS_NO_SPIN, EDS_UPLOAD=bands, EDS_FUSED_REPORT, EDS_TEAM_TEST_DROP_MEMBER (test hook).  EDS_FRAME_LAYOUT=rowmajor decides the
+ * EDS_REDUCE_PPL=4|8 (points a lane of the 6-column reduction folds: measured equal), EDS_NO_SPIN, EDS_UPLOAD=bands, EDS_FUSED_REPORT,
+ * EDS_TEAM_TEST_DROP_MEMBER (test hook).  EDS_FRAME_LAYOUT=rowmajor decides the
  * allocation and is honoured at create only (EDS_ERR_STATE here).  Unknown name: EDS_ERR_INVALID. */
 int eds_trk_set_knob(eds_trk* h, const char* name, const char* value);
 /* The strip copies of the frames (csrc/eds_layout.hpp): bytes allocated (0: none yet), their row phases, and whether they were refused

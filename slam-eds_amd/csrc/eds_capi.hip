@@ -98,10 +98,10 @@ int max_points(const eds_trk* h, int first, int count) {
 
 // geometry of the reduction grid for `count` slots with at most N points each
 // (a segment = one workgroup's record: 256 points, or 1 024 for the 6-column pass, whose lanes fold four points each — eds_kernels.hpp)
-void reduce_geometry(int N, int nb_red, int ncols, int* cpb, int* nseg) {
+void reduce_geometry(int N, int nb_red, int ncols, int* cpb, int* nseg, int ppl_knob = 4) {
     const int ne = N / nb_red;
     const int last = ne + (N - nb_red * ne);
-    const int per_seg = EDS_TPB * eds_reduce_points_per_lane(ncols, nb_red);
+    const int per_seg = EDS_TPB * eds_reduce_points_per_lane(ncols, nb_red, ppl_knob);
     *cpb = std::max(1, (last + per_seg - 1) / per_seg);
     *nseg = nb_red * (*cpb);
 }
@@ -137,9 +137,9 @@ int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bo
     if (with_reduction) {
         const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
         int cpb, nseg;
-        reduce_geometry(N, nb_red, ncols, &cpb, &nseg);
+        reduce_geometry(N, nb_red, ncols, &cpb, &nseg, h->knobs.reduce_ppl);
         if (nseg > h->max_seg) return fail(EDS_ERR_INVALID, "reduction grid exceeds allocation");
-        eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st);
+        eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st, h->knobs.reduce_ppl);
         if (fetch)
             EDS_HIP_TRY(hipMemcpyAsync(h->h_part + (size_t)first * h->max_seg * EDS_RED_K,
                                        h->dpart + (size_t)first * h->max_seg * EDS_RED_K,
@@ -153,7 +153,7 @@ int run_pass(eds_trk* h, int first, int count, int ncols, bool refresh_model, bo
 // sums of a slot after run_pass (host side, fp64)
 void gather6(const eds_trk* h, int slot, edss::Sums6* S) {
     int cpb, nseg;
-    reduce_geometry(h->slots[slot].N, 1, 6, &cpb, &nseg);
+    reduce_geometry(h->slots[slot].N, 1, 6, &cpb, &nseg, h->knobs.reduce_ppl);
     // NB: the grid was sized for the max N of the range; segments beyond this slot's own are all-zero
     double rec[EDS_RED_N6];
     for (int i = 0; i < EDS_RED_N6; ++i) rec[i] = 0.0;
@@ -1254,11 +1254,11 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
     const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
     int cpb, nseg;
-    reduce_geometry(N, nb_red, ncols, &cpb, &nseg);
+    reduce_geometry(N, nb_red, ncols, &cpb, &nseg, h->knobs.reduce_ppl);
     EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
     for (int i = 0; i < reps; ++i) {
         eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
-        if (with_reduction) eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st);
+        if (with_reduction) eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st, h->knobs.reduce_ppl);
     }
     EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
     EDS_HIP_TRY(hipEventSynchronize(h->ev1));

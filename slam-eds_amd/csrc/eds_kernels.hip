@@ -280,33 +280,41 @@ __global__ __launch_bounds__(EDS_TPB) void eds_reduce_kernel(EdsArrays A, int fi
             accumulate_normal<NC>(acc, J, r, hw, ct);
         }
     } else {
-        static_assert(PPL == 1 || PPL == 4, "one point per lane, or four consecutive ones (16-byte loads)");
-        // nb_red == 1 here (start = 0): element 4 * lane of a plane is 16-byte aligned (Np is a multiple of 256), and a group of
+        static_assert(PPL == 1 || PPL == 4 || PPL == 8, "one point per lane, or four / eight consecutive ones (16-byte loads)");
+        // nb_red == 1 here (start = 0): element 4 * k of a plane is 16-byte aligned (Np is a multiple of 256), and a group of
         // four lies wholly inside or wholly outside the padded plane
-        const int li = (c * EDS_TPB + threadIdx.x) * 4;
+        constexpr int G = PPL / 4;                   // 16-byte groups per lane and plane: all of them in flight before the first product
+        const int li = (c * EDS_TPB + threadIdx.x) * PPL;
         if (li < n) {
             const size_t o = (size_t)slot * A.Np + li;
-            float4 Jv[NC];
+            float4 Jv[G][NC], rv[G];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) Jv[j] = *reinterpret_cast<const float4*>(A.J + o + j * plane);
-            const float4 rv = *reinterpret_cast<const float4*>(A.r + o);
-            const float r4[4] = {rv.x, rv.y, rv.z, rv.w};
+            for (int g = 0; g < G; ++g) {
+                const bool in = li + 4 * g < A.Np;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float J[NC];
+                for (int j = 0; j < NC; ++j) Jv[g][j] = in ? *reinterpret_cast<const float4*>(A.J + o + 4 * g + j * plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rv[g] = in ? *reinterpret_cast<const float4*>(A.r + o + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-                for (int j = 0; j < NC; ++j) J[j] = e == 0 ? Jv[j].x : (e == 1 ? Jv[j].y : (e == 2 ? Jv[j].z : Jv[j].w));
-                const bool on = li + e < n;            // the padding behind N holds whatever was there
-                const float r = on ? r4[e] : 0.0f;
+            for (int g = 0; g < G; ++g) {
+                const float r4[4] = {rv[g].x, rv[g].y, rv[g].z, rv[g].w};
 #pragma unroll
-                for (int j = 0; j < NC; ++j) J[j] = on ? J[j] : 0.0f;
-                float hw = 1.0f, ct = r * r;
-                if (NC == 6 && tau > 0.0f) {
-                    const float ar = fabsf(r);
-                    if (ar > tau) hw = tau / ar;
-                    ct = hw * r * r * (2.0f - hw);
+                for (int e = 0; e < 4; ++e) {
+                    float J[NC];
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) J[j] = e == 0 ? Jv[g][j].x : (e == 1 ? Jv[g][j].y : (e == 2 ? Jv[g][j].z : Jv[g][j].w));
+                    const bool on = li + 4 * g + e < n;    // the padding behind N holds whatever was there
+                    const float r = on ? r4[e] : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NC; ++j) J[j] = on ? J[j] : 0.0f;
+                    float hw = 1.0f, ct = r * r;
+                    if (NC == 6 && tau > 0.0f) {
+                        const float ar = fabsf(r);
+                        if (ar > tau) hw = tau / ar;
+                        ct = hw * r * r * (2.0f - hw);
+                    }
+                    accumulate_normal<NC>(acc, J, r, hw, ct);
                 }
-                accumulate_normal<NC>(acc, J, r, hw, ct);
             }
         }
     }
@@ -347,10 +355,11 @@ void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, i
     hipLaunchKernelGGL(eds_nc_stat_kernel, dim3(grid_for(count, nb)), dim3(EDS_TPB), 0, st, A, first, count, nb);
     hipLaunchKernelGGL(eds_nc_fix_kernel, dim3(grid_for(count, nchunk)), dim3(EDS_TPB), 0, st, A, first, count, nchunk);
 }
-void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st) {
+void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st, int ppl) {
     const dim3 g(grid_for(count, nseg)), b(EDS_TPB);
     // (the 6-column pass always reduces one block per slot: the four-points-per-lane form; eds_reduce_points_per_lane says so to the host)
-    if (ncols == 6 && nb_red == 1) hipLaunchKernelGGL((eds_reduce_kernel<6, 4>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    if (ncols == 6 && nb_red == 1 && ppl == 8) hipLaunchKernelGGL((eds_reduce_kernel<6, 8>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
+    else if (ncols == 6 && nb_red == 1) hipLaunchKernelGGL((eds_reduce_kernel<6, 4>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
     else if (ncols == 6) hipLaunchKernelGGL((eds_reduce_kernel<6, 1>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
     else hipLaunchKernelGGL((eds_reduce_kernel<12, 1>), g, b, 0, st, A, first, count, nseg, nb_red, cpb);
 }

@@ -40,5 +40,5 @@ void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, i
 // per-point correction of r and of the pose columns; between the residual/Jacobian pass and the reduction
 void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, int nchunk, hipStream_t st);
 // points a lane of the reduction folds: 4 (16-byte loads) for the 6-column pass over one residual block, else 1
-static inline int eds_reduce_points_per_lane(int ncols, int nb_red) { return (ncols == 6 && nb_red == 1) ? 4 : 1; }
-void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st);
+static inline int eds_reduce_points_per_lane(int ncols, int nb_red, int knob = 4) { return (ncols == 6 && nb_red == 1) ? (knob == 8 ? 8 : 4) : 1; }
+void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st, int ppl = 4);

@@ -43,6 +43,7 @@ struct EdsKnobs {
     int no_spin = 0;            // EDS_NO_SPIN         block in the stream wait from the start
     int upload_bands = 0;       // EDS_UPLOAD=bands    one launch per band of a host frame (round 2's upload)
     int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
+    int reduce_ppl = 4;         // EDS_REDUCE_PPL      4 | 8: points a lane of eds_reduce_kernel<6> folds (16-byte loads)
 };
 
 // returns 0, or -1 for a name that is not a knob.  value == nullptr or "" resets the knob to its default.
@@ -70,6 +71,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_NO_SPIN")) k->no_spin = unset ? 0 : 1;
     else if (!strcmp(name, "EDS_UPLOAD")) k->upload_bands = is("bands") ? 1 : 0;
     else if (!strcmp(name, "EDS_FRAME_LAYOUT")) k->frame_rowmajor = is("rowmajor") ? 1 : 0;
+    else if (!strcmp(name, "EDS_REDUCE_PPL")) k->reduce_ppl = iv == 8 ? 8 : 4;
     else return -1;
     return 0;
 }
@@ -78,7 +80,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT")
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL")
 
 // the process environment, read once per handle (eds_trk_create)
 static inline void eds_knobs_from_env(EdsKnobs* k) {

@@ -337,7 +337,7 @@ def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
 def test_knob_names_and_strip_budget(hl):
     for name in ("EDS_REF12_EXEC", "EDS_FUSED_THREADS", "EDS_FUSED_PPT", "EDS_LM6_SPEC", "EDS_LM6_KERNEL", "EDS_FUSED_LAYOUT", "EDS_TEAM_TEST_DROP_MEMBER",
                  "EDS_LM6_TEAM", "EDS_TEAM_WIDE", "EDS_FUSED_GATHER", "EDS_FUSED_REPORT", "EDS_REF12_KERNEL", "EDS_REF12_TEAM", "EDS_STRIPS_PHASES",
-                 "EDS_STRIPS_POLICY", "EDS_STRIPS_BUDGET_PCT", "EDS_NO_SPIN", "EDS_UPLOAD", "EDS_FRAME_LAYOUT"):
+                 "EDS_STRIPS_POLICY", "EDS_STRIPS_BUDGET_PCT", "EDS_NO_SPIN", "EDS_UPLOAD", "EDS_FRAME_LAYOUT", "EDS_REDUCE_PPL"):
         assert hl.hl_knob_set(name.encode(), b"1") == 0 and hl.hl_knob_set(name.encode(), None) == 0
     assert hl.hl_knob_set(b"EDS_NO_SUCH_KNOB", b"1") == -1
     f = hl.hl_strips_phases_for_budget
