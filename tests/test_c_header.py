@@ -22,7 +22,8 @@ def _declared_functions():
 def test_header_is_c99_and_cxx11_clean(tmp_path):
     for lang, std, cc in (("c", "-std=c99", "gcc"), ("c++", "-std=c++11", "g++")):
         src = tmp_path / ("inc." + ("c" if lang == "c" else "cpp"))
-        src.write_text('#include "eds_hip.h"\nint main(void) { return 0; }\n')
+        # both headers of the boundary: the tracker's C ABI and the RCCL gather of the result table (opaque pointers: no rccl.h needed to include it)
+        src.write_text('#include "eds_hip.h"\n#include "eds_hip_rccl.h"\nint main(void) { return 0; }\n')
         subprocess.check_call([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                                "-o", str(tmp_path / "inc.o")])
 

@@ -36,7 +36,10 @@ for t in range(trials):
             chain[l] = {"error": str(e)}            # not usable: the next level starts from the last good pose
         h.close()
     d = po.se3_distance(p, q, cp, cq)
-    ok = d <= 1e-8 and np.abs(v - cv).max() <= 1e-8
+    # (REF12 adds its per-wavefront tiles to the block sums with fp64 LDS atomics, whose order varies from run to run: the SAME solve
+    # repeated differs by up to ~1e-7 on a weakly determined level — seed 10, trial 7 does, in round 3's binary too; LM6 is bit-stable)
+    tol = 1e-6 if ref12 else 1e-8
+    ok = d <= tol and np.abs(v - cv).max() <= tol
     print(f"trial {t}: {H}x{W} L={L} counts={counts} ref12={ref12}  distance {d:.2e}  {'ok' if ok else 'DISAGREE'}", flush=True)
     if not ok:
         keys = ("num_iterations", "num_successful_steps", "termination", "initial_cost", "final_cost", "usable", "flags")
