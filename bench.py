@@ -897,7 +897,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle as po
         samp = po.BICUBIC if a.sampling == "bicubic" else po.BILINEAR
-        nchk = min(distinct, 32)
+        nchk = min(distinct, 64 if distinct >= B else 32)      # every alignment distinct: 64 of them, one row each; replicated: 32, two replicas each
         worst, worst_row, acc_mismatch, nrows = 0.0, -1, 0, 0
         for d in range(nchk):
             x = als[d]
