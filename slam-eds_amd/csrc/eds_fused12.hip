@@ -83,6 +83,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     __shared__ __attribute__((aligned(16))) float s_patch[NTAP][CAP];
     static_assert(!QUAD || (SAMPLING == 0 && CAP % 4 == 0), "quad gather: bicubic, whole quads cached");
     __shared__ int s_cell[CAP];
+    // Candidate residuals of an evaluation: in LDS for the batch shape (two 256-thread workgroups per CU: 8 KB fit its 80 KB), copied to the
+    // residual plane when the candidate is accepted — round 3 wrote every evaluation's candidates to the mhat plane and read them back on
+    // acceptance (0.5 GB of writes per 4 096-alignment launch: profiles/r03_summary.md WRITE_SIZE).  Points beyond the buffer, and the
+    // 512-thread shapes (whose LDS is full), keep the plane.
+    constexpr int RC_CAP = (NTHR == 256) ? 2048 : 0;
+    __shared__ float s_rc[RC_CAP > 0 ? RC_CAP : 1];
     __shared__ double s_G[EDS_DEV_MAX_BLOCKS * 36];
     __shared__ double s_nc[EDS_DEV_MAX_BLOCKS][8];    // NC residual: per block 1/||E||, then sum_j E_j J'_j / ||E||^3
 
@@ -345,7 +351,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         for (int k = 0; k < 6; ++k) x[k] = w * (st7[k * jplane] * inv_e - E * (float)nk[1 + k]);
                         x[12] = w * (m * inv_n - E * inv_e);
                     }
-                    if (valid) A.mhat[base + i] = x[12];              // candidate residual
+                    if (valid) {                                      // candidate residual
+                        if (RC_CAP > 0 && i - lo < RC_CAP) s_rc[i - lo] = x[12]; else A.mhat[base + i] = x[12];
+                    }
                     if (j0 == lo) rkeep[jj] = x[12];                  // (the first two of a lane also stay in registers: see the accept copy)
                 }
                 EDS12_PSTAMP(2);                                        // row formed, candidate residual stored
@@ -508,7 +516,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             // else, and the load of the value just stored (an L2 round trip) sat at the head of the next evaluation
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) { const int i = lo + jj * nthr + tid; if (i < hi) A.r[base + i] = rkeep[jj]; }
-            for (int i = lo + 2 * nthr + tid; i < hi; i += nthr) A.r[base + i] = A.mhat[base + i];
+            for (int i = lo + 2 * nthr + tid; i < hi; i += nthr) A.r[base + i] = (RC_CAP > 0 && i - lo < RC_CAP) ? s_rc[i - lo] : A.mhat[base + i];
         }
         if (s_state == 2) break;
     }
