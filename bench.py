@@ -692,6 +692,31 @@ def main():
         t = pmc_traffic("eds_resjac_kernel" + ("<0" if a.sampling == "bicubic" else "<1"), a)
         if t:
             roof_rj["traffic"], roof_rj["traffic_source"] = t["bytes"], t["source"]
+        # the wavefront-reduction kernel on its own (north_star's second kernel; SURVEY 8d: "the residual/Jacobian kernel and the reduction
+        # kernel separately"): its time is what the pair costs beyond the first kernel, under the same HIP events
+        red_ms = max(both_ms - rj_ms, 1e-6)
+        ach_red = B * N * BYTES_REDUCE / (red_ms * 1e-3) / 1e9
+        roof_red = {"kernel": "eds_reduce_kernel<6, 4>", "bound": "hbm", "achieved": ach_red, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_red / HBM_PEAK_GBS,
+                    "traffic": None, "kernel_ms": red_ms, "note": f"{BYTES_REDUCE} B per point read once (r + six Jacobian planes, 16-byte loads, four points per lane); "
+                    "time = (resjac + reduce) - resjac under HIP events, launch gap included"}
+        t = pmc_traffic("eds_reduce_kernel", a)
+        if t:
+            roof_red["traffic"], roof_red["traffic_source"] = t["bytes"], t["source"]
+        # what this box's HBM really streams ("confirm on the box ... and report the measured peak beside the nominal"): a plain
+        # device-to-device copy of 1 GiB, read + write counted
+        try:
+            x_ = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); y_ = torch.empty_like(x_)
+            y_.copy_(x_); torch.cuda.synchronize()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0_.record()
+            for _ in range(10):
+                y_.copy_(x_)
+            e1_.record(); torch.cuda.synchronize()
+            hbm_probe = {"copy_GBps": 10 * 2 * x_.numel() * 4 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9, "bytes_per_copy": int(x_.numel() * 4),
+                         "note": "device-to-device copy of 1 GiB (read + write counted), 10 repetitions under events; nominal peak 8 000 GB/s"}
+            del x_, y_
+        except Exception as ex_:                     # never fail the bench over the probe
+            hbm_probe = {"error": str(ex_)}
         if roof is None:
             roof = roof_rj
         pose_err = float(np.median([np.linalg.norm(table[b, 0:3] - als[b % distinct].p_true) for b in range(min(B, distinct))]))
@@ -707,7 +732,7 @@ def main():
             "point_evals_per_s_in_solver": total * N * passes / (ms_per_step * 1e-3),
             "iterations_per_alignment": iters_done, "success_fraction": float(np.mean(table[:, 15])),
             "median_translation_error": pose_err,
-            "roofline": roof, "roofline_resjac": roof_rj,
+            "roofline": roof, "roofline_resjac": roof_rj, "roofline_reduce": roof_red, "hbm_probe": hbm_probe,
         }
         if a.exec_ == "device" and a.sampling == "bicubic":
             # what the frame layout of the timed kernel costs to make: the strip copies of all B frames converted again (HIP events)
