@@ -380,6 +380,7 @@ __device__ __forceinline__ void project_sample_quad(const FrameView& frame, cons
 // first row once, it goes round the quad, and lane j reads row j of each of the quad's four patches with ONE 16-byte load at a
 // 4-byte-aligned address (no second piece, no barrel shift).  `sbase`: start of the frame's strips; Hp: allocated rows;
 // copy_bytes / phases: the strip geometry.  Same arithmetic after the loads as project_sample_quad.
+template <bool NT = false>
 __device__ __forceinline__ void project_sample_quad_strips(const FrameView& frame, const char* __restrict__ sbase, int Hp, unsigned copy_bytes, int phases,
                                                            const PoseF& ps, const PointKf& k, bool valid, int lane, PointProj& o) {
     PointGeom g;
@@ -393,7 +394,14 @@ __device__ __forceinline__ void project_sample_quad_strips(const FrameView& fram
     const unsigned jr32 = 32u * (unsigned)(lane & 3);
     float4u t[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4u*>(sbase + ((unsigned)oq[q] + jr32));
+    // NT: the rows are fetched with the non-temporal bit — for ONE-PASS launches over frames that do not fit the Infinity Cache anyway
+    // (the caller's rule): the lines are then not kept, and what the pass WRITES (r and the Jacobian planes, read by the reduction next)
+    // stays in the cache instead (tools/bench_reduce.py: the reduction behind it 44 -> 36 us at 4 096 alignments).  Never for the solvers,
+    // whose passes re-read their lines (profiles/r04_ubench_sector.txt).
+    for (int q = 0; q < 4; ++q) {
+        const float4u* src = reinterpret_cast<const float4u*>(sbase + ((unsigned)oq[q] + jr32));
+        if (NT) t[q] = __builtin_nontemporal_load(src); else t[q] = *src;
+    }
     float f[4], d[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) hermite(t[q].x, t[q].y, t[q].z, t[q].w, xq[q], f[q], d[q]);

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(EDS_TPB) void eds_model_kernel(EdsArrays A, int fir
 // Residual + Jacobian pass.  NC = 6: SE(3) left-perturbation columns [d/d upsilon, d/d omega]
 // (J = -w [gradE_P, P x gradE_P]; identical to DSO's row, reference CoarseTracker.cpp:311-321).
 // NC = 12: Ceres-local columns of the reference problem [t | quaternion local | velocity local].
-template <int SAMPLING, int NC>
+// NT (bicubic on the strip copies only): non-temporal row loads — see project_sample_quad_strips.
+template <int SAMPLING, int NC, bool NT>
 __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int first, int count, int nchunk) {
     int slot, chunk;
     if (!decode_wg(first, count, nchunk, slot, chunk)) return;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
         if (A.strips) {                  // the strip copies of the frames are current for this range (the host checked): one load per patch row
             const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
             const char* sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
-            project_sample_quad_strips(frame, sbase, A.Hp, copy_bytes, A.strip_phases, ps, kf, i < N, threadIdx.x & 63, pp);
+            project_sample_quad_strips<NT>(frame, sbase, A.Hp, copy_bytes, A.strip_phases, ps, kf, i < N, threadIdx.x & 63, pp);
         } else {
             project_sample_quad(frame, A.frame + (size_t)fslot * A.Hp * A.Wp, ps, kf, i < N, threadIdx.x & 63, pp);
         }
@@ -346,10 +347,15 @@ void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipS
 }
 void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, int count, int nchunk, hipStream_t st) {
     const dim3 g(grid_for(count, nchunk)), b(EDS_TPB);
-    if (sampling == 0 && ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<0, 6>), g, b, 0, st, A, first, count, nchunk);
-    else if (sampling == 0) hipLaunchKernelGGL((eds_resjac_kernel<0, 12>), g, b, 0, st, A, first, count, nchunk);
-    else if (ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<1, 6>), g, b, 0, st, A, first, count, nchunk);
-    else hipLaunchKernelGGL((eds_resjac_kernel<1, 12>), g, b, 0, st, A, first, count, nchunk);
+    // non-temporal row loads once the frames of the range cannot stay in the 256 MiB Infinity Cache between two passes anyway: a pass
+    // touches ~128 B per point on the strip copies (eds_resjac_nt_rule)
+    const bool nt = sampling == 0 && A.strips && eds_resjac_nt_rule(count, A.Np);
+    if (sampling == 0 && ncols == 6 && nt) hipLaunchKernelGGL((eds_resjac_kernel<0, 6, true>), g, b, 0, st, A, first, count, nchunk);
+    else if (sampling == 0 && ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<0, 6, false>), g, b, 0, st, A, first, count, nchunk);
+    else if (sampling == 0 && nt) hipLaunchKernelGGL((eds_resjac_kernel<0, 12, true>), g, b, 0, st, A, first, count, nchunk);
+    else if (sampling == 0) hipLaunchKernelGGL((eds_resjac_kernel<0, 12, false>), g, b, 0, st, A, first, count, nchunk);
+    else if (ncols == 6) hipLaunchKernelGGL((eds_resjac_kernel<1, 6, false>), g, b, 0, st, A, first, count, nchunk);
+    else hipLaunchKernelGGL((eds_resjac_kernel<1, 12, false>), g, b, 0, st, A, first, count, nchunk);
 }
 void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, int nchunk, hipStream_t st) {
     hipLaunchKernelGGL(eds_nc_stat_kernel, dim3(grid_for(count, nb)), dim3(EDS_TPB), 0, st, A, first, count, nb);

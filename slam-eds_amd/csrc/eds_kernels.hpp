@@ -39,6 +39,9 @@ void eds_launch_resjac(const EdsArrays& A, int sampling, int ncols, int first, i
 // PhotometricErrorNC (reference PhotometricErrorNC.hpp:124-192): block statistics of the sampled brightness, then the
 // per-point correction of r and of the pose columns; between the residual/Jacobian pass and the reduction
 void eds_launch_nc_normalise(const EdsArrays& A, int first, int count, int nb, int nchunk, hipStream_t st);
+// one-pass residual/Jacobian launches fetch their patch rows non-temporally when the lines they touch (128 B per point on the strip copies) plus
+// the planes they write (28 B per point) exceed the Infinity Cache: nothing of a frame would survive to the next pass, and the planes should
+static inline bool eds_resjac_nt_rule(int count, int Np) { return (long long)count * Np * 156ll > 256ll * 1024 * 1024; }
 // points a lane of the reduction folds: 4 (16-byte loads) for the 6-column pass over one residual block, else 1
 static inline int eds_reduce_points_per_lane(int ncols, int nb_red, int knob = 4) { return (ncols == 6 && nb_red == 1) ? (knob == 8 ? 8 : 4) : 1; }
 void eds_launch_reduce(const EdsArrays& A, int ncols, int first, int count, int nseg, int nb_red, int cpb, hipStream_t st, int ppl = 4);
