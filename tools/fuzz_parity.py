@@ -130,15 +130,38 @@ for c in range(cases):
             continue
         if fails["host"]:
             continue
+        # the yardstick for the pose-only solvers too (round 4): how far the fp64 oracle's OWN answer moves when the frame and the start change
+        # at the level of fp32 rounding — a near-tie in one accept test sends two correct solvers down different branches (seed 142, case 703:
+        # 12 LM6 iterations on 480 points; every path is within the oracle's own spread)
+        spread6 = None
+
+        def lm6_spread():
+            prng = np.random.default_rng(12345)
+            dmax = 0.0
+            for _ in range(4):
+                alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + 6e-8 * prng.standard_normal(al.frame.shape))})
+                op = po.Oracle(alp, sampling=sampling)
+                pp = p0 * (1 + 6e-8 * prng.standard_normal(3)) + 6e-8 * prng.standard_normal(3) * np.abs(p0).max()
+                rr = op.pose6_lm(pp, q0, cfg_start[2], iters=iters, lambda0=0.01, huber_tau=tau) if solver == "lm6" else op.pose6_gn(pp, q0, cfg_start[2], iters=iters, huber_tau=tau)
+                dmax = max(dmax, po.se3_distance(rr["p"], rr["q"], ref["p"], ref["q"]))
+            return dmax
         for name, r in runs.items():
             er = o.pose6_eval(r[0], r[1], cfg_start[2])["r"]
             if np.abs(r[4] - er).max() > 5e-5 * max(np.abs(er).max(), 1e-30):
                 print(tag, f"tau={tau}: {name} residuals at the returned pose off by {np.abs(r[4] - er).max() / np.abs(er).max():.2e}"); bad += 1
             d = po.se3_distance(r[0], r[1], runs["host"][0], runs["host"][1])
             if d > 1e-4 and N >= 100 and not far and sampling == 0:
-                print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e}"); bad += 1
+                if spread6 is None: spread6 = lm6_spread()
+                if spread6 >= 0.3 * d:
+                    print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+                else:
+                    print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e}"); bad += 1
         if solver == "lm6" and sampling == 0 and not far and N >= 100:
             from_dev = po.se3_distance(runs["default"][0], runs["default"][1], ref["p"], ref["q"])
             if from_dev > 5e-4:
-                print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
+                if spread6 is None: spread6 = lm6_spread()
+                if spread6 >= 0.3 * from_dev:
+                    print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+                else:
+                    print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
 print(f"{cases} cases ({stats}), {bad} disagreements" + (f", {chaotic} differences on ill-conditioned cases (the oracle itself moves as much)" if chaotic else ""))
