@@ -25,6 +25,8 @@ def test_patch_cache_simulation_reproduces_the_hardware_hit_rate():
     assert 1.85 <= p1[1] <= 1.95                         # x 2.41 lines per patch on the 4x4 tiles (two tiles per 128-byte line)
     assert p2[0] < p1[0] and p3[0] < p2[0] and p4[0] < p3[0]          # bigger caches do gather less often ...
     assert min(p2[1], p3[1], p4[1]) > 1.55               # ... but none comes near 1.37 lines per point-pass (windows fetch 3.7-5.2 lines a time)
+    p6 = rows["P6 incremental"]
+    assert p6[0] == p1[0] and 1.45 < p6[1] < p1[1] - 0.2 # fetching only a shifted patch's NEW taps: the best that fits 64 B per point, still > 1.37
     assert "rejected 0.5" in r.stdout or "rejected 0.6" in r.stdout   # LM rejects more than half of its candidates on this problem
 
 

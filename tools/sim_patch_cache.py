@@ -99,6 +99,10 @@ def main():
         # P5: two-entry LRU
         e0 = np.full((N, 2), -99); e1 = np.full((N, 2), -99)
         g5 = l5 = 0
+        # P6: single slot, INCREMENTAL refetch: a patch that overlaps the cached one fetches only its new taps (rows / columns kept in place
+        # by toroidal addressing) — same gathers as P1, fewer lines per gather
+        ir, ic = np.full(N, -99), np.full(N, -99)
+        l6 = 0
         disp_acc, disp_rej = [], []
         prev_u = prev_v = None
         for k in range(npass):
@@ -136,6 +140,13 @@ def main():
             m4 = (np.abs(w2r - r0) > 2) | (np.abs(w2c - c0) > 2)
             g4 += m4.sum(); l4 += np.array([lines_of_window(int(r), int(c), 2) for r, c in zip(r0[m4], c0[m4])]).sum()
             w2r[m4], w2c[m4] = r0[m4], c0[m4]
+            # P6
+            for n in np.nonzero((ir != r0) | (ic != c0))[0]:
+                new_t = {(int(r0[n]) - 1 + i, int(c0[n]) - 1 + j) for i in range(4) for j in range(4)}
+                if ir[n] > -90:
+                    new_t -= {(int(ir[n]) - 1 + i, int(ic[n]) - 1 + j) for i in range(4) for j in range(4)}
+                l6 += len({(r // 4, c // 8) for r, c in new_t})
+            ir, ic = r0.copy(), c0.copy()
             # P5 LRU-2
             key = np.stack([r0, c0], 1)
             h0 = (e0 == key).all(1); h1 = (e1 == key).all(1) & ~h0
@@ -149,7 +160,8 @@ def main():
                 d = np.hypot(u - prev_u, v - prev_v)
                 (disp_acc if acc_flags[k] else disp_rej).append(d)
             prev_u, prev_v = u, v
-        for nm, g, l in (("P1 single slot", g1, l1), ("P2 accepted backup", g2, l2), ("P3 6x6 window", g3, l3), ("P4 8x8 window", g4, l4), ("P5 LRU-2", g5, l5)):
+        for nm, g, l in (("P1 single slot", g1, l1), ("P2 accepted backup", g2, l2), ("P3 6x6 window", g3, l3), ("P4 8x8 window", g4, l4), ("P5 LRU-2", g5, l5),
+                         ("P6 incremental", g1, l6)):
             add(nm + " gathers", g); add(nm + " lines", l)
         add("disp_acc_mean", np.mean(np.concatenate(disp_acc)) if disp_acc else 0)
         add("disp_rej_mean", np.mean(np.concatenate(disp_rej)) if disp_rej else 0)
@@ -157,7 +169,7 @@ def main():
     pp = tot["point_passes"]
     print(f"\n{a.n} alignments, {tot['passes'] / a.n:.1f} passes each, rejected {tot['rejected'] / tot['passes']:.2f}")
     print(f"mean displacement between consecutive passes: accepted candidates {tot['disp_acc_mean'] / a.n:.2f} px, rejected {tot['disp_rej_mean'] / a.n:.2f} px")
-    for nm in ("P1 single slot", "P2 accepted backup", "P3 6x6 window", "P4 8x8 window", "P5 LRU-2"):
+    for nm in ("P1 single slot", "P2 accepted backup", "P3 6x6 window", "P4 8x8 window", "P5 LRU-2", "P6 incremental"):
         g, l = tot[nm + " gathers"], tot[nm + " lines"]
         print(f"{nm:22s}: gathers / point-pass {g / pp:.3f}   lines / gather {l / max(g, 1):.2f}   lines / point-pass {l / pp:.3f}")
     print("misses per pass (fraction of points), P1 | P2 | P3:")
