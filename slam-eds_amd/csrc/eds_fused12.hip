@@ -83,6 +83,11 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     __shared__ __attribute__((aligned(16))) float s_patch[NTAP][CAP];
     static_assert(!QUAD || (SAMPLING == 0 && CAP % 4 == 0), "quad gather: bicubic, whole quads cached");
     __shared__ int s_cell[CAP];
+    // The batch shape (two 256-thread workgroups per CU) gathers EVERY patch every evaluation: its 20 KB could cache 320 of 2 000 points
+    // (3 % of the line fills at the pose-only kernel's 21 % hit rate), and probing, selecting and writing back for all points cost more
+    // vector instructions than that returns (profiles/r04_sq_counters.txt: 523 per point-evaluation, a quarter of the wavefront-cycles wait
+    // for an issue slot).  The quad gather of that shape therefore skips the cache (round 4); the lane gather and the 512-thread shapes keep it.
+    constexpr bool QCACHE = !(QUAD != 0 && NTHR == 256);
     // Candidate residuals of an evaluation: in LDS for the batch shape (two 256-thread workgroups per CU: 8 KB fit its 80 KB), copied to the
     // residual plane when the candidate is accepted — round 3 wrote every evaluation's candidates to the mhat plane and read them back on
     // acceptance (0.5 GB of writes per 4 096-alignment launch: profiles/r03_summary.md WRITE_SIZE).  Points beyond the buffer, and the
@@ -210,9 +215,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const int li = i - lo;                                  // cache index: local to this workgroup's slice
                 const bool cached = li < CAP;
                 const int key = (pg[jj].r0 << 16) ^ (pg[jj].c0 & 0xffff);
-                miss[jj] = !(cached && s_cell[li] == key);
+                miss[jj] = !QCACHE || !(cached && s_cell[li] == key);
                 if (QUAD) {
-                    if (miss[jj] && cached) s_cell[li] = key;
+                    if (QCACHE && miss[jj] && cached) s_cell[li] = key;
                     if (QUAD == 2) {            // strips: the byte offset of the patch's first row (cached: offset 0, as below)
                         const int ra_ = clampi(pg[jj].r0, -2, frame.H) + (EDS_FRAME_MARGIN - 1), ca_ = clampi(pg[jj].c0, -2, frame.W) + (EDS_FRAME_MARGIN - 1);
                         org[jj] = miss[jj] ? (int)(eds_strips_row_offset(ra_, ca_, A.Hp, copy_bytes, A.strip_phases) | 0x80000000u) : 0;
@@ -290,14 +295,16 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         float f[4], d[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float* unit = cache + 4 * patch_unit(qcached ? qli + q : q, jr);
-                            const float4 c = *reinterpret_cast<const float4*>(unit);
                             float t[4];
                             if (QUAD == 2) { t[0] = ra[jj][q].x; t[1] = ra[jj][q].y; t[2] = ra[jj][q].z; t[3] = ra[jj][q].w; }
                             else shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
-                            const int m = oq[q] >> 31;               // all ones: gathered this pass
-                            t[0] = flag_select(m != 0, t[0], c.x); t[1] = flag_select(m != 0, t[1], c.y); t[2] = flag_select(m != 0, t[2], c.z); t[3] = flag_select(m != 0, t[3], c.w);
-                            if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
+                            if (QCACHE) {
+                                float* unit = cache + 4 * patch_unit(qcached ? qli + q : q, jr);
+                                const float4 c = *reinterpret_cast<const float4*>(unit);
+                                const int m = oq[q] >> 31;               // all ones: gathered this pass
+                                t[0] = flag_select(m != 0, t[0], c.x); t[1] = flag_select(m != 0, t[1], c.y); t[2] = flag_select(m != 0, t[2], c.z); t[3] = flag_select(m != 0, t[3], c.w);
+                                if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
+                            }
                             hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
                         }
                         quad_transpose(f, lane);
