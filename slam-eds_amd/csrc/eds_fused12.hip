@@ -293,9 +293,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         const float x0 = quad_bcast_f<0>(pg[jj].ax), x1 = quad_bcast_f<1>(pg[jj].ax), x2 = quad_bcast_f<2>(pg[jj].ax), x3 = quad_bcast_f<3>(pg[jj].ax);
                         const float xq[4] = {x0, x1, x2, x3};
                         float f[4], d[4];
+                        float tq[4][4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            float t[4];
+                            float (&t)[4] = tq[q];
                             if (QUAD == 2) { t[0] = ra[jj][q].x; t[1] = ra[jj][q].y; t[2] = ra[jj][q].z; t[3] = ra[jj][q].w; }
                             else shift_patch_row(ra[jj][q], rb[jj][q], oq[q], t);
                             if (QCACHE) {
@@ -305,13 +306,26 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                                 t[0] = flag_select(m != 0, t[0], c.x); t[1] = flag_select(m != 0, t[1], c.y); t[2] = flag_select(m != 0, t[2], c.z); t[3] = flag_select(m != 0, t[3], c.w);
                                 if (qcached) *reinterpret_cast<float4*>(unit) = make_float4(t[0], t[1], t[2], t[3]);
                             }
-                            hermite(t[0], t[1], t[2], t[3], xq[q], f[q], d[q]);
+                        }
+                        // the row splines of two patches per packed instruction, then the column spline of {value, column derivative} as one
+                        // more pair (hermite_pair: what the pose-only kernel's point phase does since round 3) — 42 packed instructions where six
+                        // scalar splines took ~100 (round 4: this kernel issued 523 vector instructions per point-evaluation)
+                        {
+                            const f2 x01 = {xq[0], xq[1]}, x23 = {xq[2], xq[3]};
+                            f2 f01, d01, f23, d23;
+                            hermite_pair((f2){tq[0][0], tq[1][0]}, (f2){tq[0][1], tq[1][1]}, (f2){tq[0][2], tq[1][2]}, (f2){tq[0][3], tq[1][3]}, x01, 0.5f * x01, 3.0f * x01, f01, d01);
+                            hermite_pair((f2){tq[2][0], tq[3][0]}, (f2){tq[2][1], tq[3][1]}, (f2){tq[2][2], tq[3][2]}, (f2){tq[2][3], tq[3][3]}, x23, 0.5f * x23, 3.0f * x23, f23, d23);
+                            f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
+                            d[0] = d01.x; d[1] = d01.y; d[2] = d23.x; d[3] = d23.y;
                         }
                         quad_transpose(f, lane);
                         quad_transpose(d, lane);
-                        float unused;
-                        hermite(f[0], f[1], f[2], f[3], pg[jj].ay, E, Er);
-                        hermite(d[0], d[1], d[2], d[3], pg[jj].ay, Ec, unused);
+                        {
+                            const f2 y2 = (f2)(pg[jj].ay);
+                            f2 EEc, dE;
+                            hermite_pair((f2){f[0], d[0]}, (f2){f[1], d[1]}, (f2){f[2], d[2]}, (f2){f[3], d[3]}, y2, 0.5f * y2, 3.0f * y2, EEc, dE);
+                            E = EEc.x; Ec = EEc.y; Er = dE.x;
+                        }
                     } else {
                     if (miss[jj] && i - lo < CAP) {
 #pragma unroll
