@@ -167,6 +167,14 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         float vf[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) vf[k] = uniformf((float)s_pose[EDS_PB_V + k]);
+        const bool one_block = nb == 1;
+        float inv_n1 = 0.0f, gv1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (one_block) {
+            const double* bk = s_pose + EDS_PB_BLK;
+            inv_n1 = uniformf((float)bk[0]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gv1[k] = uniformf((float)bk[1 + k]);
+        }
         acc4d C = {0, 0, 0, 0}, C2 = {0, 0, 0, 0};
         int cb = -1;                    // residual block the tile currently belongs to (wave-uniform)
         EDS12_PSTAMP(6);                // pose block -> registers
@@ -260,11 +268,17 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const int i_first = j0 + jj * nthr + wave * 64;        // this wavefront's 64 consecutive points
                 if (!QUAD && edsc::uniform_int(i_first) >= hi) continue;
                 const int i_last = (i_first + 63 < hi) ? i_first + 63 : hi - 1;
-                const int b_lo = edsc::uniform_int(block_of(i_first < hi ? i_first : 0, ne, nb));
-                const int b_hi = edsc::uniform_int(block_of(i_last > 0 ? i_last : 0, ne, nb));
+                // (one residual block — nb is a kernel argument, the branch is scalar: no integer divisions for the block index, and the block's
+                // constants were narrowed once per evaluation, in front of the sweep)
+                const int b_lo = one_block ? 0 : edsc::uniform_int(block_of(i_first < hi ? i_first : 0, ne, nb));
+                const int b_hi = one_block ? 0 : edsc::uniform_int(block_of(i_last > 0 ? i_last : 0, ne, nb));
                 int myb = b_lo;
                 float inv_n, gv[6];
-                if (b_lo == b_hi) {                                  // the usual case: block constants are wave-uniform
+                if (one_block) {
+                    inv_n = inv_n1;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) gv[k] = gv1[k];
+                } else if (b_lo == b_hi) {                           // the usual case: block constants are wave-uniform
                     const double* bk = s_pose + EDS_PB_BLK + EDS_PB_BLK_STRIDE * b_lo;
                     inv_n = uniformf((float)bk[0]);
 #pragma unroll
@@ -385,7 +399,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                             C = acc4d{0, 0, 0, 0}; C2 = acc4d{0, 0, 0, 0};
                             cb = b;
                         }
-                        const bool on = valid && myb == b;
+                        // (one block, plain residual: a lane without a point carries w = 0 and the constants of the slot's first point, so its row is
+                        // all zeros already — no select in front of the 13 staging stores)
+                        const bool on = (MODE == 0 && one_block) ? true : (valid && myb == b);
 #pragma unroll
                         for (int c = 0; c < 13; ++c) stage[lane * 17 + c] = on ? x[c] : 0.0f;
                         EDS_WSYNC();
