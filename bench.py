@@ -774,6 +774,30 @@ def main():
                 t_nf = pmc_traffic(nk, a)
                 if t_nf:
                     out["roofline_new_frame_per_solve"]["traffic"], out["roofline_new_frame_per_solve"]["traffic_source"] = t_nf["bytes"], t_nf["source"]
+        if world == 1 and a.exec_ == "device" and a.solver == "lm6" and not a.no_configs:
+            # The boundary takes HOST buffers (the reference hands `optimize` a std::vector<double>): what a batch costs when its frames
+            # cross PCIe inside the timed region — never `value` (the contract's inputs are resident).  256 alignments, frames new for
+            # the solve (tiles), fp64 host frames as the reference holds them, then fp32 ones (eds_trk_set_event_frame_f32).
+            nhb = min(B, 256)
+            hb = {}
+            for nm, fr in (("fp64", [frames32[b % distinct].astype(np.float64) for b in range(nhb)]), ("fp32", [frames32[b % distinct] for b in range(nhb)])):
+                ts = []
+                for k in range(3):
+                    t1 = time.perf_counter()
+                    for b in range(nhb):
+                        h.set_event_frame(b, fr[b])
+                    h.set_states(0, p0[:nhb], q0[:nhb], v0[:nhb])
+                    h.optimize_batch(0, 0, nhb, sync=True)
+                    ts.append(time.perf_counter() - t1)
+                its_hb = float(np.mean(h.results(0, nhb)[:, 14]))
+                hb[nm] = {"iterations_per_s": nhb * its_hb / float(np.median(ts)), "ms_per_batch": 1e3 * float(np.median(ts)),
+                          "host_GB_per_s": nhb * fr[0].nbytes / float(np.median(ts)) / 1e9, "kernel": h.last_launch()["kernel"]}
+                del fr
+            hb["alignments"] = nhb
+            hb["note"] = ("NOT `value`: every frame is handed over as a host buffer inside the timed region (one eds_trk_set_event_frame per alignment, then one "
+                          "launch): the upload, not the solve, is what this measures")
+            out["host_buffers_inclusive"] = hb
+            h.prepare_frames(0, B)                        # (the legs below solve resident frames again)
         if strong is not None:
             out["strong_scaling_config4"] = strong
         out["input_generation_s"] = t_gen

@@ -14,3 +14,8 @@ print("resjac", d["roofline_resjac"]["kernel_ms"], d["roofline_resjac"]["frac"],
 print("strong", d["strong_scaling_config4"]["ms_per_step"], "gen", d["input_generation_s"], "parity", d["parity"]["parity_max_se3"], d["parity"]["rows_checked"])
 print("configs", {k: (v["iterations_per_s"], v["ms_per_step"]) for k, v in d["configs"].items()})
 PY
+python - <<'PY'
+import json
+d = json.loads(open('gpurun_out/bench_r04_final.json').read().strip().splitlines()[-1])
+print("host buffers inclusive", d.get("host_buffers_inclusive"))
+PY
