@@ -172,7 +172,7 @@ __global__ __launch_bounds__(EDS_TPB) void eds_resjac_kernel(EdsArrays A, int fi
         Jo[4 * plane] = w2 * (rz * pp.g0 - rx * pp.g2);
         Jo[5 * plane] = w2 * (rx * pp.g1 - ry * pp.g0);
         // velocity part w (a/n - m (G v)/n^3) WITHOUT the local-parameterisation factor (I - v v^T/|v|^2)/|v|: it is the same
-        // for every point, so the host applies it in fp64 to the 12 x 12 sums (eds_capi.hip gather12) and to the rows it hands out
+        // for every point, so the host applies it in fp64 to the 12 x 12 sums (eds_capi_solve.hip gather12) and to the rows it hands out
 #pragma unroll
         for (int k = 0; k < 6; ++k) Jo[(6 + k) * plane] = w * (a[k] * inv_n - m * (float)bk[1 + k]);
     }
