@@ -31,9 +31,11 @@ def oracle_spread(al, kw, start, ref):
     square-root singularity s = a^2 (tools/replay_parity_case.py)."""
     prng = np.random.default_rng(12345)
     dmax, cmax = 0.0, 0.0
-    for _ in range(3):
-        alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + 6e-8 * prng.standard_normal(al.frame.shape))})
-        r = po.Oracle(alp, **kw).solve_lm(start[0] * (1 + 6e-8 * prng.standard_normal(3)), start[1], start[2])
+    # (6e-8: one fp32 rounding of the inputs; 2e-7: what the fp32 kernels' residuals are measured to differ from the fp64 oracle's by,
+    # relative to max |r| — DESIGN.md section 2 — i.e. the perturbation the GPU path really is)
+    for eps in (6e-8, 6e-8, 6e-8, 2e-7, 2e-7):
+        alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + eps * prng.standard_normal(al.frame.shape))})
+        r = po.Oracle(alp, **kw).solve_lm(start[0] * (1 + eps * prng.standard_normal(3)), start[1], start[2])
         dmax = max(dmax, po.se3_distance(r["p"], r["q"], ref["p"], ref["q"]))
         cmax = max(cmax, abs(r["final_cost"] - ref["final_cost"]))
     return dmax, cmax
@@ -93,10 +95,10 @@ for c in range(cases):
             if not same_path:
                 # legit only when a tolerance decision fell the other way: costs must then agree to the tolerance
                 dc = abs(r[3]["final_cost"] - ref["final_cost"])
-                if dc > 2e-4 * max(ref["final_cost"], 1e-12):
+                if dc > 2e-4 * max(ref["final_cost"], 1e-10):      # (costs below 1e-10 are zero to fp32 residuals: which tolerance test ends such a solve is noise)
                     spread = spread or oracle_spread(al, okw, cfg_start, ref)
                     if spread[1] > 0.3 * dc:
-                        print(tag, f"nb={nb} loss={loss}: {name} path differs (it {r[3]['num_iterations']} vs {ref['num_iterations']}) — ill-conditioned: the oracle's own cost moves by {spread[1]:.1e} on inputs perturbed by 6e-8 (difference {dc:.1e})"); chaotic += 1
+                        print(tag, f"nb={nb} loss={loss}: {name} path differs (it {r[3]['num_iterations']} vs {ref['num_iterations']}) — ill-conditioned: the oracle's own cost moves by {spread[1]:.1e} on inputs perturbed by 6e-8 .. 2e-7 (difference {dc:.1e})"); chaotic += 1
                     else:
                         print(tag, f"nb={nb} loss={loss}: {name} path differs: it {r[3]['num_iterations']} vs {ref['num_iterations']}, cost {r[3]['final_cost']:.6e} vs {ref['final_cost']:.6e}"); bad += 1
                 continue
@@ -104,7 +106,7 @@ for c in range(cases):
             if d > 5e-4 and N >= 100 and not far and sampling == 0:   # bilinear: kinks make trajectories chaotic
                 spread = spread or oracle_spread(al, okw, cfg_start, ref)
             if d > 5e-4 and N >= 100 and not far and sampling == 0 and spread[0] > 0.3 * d:
-                print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread[0]:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+                print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread[0]:.1e} on inputs perturbed by 6e-8 .. 2e-7"); chaotic += 1
             elif d > 5e-4 and N >= 100 and not far and sampling == 0:
                 print(tag, f"nb={nb} loss={loss}: {name} pose differs from the oracle by {d:.2e}"
                       f" (cost {r[3]['final_cost']:.9e} vs {ref['final_cost']:.9e}, ok steps {r[3]['num_successful_steps']} vs {ref['num_successful_steps']},"
@@ -138,10 +140,10 @@ for c in range(cases):
         def lm6_spread():
             prng = np.random.default_rng(12345)
             dmax = 0.0
-            for _ in range(4):
-                alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + 6e-8 * prng.standard_normal(al.frame.shape))})
+            for eps in (6e-8, 6e-8, 6e-8, 2e-7, 2e-7):          # (as oracle_spread)
+                alp = type(al)(**{**al.__dict__, "frame": al.frame * (1.0 + eps * prng.standard_normal(al.frame.shape))})
                 op = po.Oracle(alp, sampling=sampling)
-                pp = p0 * (1 + 6e-8 * prng.standard_normal(3)) + 6e-8 * prng.standard_normal(3) * np.abs(p0).max()
+                pp = p0 * (1 + eps * prng.standard_normal(3)) + eps * prng.standard_normal(3) * np.abs(p0).max()
                 rr = op.pose6_lm(pp, q0, cfg_start[2], iters=iters, lambda0=0.01, huber_tau=tau) if solver == "lm6" else op.pose6_gn(pp, q0, cfg_start[2], iters=iters, huber_tau=tau)
                 dmax = max(dmax, po.se3_distance(rr["p"], rr["q"], ref["p"], ref["q"]))
             return dmax
@@ -153,7 +155,7 @@ for c in range(cases):
             if d > 1e-4 and N >= 100 and not far and sampling == 0:
                 if spread6 is None: spread6 = lm6_spread()
                 if spread6 >= 0.3 * d:
-                    print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+                    print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8 .. 2e-7"); chaotic += 1
                 else:
                     print(tag, f"tau={tau}: {name} pose differs from the host loop by {d:.2e}"); bad += 1
         if solver == "lm6" and sampling == 0 and not far and N >= 100:
@@ -161,7 +163,7 @@ for c in range(cases):
             if from_dev > 5e-4:
                 if spread6 is None: spread6 = lm6_spread()
                 if spread6 >= 0.3 * from_dev:
-                    print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8"); chaotic += 1
+                    print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e} — ill-conditioned: the oracle's own pose moves by {spread6:.1e} on inputs perturbed by 6e-8 .. 2e-7"); chaotic += 1
                 else:
                     print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
 print(f"{cases} cases ({stats}), {bad} disagreements" + (f", {chaotic} differences on ill-conditioned cases (the oracle itself moves as much)" if chaotic else ""))
