@@ -673,8 +673,9 @@ def main():
                     "achieved_must_move": ach_mm, "frac_must_move": ach_mm / HBM_PEAK_GBS, "must_move_bytes_per_launch": B * N * passes * mm,
                     "frame_layout": {0: "row-major", 1: "4x4 tiles", 2: "strips"}.get(launch["layout"], "?"),
                     "note": f"achieved/frac: SURVEY 8d credit, {per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch "
-                            f"(a fused kernel is credited the J bytes it never moves); *_must_move: {mm} B per point-evaluation "
-                            f"(point constants + taps only)"}
+                            f"(a fused kernel is credited the J bytes it never moves, so this credit can exceed 1.0 and is NOT the fraction of the "
+                            f"HBM rate in use); *_must_move: {mm} B per point-evaluation (point constants + taps only) - the figure to read as a "
+                            f"fraction of the 8 TB/s peak"}
             t = pmc_traffic(launch["kernel"], a)
             if t:
                 roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]

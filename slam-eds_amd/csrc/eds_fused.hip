@@ -27,6 +27,9 @@
 
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
+#ifndef EDS_GATHER_STAGES
+#define EDS_GATHER_STAGES 2      // groups the strip kernels consume their points in, each behind a counted wait (1: one wait for all rows)
+#endif
 #include "eds_handle.hpp"
 #include "eds_launch_rule.hpp"
 #include "eds_math.hpp"
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
             const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
             const unsigned row_add = 0x80000000u + 32u * (unsigned)jr;
+            int nld[NREG];                               // row-load instructions this wavefront really issued for point j (wave-uniform)
 #pragma unroll
             for (int g = 0; g < NPAIR; ++g) {
                 int r0[2], c0[2];
@@ -283,6 +287,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int j = 2 * g + e, i = tid + j * nthr;
+                    nld[j] = 0;
                     const int key = (r0[e] << 16) ^ (c0[e] & 0xffff);
                     const bool miss = s_cell[i] != key;
                     EDS_COUNT_MISS(miss && i < N);
@@ -292,13 +297,25 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     const int o0 = quad_bcast_i<0>(off), o1 = quad_bcast_i<1>(off), o2 = quad_bcast_i<2>(off), o3 = quad_bcast_i<3>(off);
                     const int oq[4] = {o0, o1, o2, o3};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (oq[q] < 0 && (SAMPLING == 0 || jr == 1 || jr == 2))      // (the bilinear sampler reads rows 1 and 2 of the patch only)
+                    for (int q = 0; q < 4; ++q) {
+                        const bool need = oq[q] < 0 && (SAMPLING == 0 || jr == 1 || jr == 2);      // (the bilinear sampler reads rows 1 and 2 of the patch only)
+                        if (need)
                             __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * 256), 16, 0, 0);
+                        if (EDS_GATHER_STAGES > 1) nld[j] += __ballot(need) != 0ull ? 1 : 0;
+                    }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): every row has landed (each lane reads back only what it fetched itself)
-            asm volatile("" ::: "memory");
+            // Loads return in order, so "at most n outstanding" with n = the loads issued for LATER points means this point's rows have
+            // landed: the points are consumed in EDS_GATHER_STAGES groups, each behind its own counted wait, while the rows of the groups
+            // behind it are still on their way.  (n rounded down to the immediates below: a stricter wait, never a laxer one.)
+            auto wait_rows_but = [](int later) {
+                if (later >= 12) __builtin_amdgcn_s_waitcnt(0x0F7C);
+                else if (later >= 8) __builtin_amdgcn_s_waitcnt(0x0F78);
+                else if (later >= 4) __builtin_amdgcn_s_waitcnt(0x0F74);
+                else __builtin_amdgcn_s_waitcnt(0x0F70);
+                asm volatile("" ::: "memory");
+            };
+            if (EDS_GATHER_STAGES <= 1) wait_rows_but(0);        // vmcnt(0): every row has landed (each lane reads back only what it fetched itself)
             // phase B: the rows of two patches per packed instruction straight out of LDS (ds_read2st64_b32 pairs {q, q + 1}), the
             // transposes, the column spline of {value, column derivative}, the row and its 28 products
             Acc6 A6;
@@ -307,6 +324,17 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
             for (int j = 0; j < NREG; ++j) {
                 const int g = j >> 1;
+                if (EDS_GATHER_STAGES > 1 && j % (NREG / (EDS_GATHER_STAGES < NREG ? EDS_GATHER_STAGES : NREG)) == 0) {
+                    constexpr int per = NREG / (EDS_GATHER_STAGES < NREG ? EDS_GATHER_STAGES : NREG);
+                    int later = 0;
+#pragma unroll
+                    for (int jj = 0; jj < NREG; ++jj)
+                        if (jj >= j + per) later += nld[jj];
+                    // (the group before this wait must really be computed before it: without the tie the scheduler sinks its arithmetic below
+                    // the wait and reads every group's rows up front)
+                    if (j > 0) asm volatile("" : "+v"(rcand[j - 1]) :: "memory");
+                    wait_rows_but(later);
+                }
                 const float ax_j = (j & 1) ? pg[g].ax.y : pg[g].ax.x, ay_j = (j & 1) ? pg[g].ay.y : pg[g].ay.x;
                 if constexpr (SAMPLING == 1) {
                     // bilinear: the lane's own point needs pixels 1-2 of rows 1-2 of its patch — the rows quad lanes 1 and 2 fetched

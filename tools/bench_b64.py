@@ -9,9 +9,11 @@ als = [synth.make_alignment(5000 + i) for i in range(16)]
 fr = [np.ascontiguousarray(a.frame, dtype=np.float32) for a in als]
 for B in Bs:
     ref = None
-    for team in ("", "4", "2", "1"):
+    for team, gather in (("", ""), ("", "lane"), ("4", ""), ("2", ""), ("2", "lane"), ("1", ""), ("1", "lane")):
         if team: os.environ["EDS_LM6_TEAM"] = team
         else: os.environ.pop("EDS_LM6_TEAM", None)
+        if gather: os.environ["EDS_FUSED_GATHER"] = gather
+        else: os.environ.pop("EDS_FUSED_GATHER", None)
         h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10), B, 2000, 480, 640)
         for b in range(B):
             a = als[b % 16]; h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy); h.set_event_frame(b, fr[b % 16])
@@ -21,5 +23,5 @@ for B in Bs:
             h.set_states(0, p0, q0, v0); t = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); ts.append(time.perf_counter() - t); ds.append(h.info(0)["device_time_us"])
         tab = h.results(0, B)[:, :7].copy()
         if ref is None: ref = tab
-        print(f"B={B:4d} EDS_LM6_TEAM={team or 'auto':4s}: wall {np.median(ts[5:])*1e6:7.1f} us  kernel {np.median(ds[5:]):7.1f} us  {h.last_launch()['kernel']}  max|dpose| vs auto {np.abs(tab-ref).max():.1e}", flush=True)
+        print(f"B={B:4d} EDS_LM6_TEAM={team or 'auto':4s} gather={gather or 'rule':4s}: wall {np.median(ts[5:])*1e6:7.1f} us  kernel {np.median(ds[5:]):7.1f} us  {h.last_launch()['kernel']}  max|dpose| vs auto {np.abs(tab-ref).max():.1e}", flush=True)
         h.close()
