@@ -30,6 +30,7 @@ The same JSON line carries
                 T residual blocks evaluated on T threads (Tracker.cpp:178-195) for T in {1, 8, all}
 """
 import argparse
+import gc
 import importlib
 import json
 import os
@@ -434,25 +435,44 @@ def strong_scaling_config4(capi, synth, batchmod, a, rank, world, local_rank, de
     V0 = np.stack([x.v0 for x in als]) if count else np.zeros((0, 6))
     g = batchmod.ResultGatherer(TOTAL, device=dev, to_host=(rank == 0), force=forced)
 
+    dbg = bool(os.environ.get("EDS_BENCH_DEBUG"))
+
     def step():
+        ta = time.perf_counter()
         if count:
             h.set_states(0, P0, Q0, V0)
+            tb = time.perf_counter()
             h.optimize_batch(0, 0, count, sync=True)
+        tc = time.perf_counter()
         g.start(h.results(0, count) if count else np.zeros((0, batchmod.RESULT_WIDTH)))
-        return g.finish()
+        out_ = g.finish()
+        if dbg and count and time.perf_counter() - ta > 1e-3:
+            sys.stderr.write(f"[bench] strong-scaling step on rank {rank}: set_states {1e3 * (tb - ta):.3f} ms, optimize {1e3 * (tc - tb):.3f} ms, gather "
+                             f"{1e3 * (time.perf_counter() - tc):.3f} ms, kernel {h.info(0)['device_time_us']:.1f} us, flags {h.info(0)['flags']}\n")
+        return out_
 
+    tg_ = time.perf_counter(); gc.collect(); gc_ms = 1e3 * (time.perf_counter() - tg_)
+    gc.disable()                                     # (as for the headline loop: no interpreter collection inside a timed region, no idle gap in front of it)
     for _ in range(warmup):
         table = step()
     if world > 1 or forced:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_ms, timeouts, paused = [], 0, 0
     for _ in range(steps):
+        ts_ = time.perf_counter()
         table = step()
+        step_ms.append(1e3 * (time.perf_counter() - ts_))
+        if count:                                    # the library's own diagnostics of the step (include/eds_hip.h: EDS_INFO_*)
+            fl = h.info(0)["flags"]
+            timeouts += 1 if fl & capi.INFO_TEAM_TIMEOUT else 0
+            paused += 1 if fl & capi.INFO_TEAMS_PAUSED else 0
     torch.cuda.synchronize()
     if world > 1 or forced:
         dist.barrier()
     el = time.perf_counter() - t0
+    gc.enable()
     if world > 1 or forced:
         tt = torch.tensor([el], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -469,7 +489,11 @@ def strong_scaling_config4(capi, synth, batchmod, a, rank, world, local_rank, de
             "ms_per_step": 1e3 * el / steps, "iterations_per_s": TOTAL * its / (el / steps), "alignments_per_s": TOTAL / (el / steps),
             "kernel": launch["kernel"] if launch else None, "cus_per_alignment": launch["cus_per_alignment"] if launch else None, "kernel_ms_rank0": k_us * 1e-3,
             "success_fraction": float(np.mean(table[:, 15])), "rows_gathered": int(table.shape[0]),
-            "note": "strong scaling (total work fixed): informational beside `value`, which is weak scaling at 4 096 alignments per GPU"}
+            "median_ms_per_step_rank0": float(np.median(step_ms)), "max_ms_per_step_rank0": float(np.max(step_ms)),
+            "team_timeouts_rank0": timeouts, "steps_with_teams_paused_rank0": paused, "step_ms_rank0": [round(x, 3) for x in step_ms],
+            "interpreter_full_gc_ms": gc_ms,        # what ONE full collection of CPython's collector costs in this process (kept out of the timed regions)
+            "note": "strong scaling (total work fixed): informational beside `value`, which is weak scaling at 4 096 alignments per GPU; ms_per_step is the mean "
+                    "over the steps (MAX over ranks); a team of CUs that did not assemble within 50 ms is re-run on one CU per alignment and counted here"}
 
 
 def spawn_ranks(a):
@@ -607,6 +631,11 @@ def main():
         table = gatherer.finish() if prev_local is not None else None
         return h.results(0, B), table
 
+    # The timed region measures the library, not the interpreter: with torch imported a full (generation-2) collection of CPython's cyclic
+    # garbage collector walks several 10^5 objects — 40-150 ms in this process, dozens of headline steps — whenever its allocation counters
+    # happen to trip (seen as ONE 74.7 ms step in 2 of 5 runs of the strong-scaling block below).  Collect now — BEFORE the warm-up, so that
+    # no idle gap separates warm-up and timed steps — and keep the collector off until the clock stops.
+    gc.collect(); gc.disable()
     for _ in range(a.warmup):
         table = step()
         if world > 1 or forced:
@@ -637,6 +666,7 @@ def main():
     if world > 1 or forced:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1 or forced:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

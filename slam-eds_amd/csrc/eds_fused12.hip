@@ -33,6 +33,9 @@
 
 #include "eds_device.hpp"
 #include "eds_fused.hpp"
+#ifndef EDS_REF12_PREFETCH
+#define EDS_REF12_PREFETCH 1
+#endif
 #include "eds_handle.hpp"
 #include "eds_launch_rule.hpp"
 #include "eds_math.hpp"
@@ -186,8 +189,32 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         auto sweep = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             const size_t jplane = (size_t)A.B * A.Np;
+        // (batch shape on the strips: the NEXT step's point constants are asked for while this step computes — a step was two trips to
+        // memory in a row, constants then rows, on two wavefronts per SIMD)
+        constexpr bool PREF = EDS_REF12_PREFETCH && QUAD == 2 && NTHR == 256 && MODE == 0;
+        float pc[2][9];
+        auto fetch_consts = [&](int j0_, float (&dst)[2][9]) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int i = j0_ + jj * nthr + tid;
+                const float* __restrict__ c = A.kf + base + (i < hi ? i : 0);
+                const size_t pl = A.kf_plane;
+                dst[jj][0] = c[EDS_KF_X * pl]; dst[jj][1] = c[EDS_KF_Y * pl]; dst[jj][2] = c[EDS_KF_RHO * pl]; dst[jj][3] = c[EDS_KF_W * pl];
+                dst[jj][4] = c[EDS_KF_GX * pl]; dst[jj][5] = c[EDS_KF_GY * pl]; dst[jj][6] = c[EDS_KF_F0X * pl]; dst[jj][7] = c[EDS_KF_F0Y * pl];
+                dst[jj][8] = c[EDS_KF_CELL0 * pl];
+            }
+        };
+        if (PREF) fetch_consts(lo, pc);
         for (int j0 = lo; j0 < hi; j0 += 2 * nthr) {
             // phase A: two points per lane: constants from HBM/L2, projection, cache probe, gathers in flight
+            float cc[2][9];
+            if (PREF) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) cc[jj][k] = pc[jj][k];
+                fetch_consts(j0 + 2 * nthr, pc);
+            }
             PointKf kf[2];
             float kw[2], kgx[2], kgy[2];
             PointGeom pg[2];
@@ -210,15 +237,22 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 const size_t o = base + (valid ? i : 0);
                 const float* __restrict__ c = A.kf + o;                 // one base pointer, nine planes (eds_layout.hpp EDS_KF_*)
                 const size_t pl = A.kf_plane;
-                kf[jj].x = c[EDS_KF_X * pl]; kf[jj].y = c[EDS_KF_Y * pl]; kf[jj].rhop = c[EDS_KF_RHO * pl] + 1e-5f;
-                kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;
-                kgx[jj] = c[EDS_KF_GX * pl]; kgy[jj] = c[EDS_KF_GY * pl];
+                if (PREF) {
+                    kf[jj].x = cc[jj][0]; kf[jj].y = cc[jj][1]; kf[jj].rhop = cc[jj][2] + 1e-5f;
+                    kw[jj] = valid ? cc[jj][3] : 0.0f;
+                    kgx[jj] = cc[jj][4]; kgy[jj] = cc[jj][5];
+                } else {
+                    kf[jj].x = c[EDS_KF_X * pl]; kf[jj].y = c[EDS_KF_Y * pl]; kf[jj].rhop = c[EDS_KF_RHO * pl] + 1e-5f;
+                    kw[jj] = valid ? c[EDS_KF_W * pl] : 0.0f;
+                    kgx[jj] = c[EDS_KF_GX * pl]; kgy[jj] = c[EDS_KF_GY * pl];
+                }
                 miss[jj] = false;
 #ifdef EDS_FUSED_STAMPS
                 if (jj == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); EDS12_PSTAMP(7); }     // (diagnostic builds wait for the constants here)
 #endif
                 if (MODE == 2) continue;                                // rows come from the stash: no projection, no gather
-                kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]);
+                if (PREF) { kf[jj].f0x = cc[jj][6]; kf[jj].f0y = cc[jj][7]; kf[jj].cell0 = __float_as_int(cc[jj][8]); }
+                else { kf[jj].f0x = c[EDS_KF_F0X * pl]; kf[jj].f0y = c[EDS_KF_F0Y * pl]; kf[jj].cell0 = __float_as_int(c[EDS_KF_CELL0 * pl]); }
                 project_point(ps, kf[jj], pg[jj]);
                 const int li = i - lo;                                  // cache index: local to this workgroup's slice
                 const bool cached = li < CAP;
