@@ -604,6 +604,7 @@ def main():
     # to itself the library makes them when a frame is solved a SECOND time (they cost more than one solve gains: eds_strips.hip), which
     # the warm-up steps would trigger as well; made explicitly here so that no --warmup value moves them into the timed steps.  Their
     # cost is reported (frame_layout_prep) and so is the rate of solves on frames that are new every time (new_frame_per_solve).
+    gc.collect(); gc.disable()                       # (see the note at the warm-up loop below)
     h.prepare_frames(0, B)
     p0 = np.stack([als[b % distinct].p0 for b in range(B)])
     q0 = np.stack([als[b % distinct].q0 for b in range(B)])
@@ -634,8 +635,8 @@ def main():
     # The timed region measures the library, not the interpreter: with torch imported a full (generation-2) collection of CPython's cyclic
     # garbage collector walks several 10^5 objects — 40-150 ms in this process, dozens of headline steps — whenever its allocation counters
     # happen to trip (seen as ONE 74.7 ms step in 2 of 5 runs of the strong-scaling block below).  Collect now — BEFORE the warm-up, so that
-    # no idle gap separates warm-up and timed steps — and keep the collector off until the clock stops.
-    gc.collect(); gc.disable()
+    # no idle gap separates warm-up and timed steps — and keep the collector off until the clock stops.  (The collection itself sits in
+    # front of prepare_frames above, so that the GPU is busy from there to the last timed step.)
     for _ in range(a.warmup):
         table = step()
         if world > 1 or forced:
