@@ -103,7 +103,13 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     constexpr int NREG = PPT > 0 ? PPT : 1;
     constexpr bool CACHE = true;
     constexpr int NPATCH = (QUAD >= 3) ? 16 : NTAP;      // the strips' landing zone holds 4 rows x 4 pixels per point whatever the sampler reads of them
-    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NPATCH : 1][CACHE ? EDS_CACHE_CAP : 1];
+    // (the bilinear sampler on the strips reads two 16-byte units of OTHER lanes' rows per point: its landing slots are 1 KB + 16 bytes apart
+    // — ZSH floats of slack behind every slot — so that the four lanes of a quad, which read the same units of four consecutive slots, do
+    // not meet in one bank group: 16-way conflicts on every read before, profiles/r04_sq_counters.txt)
+    constexpr int ZSH = (QUAD >= 3 && SAMPLING == 1) ? 4 : 0;
+    constexpr int ZSLOT = 256 + ZSH;                     // floats from one landing slot (64 lanes x 16 bytes) to the next
+    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NPATCH : 1][CACHE ? EDS_CACHE_CAP + 8 * ZSH : 1];
+    static_assert(QUAD < 3 || (MAXT / 64) * NREG * 4 * ZSLOT <= NPATCH * (EDS_CACHE_CAP + 8 * ZSH), "landing zone exceeds its allocation");
     __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             EDS_LOAD_POSE_SCALARS(rtf, s_posef + 12);
             PairGeom pg[NPAIR];
             const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-            float* __restrict__ zone = &s_patch[0][0] + wave_u * (NREG * 4 * 256);
+            float* __restrict__ zone = &s_patch[0][0] + wave_u * (NREG * 4 * ZSLOT);
             const unsigned copy_bytes = (unsigned)(eds_strips_copy_elems(A.Hp, A.Wp) * 4);
             const char* __restrict__ sbase = reinterpret_cast<const char*>(A.strips) + (size_t)(unsigned)fslot * ((size_t)(2 * A.strip_phases) * copy_bytes);
             const unsigned row_add = 0x80000000u + 32u * (unsigned)jr;
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                     for (int q = 0; q < 4; ++q) {
                         const bool need = oq[q] < 0 && (SAMPLING == 0 || jr == 1 || jr == 2);      // (the bilinear sampler reads rows 1 and 2 of the patch only)
                         if (need)
-                            __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * 256), 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * ZSLOT), 16, 0, 0);
                         if (EDS_GATHER_STAGES > 1) nld[j] += __ballot(need) != 0ull ? 1 : 0;
                     }
                 }
@@ -339,8 +345,9 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 if constexpr (SAMPLING == 1) {
                     // bilinear: the lane's own point needs pixels 1-2 of rows 1-2 of its patch — the rows quad lanes 1 and 2 fetched
                     // (the wavefront's vmcnt(0) covers every lane's loads): four LDS reads, no row pass, no transposes
-                    const float* __restrict__ r1 = zone + (4 * j + (lane & 3)) * 256 + 4 * ((lane & ~3) + 1);
-                    const float p4[4] = {r1[1], r1[2], r1[5], r1[6]};          // row 2 sits one lane (4 floats) further
+                    const float* __restrict__ r1 = zone + (4 * j + (lane & 3)) * ZSLOT + 4 * ((lane & ~3) + 1);
+                    const float4 u1 = *reinterpret_cast<const float4*>(r1), u2 = *reinterpret_cast<const float4*>(r1 + 4);      // rows 1 and 2 as whole 16-byte units
+                    const float p4[4] = {u1.y, u1.z, u2.y, u2.z};              // (row 2 sits one lane — 4 floats — further)
                     float E, Er, Ec;
                     bilinear_patch(p4, ay_j, ax_j, E, Er, Ec);
                     const float iz_b = (j & 1) ? pg[g].iz.y : pg[g].iz.x, un_b = (j & 1) ? pg[g].un.y : pg[g].un.x, vn_b = (j & 1) ? pg[g].vn.y : pg[g].vn.x;
@@ -352,8 +359,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 f2 ta[4], tb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    ta[k] = (f2){mine[(4 * j + 0) * 256 + k], mine[(4 * j + 1) * 256 + k]};
-                    tb[k] = (f2){mine[(4 * j + 2) * 256 + k], mine[(4 * j + 3) * 256 + k]};
+                    ta[k] = (f2){mine[(4 * j + 0) * ZSLOT + k], mine[(4 * j + 1) * ZSLOT + k]};
+                    tb[k] = (f2){mine[(4 * j + 2) * ZSLOT + k], mine[(4 * j + 3) * ZSLOT + k]};
                 }
                 f2 f01, d01, f23, d23;
                 hermite_pair(ta[0], ta[1], ta[2], ta[3], x01, 0.5f * x01, 3.0f * x01, f01, d01);
