@@ -176,6 +176,42 @@ def test_ref12_batch_kernels_at_the_bench_shape_vs_oracle(gpu, capi, synth, po, 
 
 
 @pytest.mark.parametrize("sampling", [0, 1])
+@pytest.mark.parametrize("npts", [900, 2000])
+def test_strip_kernels_warm_started_at_the_solution(gpu, capi, synth, po, sampling, npts):
+    """The strip kernels consume a lane's points in groups behind COUNTED waits (s_waitcnt vmcnt(n), n = the row loads the wavefront really
+    issued for the later group, eds_fused.hip): a cold solve issues every load.  Here the second and third solves START AT THE SOLUTION of
+    the one before: the candidates move the points by fractions of a pixel, nearly every patch is still in the landing zone, whole load
+    instructions are skipped and the counts run through their small values — the result must still be the oracle's from the same start
+    (and the kernel the strips one: 2 and 4 points per lane)."""
+    H, W, D = 120, 160, 4
+    B = 40 if npts <= 1024 else 136          # (2 000 points: up to 128 alignments go out on teams of 4 CUs, which sample the tiles)
+    als = [synth.make_alignment(1300 + i, H=H, W=W, N=npts - 11 * i, margin=2) for i in range(D)]
+    cfg = capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, sampling=sampling, max_num_iterations=6)
+    h = capi.Handle(cfg, B, npts, H, W)
+    for b in range(B):
+        h.set_alignment(b, als[b % D])
+    h.prepare_frames(0, B)
+    ps, qs = np.array([1e-3, -2e-3, 5e-4]), synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
+    P, Q, V = np.stack([ps] * B), np.stack([qs] * B), np.stack([als[b % D].v0 for b in range(B)])
+    for round_ in range(3):
+        h.set_states(0, P, Q, V)
+        h.optimize_batch(0, 0, B)
+        tab = h.results(0, B)
+        li = h.last_launch()
+        assert li["layout"] == 2 and li["kernel"].startswith(f"eds_fused6_kernel<{sampling}, {2 if npts <= 1024 else 4}, 512, 3, 1>"), li
+        for d, a in enumerate(als):
+            ref = po.Oracle(a, sampling=sampling).pose6_lm(P[d], Q[d], a.v0, iters=6, lambda0=cfg.lambda0)
+            for slot in (d, d + D * ((B - 1 - d) // D)):
+                dist = po.se3_distance(tab[slot, 0:3], tab[slot, 3:7], ref["p"], ref["q"])
+                # the bilinear sampler's derivative is one-sided at pixel boundaries: a warm start may sit on one (see DESIGN.md) — its poses are
+                # compared at the fp32 level of the sampler, the bicubic ones at the suite's tolerance
+                assert dist <= (TOL_POSE if sampling == 0 else 2e-3), (round_, li["kernel"], slot, dist)
+                assert np.array_equal(tab[slot, 0:7], tab[d, 0:7]), (round_, slot)          # replicas bit for bit
+        P, Q = tab[:, 0:3].copy(), tab[:, 3:7].copy()                                        # next round: from this solution
+    h.close()
+
+
+@pytest.mark.parametrize("sampling", [0, 1])
 @pytest.mark.parametrize("count", [8, 40, 300])
 @pytest.mark.parametrize("npts", [700, 1753, 3000])
 def test_sampler_is_honoured_at_every_batch_size(gpu, capi, synth, po, sampling, count, npts):
