@@ -344,7 +344,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 const float ax_j = (j & 1) ? pg[g].ax.y : pg[g].ax.x, ay_j = (j & 1) ? pg[g].ay.y : pg[g].ay.x;
                 if constexpr (SAMPLING == 1) {
                     // bilinear: the lane's own point needs pixels 1-2 of rows 1-2 of its patch — the rows quad lanes 1 and 2 fetched
-                    // (the wavefront's vmcnt(0) covers every lane's loads): four LDS reads, no row pass, no transposes
+                    // (the wavefront's counted wait covers every lane's loads of this point): two 16-byte LDS reads, no row pass, no transposes
                     const float* __restrict__ r1 = zone + (4 * j + (lane & 3)) * ZSLOT + 4 * ((lane & ~3) + 1);
                     const float4 u1 = *reinterpret_cast<const float4*>(r1), u2 = *reinterpret_cast<const float4*>(r1 + 4);      // rows 1 and 2 as whole 16-byte units
                     const float p4[4] = {u1.y, u1.z, u2.y, u2.z};              // (row 2 sits one lane — 4 floats — further)
