@@ -429,12 +429,16 @@ class Handle:
         _check(lib().eds_trk_get_states(self._h, first, count, _p(p), _p(q), _p(v)))
         return p, q, v
 
-    def results(self, first=0, count=None):
-        """count x 16 table: p[3] q[4] v[6] final_cost iterations success."""
+    def results(self, first=0, count=None, out=None):
+        """count x 16 table: p[3] q[4] v[6] final_cost iterations success.  `out`: a C-contiguous float64 array of that shape to fill
+        (a caller that steps in a loop keeps one: a fresh half-megabyte array per call is an mmap and its page faults)."""
         count = self.batch - first if count is None else count
-        t = np.empty((count, 16))               # (the call fills every column; zeroing half a megabyte per step of a 4 096-alignment batch was 10 us)
-        _check(lib().eds_trk_get_results(self._h, first, count, _p(t)))
-        return t
+        if out is None:
+            out = np.empty((count, 16))         # (the call fills every column)
+        elif out.shape != (count, 16) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise EdsError(ERR_INVALID, "results(out=...): a C-contiguous float64 array of shape (count, 16)")
+        _check(lib().eds_trk_get_results(self._h, first, count, _p(out)))
+        return out
 
     # -- evaluation / solve --------------------------------------------------------------
     def eval(self, slot, p, q, v, ncols=6, want_jacobian=True):
