@@ -26,6 +26,7 @@
 #ifndef EDS_HIP_H_
 #define EDS_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -39,8 +40,11 @@ extern "C" {
  * call eds_kf_select_default first, as the header always said).
  * 4 (round 4): tuning knobs are per HANDLE — read from the environment once, at eds_trk_create, and changed with eds_trk_set_knob; no
  * entry point reads the environment afterwards.  New entry points: eds_trk_set_knob, eds_trk_get_strips_info, eds_gather_results*
- * (RCCL gather of the result table for a C / C++ caller).  Nothing was removed or re-ordered. */
-#define EDS_HIP_ABI_VERSION 4
+ * (RCCL gather of the result table for a C / C++ caller).  Nothing was removed or re-ordered.
+ * 5 (round 5): new entry points eds_trk_bench_kernel_cold, eds_trk_hbm_probe (measurement), eds_trk_set_event_frames (many host frames,
+ * narrowed on a thread pool), eds_trk_kernel_instances (the compiled instantiation lists); new knob EDS_LM6_GROUPS (candidate groups
+ * of the team kernel).  Nothing was removed or re-ordered. */
+#define EDS_HIP_ABI_VERSION 5
 #define EDS_MAX_LEVELS 8
 
 typedef enum eds_status {
@@ -382,6 +386,14 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the 
  * [first, first+count) `reps` times back-to-back at the stored states and reports the mean
  * duration per launch in ms, measured with HIP events on the handle's stream. */
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
+/* ABI 5.  ONE kernel of the streaming path timed COLD: before every repetition 1 GiB is streamed through the caches (the Infinity
+ * Cache holds 256 MB), then the kernel runs between its own pair of HIP events; mean over `reps`.  which: 0 the residual/Jacobian
+ * kernel, 1 the reduction kernel over the planes of a residual/Jacobian pass made beforehand. */
+int eds_trk_bench_kernel_cold(eds_trk* h, int first, int count, int ncols, int which, int reps, float* mean_ms);
+/* ABI 5.  What the box's HBM streams through the library's OWN plain kernel (16 bytes per lane, grid-stride) over `bytes` of scratch:
+ * a read-only pass and a copy (read + write counted), GB/s, HIP events on the handle's stream (the measured peak beside
+ * the nominal 8 TB/s). */
+int eds_trk_hbm_probe(eds_trk* h, size_t bytes, int reps, float* read_GBps, float* copy_GBps);
 /* Latency of the live sequence measured INSIDE the library's language (no interpreter between the calls): `reps` times
  *   [eds_trk_set_idepth(idp)] -> [eds_trk_set_event_frame(frame)] -> eds_trk_optimize(level, p0, q0, v0) -> [eds_trk_residuals_and_loss(method)]
  * on `slot` (Tracker.cpp:167 -> EventFrame -> :104-241 -> :223-233), each from the same start state; the bracketed calls are skipped when

@@ -41,7 +41,7 @@ EXPORTS = (
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_last_launch", "eds_trk_prepare_frames",
-    "eds_trk_set_knob", "eds_trk_get_strips_info",
+    "eds_trk_set_knob", "eds_trk_get_strips_info", "eds_trk_bench_kernel_cold", "eds_trk_hbm_probe",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
     "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
@@ -202,6 +202,8 @@ def lib():
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
         L.eds_trk_bench_live.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        L.eds_trk_bench_kernel_cold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
+        L.eds_trk_hbm_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _fp, _fp]
         L.eds_pyr_create.argtypes = [C.POINTER(Cfg), C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.eds_pyr_destroy.argtypes = [C.c_void_p]
         L.eds_pyr_destroy.restype = None
@@ -624,6 +626,20 @@ class Handle:
         ms = C.c_float(0.0)
         _check(lib().eds_trk_bench_eval(self._h, first, count, ncols, int(with_reduction), reps, C.byref(ms)))
         return ms.value
+
+
+    def bench_kernel_cold(self, first, count, ncols=6, which=0, reps=10) -> float:
+        """One streaming kernel (which: 0 residual/Jacobian, 1 reduction) timed cold — 1 GiB streamed through the caches in front of
+        every repetition; mean ms per launch (HIP events on the handle's stream)."""
+        ms = C.c_float(0.0)
+        _check(lib().eds_trk_bench_kernel_cold(self._h, first, count, ncols, int(which), reps, C.byref(ms)))
+        return ms.value
+
+    def hbm_probe(self, nbytes=1 << 30, reps=10) -> dict:
+        """What the box's HBM streams through the library's own plain kernel: read-only pass and copy (read + write counted), GB/s."""
+        r, c = C.c_float(0.0), C.c_float(0.0)
+        _check(lib().eds_trk_hbm_probe(self._h, int(nbytes), reps, C.byref(r), C.byref(c)))
+        return {"read_GBps": r.value, "copy_GBps": c.value, "bytes": int(nbytes), "reps": reps}
 
 
 class Pyramid:

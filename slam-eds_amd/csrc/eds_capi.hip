@@ -96,7 +96,7 @@ void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     void* dptrs[] = {h->dkf, h->dpose, h->dG, h->dpart, h->dncstat,
-                     h->dmhat, h->dframe, h->dr, h->dJ};
+                     h->dmhat, h->dframe, h->dr, h->dJ, h->d_probe};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
     eds_strips_free(h);

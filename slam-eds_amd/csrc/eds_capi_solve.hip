@@ -486,6 +486,100 @@ int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_red
     return EDS_OK;
 }
 
+// ---- measurement helpers of bench.py (round 5) -------------------------------------------------------------------------------------
+// A plain streaming kernel of the library's own: 16 bytes per lane, grid-stride, 8 192 workgroups of 256 threads — what the box's HBM
+// gives a coalesced read (mode 0), a copy (1).  Also the EVICTION pass of the cold timings below: 1 GiB through the caches.
+__global__ __launch_bounds__(256) void eds_probe_kernel(const float4* __restrict__ a, float4* __restrict__ b, float* __restrict__ sink, size_t n, int mode) {
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = a[i];
+        if (mode == 1) b[i] = v; else acc += v.x + v.y + v.z + v.w;
+    }
+    if (mode == 0 && acc == 12345.678f) sink[0] = acc;
+}
+
+static int probe_buffers(eds_trk* h, size_t bytes) {
+    if (h->probe_bytes >= bytes) return EDS_OK;
+    if (h->d_probe) { hipFree(h->d_probe); h->d_probe = nullptr; h->probe_bytes = 0; }
+    EDS_HIP_TRY(hipMalloc(&h->d_probe, 2 * bytes + 256));
+    EDS_HIP_TRY(hipMemsetAsync(h->d_probe, 0, 2 * bytes + 256, h->st));
+    h->probe_bytes = bytes;
+    return EDS_OK;
+}
+
+int eds_trk_hbm_probe(eds_trk* h, size_t bytes, int reps, float* read_GBps, float* copy_GBps) {
+    if (!h || !read_GBps || !copy_GBps) return fail(EDS_ERR_INVALID, "null argument");
+    if (bytes < (1u << 20) || reps < 1) return fail(EDS_ERR_INVALID, "bad size");
+    bytes &= ~(size_t)255;
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    int rc = probe_buffers(h, bytes);
+    if (rc) return rc;
+    const float4* a = reinterpret_cast<const float4*>(h->d_probe);
+    float4* b = reinterpret_cast<float4*>(reinterpret_cast<char*>(h->d_probe) + bytes);
+    float* sink = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_probe) + 2 * bytes);
+    const size_t n = bytes / 16;
+    for (int mode = 0; mode < 2; ++mode) {
+        hipLaunchKernelGGL(eds_probe_kernel, dim3(8192), dim3(256), 0, h->st, a, b, sink, n, mode);      // warm-up
+        EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(eds_probe_kernel, dim3(8192), dim3(256), 0, h->st, a, b, sink, n, mode);
+        EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
+        EDS_HIP_TRY(hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        EDS_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        const float gbps = (float)((double)(mode == 1 ? 2 : 1) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9);
+        if (mode == 0) *read_GBps = gbps; else *copy_GBps = gbps;
+    }
+    EDS_HIP_TRY(hipGetLastError());
+    return EDS_OK;
+}
+
+// One kernel of the streaming path timed COLD: before every repetition 1 GiB is streamed through the caches (the Infinity Cache holds
+// 256 MB: the planes the previous kernel wrote, or the frames an earlier repetition read, are gone), then the kernel runs between its
+// own pair of events.  which: 0 the residual/Jacobian kernel, 1 the reduction kernel (over the planes of a residual/Jacobian pass made
+// beforehand).  Reports the mean over the repetitions.
+int eds_trk_bench_kernel_cold(eds_trk* h, int first, int count, int ncols, int which, int reps, float* mean_ms) {
+    if (!h || !mean_ms) return fail(EDS_ERR_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > h->B || reps < 1) return fail(EDS_ERR_INVALID, "bad range");
+    if (ncols != 6 && ncols != 12) return fail(EDS_ERR_INVALID, "ncols must be 6 or 12");
+    if (which != 0 && which != 1) return fail(EDS_ERR_INVALID, "which: 0 residual/Jacobian, 1 reduction");
+    if (ncols == 6 && h->cfg.nc) return fail(EDS_ERR_INVALID, "the NC residual (cfg.nc) has 12-column rows only");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    for (int s = first; s < first + count; ++s) {
+        const Slot& sl = h->slots[s];
+        if (!sl.has_kf || !sl.has_frame) return fail(EDS_ERR_STATE, "keyframe or event frame not set");
+        fill_pose(h, s, sl.p, sl.q, sl.v);
+    }
+    int rc = run_pass(h, first, count, ncols, true, true, false);   // model + one warm pass (the planes the reduction reads)
+    if (rc) return rc;
+    const size_t evict_bytes = (size_t)1 << 30;
+    if ((rc = probe_buffers(h, evict_bytes))) return rc;
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    const EdsArrays A = arrays_for_pass(h, first, count);
+    const int N = max_points(h, first, count);
+    const int nchunk = (N + EDS_TPB - 1) / EDS_TPB;
+    const int nb_red = (ncols == 12) ? effective_blocks(h) : 1;
+    int cpb, nseg;
+    reduce_geometry(N, nb_red, ncols, &cpb, &nseg, h->knobs.reduce_ppl);
+    const float4* a = reinterpret_cast<const float4*>(h->d_probe);
+    float4* b = reinterpret_cast<float4*>(reinterpret_cast<char*>(h->d_probe) + evict_bytes);
+    float* sink = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_probe) + 2 * evict_bytes);
+    double total = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        hipLaunchKernelGGL(eds_probe_kernel, dim3(8192), dim3(256), 0, h->st, a, b, sink, evict_bytes / 16, 1);
+        EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
+        if (which == 0) eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
+        else eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st, h->knobs.reduce_ppl);
+        EDS_HIP_TRY(hipEventRecord(h->ev1, h->st));
+        EDS_HIP_TRY(hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        EDS_HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        total += ms;
+    }
+    EDS_HIP_TRY(hipGetLastError());
+    *mean_ms = (float)(total / reps);
+    return EDS_OK;
+}
+
 int eds_trk_loss_param_batch(eds_trk* h, int first, int count, int method, double* tau) {
     int rc = check_range(h, first, count);
     if (rc) return rc;

@@ -66,7 +66,18 @@ using namespace edsd;
 // by the very next workgroups to start: no co-residency assumption, no deadlock whatever the dispatch order.  Polls are bounded
 // (EDS_TEAM_TIMEOUT_TICKS of the 100 MHz clock); on a timeout the solve is reported failed-with-timeout and the host re-runs the
 // range with TEAM = 1.
-template <int SAMPLING, int PPT, int MAXT, int QUAD, int TEAM>
+//
+// GROUPS = G > 1 (round 5; TEAM > 1 only): SPECULATIVE CANDIDATE GROUPS.  One optimize per event slice (Tracker.cpp:104) leaves 250 of the
+// 256 CUs idle, and the damped solver rejects more than half of its candidates on this problem (accept pattern 0000010111) — each
+// rejection a full pass whose only product is one number.  The candidates that a run of rejections would walk through (lambda,
+// 4 lambda, 16 lambda, ...) are all known once a linearisation exists (eds_solver6_spec.hpp prepares EDS_NSPEC of them side by side), so
+// G teams of K CUs evaluate candidates k .. k + G - 1 AT THE SAME TIME: team g samples the frame at candidate k + g, all G x K
+// workgroups exchange their 28 sums in one round of granules, and every workgroup replays Solver6::on_eval over the G results in
+// order — reject, reject, ..., accept (everything behind the first accepted candidate is discarded).  Decisions, lambdas, trace
+// records and iteration counts are those of the sequential solver bit for bit (each candidate's sums are added in the same member
+// order as a team of K adds them); the pattern above takes 5 rounds instead of 11 passes.  The residuals at the accepted pose live in
+// the registers of the group that evaluated it: that group writes them at the end.
+template <int SAMPLING, int PPT, int MAXT, int QUAD, int TEAM, int GROUPS = 1>
 __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
@@ -75,20 +86,23 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int lane = tid & 63, wave = tid >> 6;
     __shared__ int s_ticket;
-    __shared__ unsigned s_xchg[TEAM > 1 ? TEAM : 1][EDS_TEAM_GRANULES];
+    static_assert(GROUPS == 1 || (TEAM > 1 && EDS_NSPEC % GROUPS == 0), "candidate groups: teams only, whole rounds of prepared candidates");
+    constexpr int VTEAM = TEAM * GROUPS;              // workgroups per alignment
+    __shared__ unsigned s_xchg[TEAM > 1 ? VTEAM : 1][EDS_TEAM_GRANULES];
     __shared__ int s_timeout;
-    int team_slot = blockIdx.x, member = 0;
+    int team_slot = blockIdx.x, member = 0, group = 0;
     if (TEAM > 1) {
         if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
         // a ticket outside this launch's stretch means host and device counters disagree (a launch that failed half-way): leave —
         // the host pre-marks every slot of a team launch as timed out, so the range is solved again and the counter reset
         if ((unsigned)s_ticket >= gridDim.x) return;
-        team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
+        team_slot = s_ticket / VTEAM; member = s_ticket % TEAM; group = (s_ticket % VTEAM) / TEAM;
     }
     const int slot = first + team_slot;
-    if (tid == 0 && member == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && member == 0 && group == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned pass_no = 0;                         // exchanges so far (TEAM > 1)
+    int res_owner = 0;                            // GROUPS > 1: the group whose registers hold the residuals of the accepted pose
     __shared__ edss::Solver6 sv;
     __shared__ double s_pose[EDS_POSE_STRIDE];
     __shared__ float s_posef[16];      // fp32 copies for the point phase: [0..11] R - I and t of the pose to evaluate (serial solver), [12..13] fx, fy
@@ -96,7 +110,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     __shared__ float s_costp[2][EDS_FUSED_MAX_WAVES];   // per-wavefront cost of the pass in flight, double-buffered by pass parity (quick accept test)
     __shared__ edss::Sums6 s_sums;
     __shared__ int s_state;            // 0: iterate, 1: this pass is the final one, 2: done
-    __shared__ int s_accept;           // the pass just consumed became the accepted pose
+    __shared__ int s_accept;           // the pass just consumed became the accepted pose (GROUPS > 1: 1 + the group whose candidate was
+                                       // accepted, 0: none, -1: the first pass — every group evaluated the start pose)
     __shared__ edsp::SpecState sp;     // damped solver with register-resident points: prepared candidates (eds_solver6_spec.hpp)
     const bool spec_mode = (PPT > 0) && damped == 1 && iters > 0;   // (iters == 0: one residual pass, no solve) damped == 2: the serial solver lane of round 1 (A/B runs: EDS_LM6_SPEC=0)
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
@@ -253,7 +268,8 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     for (;;) {
         EDS_STAMP(0);
         const int state = s_state;
-        const int kcur = (QUICK && spec_mode) ? k_r : sp.k;      // the prepared candidate this pass evaluates
+        // the prepared candidate this pass evaluates (candidate groups: group g takes candidate sp.k + g; the first pass has one candidate, the start pose)
+        const int kcur = (QUICK && spec_mode) ? k_r : (GROUPS > 1 ? sp.k + (sv.have_cur ? group : 0) : sp.k);
         PoseF ps;
         if (PAIRS) { }
         else if (spec_mode) load_pose_rt(sp.spec[kcur].rt.D, sp.spec[kcur].rt.t, s_pose, ps);
@@ -625,18 +641,47 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 // on different XCDs (consecutive workgroup ids), so a poll is a fabric round trip, and K of them in a row on one
                 // wavefront were most of the exchange.
                 const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
-                unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * (TEAM * EDS_TEAM_GRANULES);
+                unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * (VTEAM * EDS_TEAM_GRANULES);
+                const int me = group * TEAM + member;
                 if (wave == 0 && lane < EDS_RED_N6) {
                     double s = 0.0;
 #pragma unroll
                     for (int wv = 0; wv < EDS_FUSED_MAX_WAVES; ++wv) s += (double)s_red[wv][lane];
                     const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
-                    __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xffffffffull),
+                    __hip_atomic_store(mb + me * EDS_TEAM_GRANULES + 2 * lane, ((unsigned long long)tag << 32) | (bits & 0xffffffffull),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(mb + member * EDS_TEAM_GRANULES + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32),
+                    __hip_atomic_store(mb + me * EDS_TEAM_GRANULES + 2 * lane + 1, ((unsigned long long)tag << 32) | (bits >> 32),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                if constexpr (GROUPS > 1) {
+                    // G x K members: a wavefront asks for ALL its members' granules at once (one fabric round trip for the lot), then
+                    // asks again only for the late ones
+                    constexpr int NW = MAXT / 64, PER = (VTEAM + NW - 1) / NW;
+                    if (lane < 2 * EDS_RED_N6) {
+                        unsigned long long v[PER];
+#pragma unroll
+                        for (int i = 0; i < PER; ++i) {
+                            const int m = wave + i * NW;
+                            v[i] = m < VTEAM ? __hip_atomic_load(mb + m * EDS_TEAM_GRANULES + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+                        }
+                        for (;;) {
+                            bool late = false;
+#pragma unroll
+                            for (int i = 0; i < PER; ++i) late |= (unsigned)(v[i] >> 32) != tag;
+                            if (!late) break;
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                            for (int i = 0; i < PER; ++i)
+                                if ((unsigned)(v[i] >> 32) != tag)
+                                    v[i] = __hip_atomic_load(mb + (wave + i * NW) * EDS_TEAM_GRANULES + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int i = 0; i < PER; ++i)
+                            if (wave + i * NW < VTEAM) s_xchg[wave + i * NW][lane] = (unsigned)v[i];
+                    }
+                } else {
                 for (int m = wave; m < TEAM; m += nthr >> 6) {
                     if (lane < 2 * EDS_RED_N6) {
                         const unsigned long long* g = mb + m * EDS_TEAM_GRANULES + lane;
@@ -649,9 +694,91 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                         s_xchg[m][lane] = (unsigned)v;
                     }
                 }
+                }
                 ++pass_no;
                 __syncthreads();
             }
+            if constexpr (GROUPS > 1) {
+              if (wave == 0) {
+                // ---- candidate groups: Solver6::on_eval replayed over the G candidates of this round, in order --------------------------
+                EDS_STAMP(2);
+                EDS_STAMP2(3);
+                const int k = sp.k, max_iters = sv.max_iters;
+                int have_cur = sv.have_cur, iter = sv.iter, ntrace = sv.ntrace;
+                double lambda = sv.lambda;
+                double cur_cost = sp.cur[EDS_RED_N6 - 1];
+                int mode = edsp::MODE_SOLVE, nk = 0, acc = 0, last_ok = 1;
+                bool decided = false;
+#pragma unroll
+                for (int g = 0; g < GROUPS; ++g) {
+                    if (decided) break;
+                    double s = 0.0;
+                    if (lane < EDS_RED_N6) {
+#pragma unroll
+                        for (int m = 0; m < TEAM; ++m)
+                            s += __longlong_as_double((long long)(((unsigned long long)s_xchg[g * TEAM + m][2 * lane + 1] << 32) | s_xchg[g * TEAM + m][2 * lane]));
+                    }
+                    const long long sb = __double_as_longlong(s);
+                    const double cost = __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(sb >> 32), EDS_RED_N6 - 1) << 32) |
+                                                             (unsigned int)__builtin_amdgcn_readlane((int)(sb & 0xffffffffll), EDS_RED_N6 - 1));
+                    const bool bad = lane < EDS_RED_N6 && !(fabs(s) < 1e300);
+                    const bool fin = __ballot(bad) == 0ull;
+                    if (!have_cur) {                    // first round: every group evaluated the start pose; group 0's sums are the linearisation
+                        decided = true;
+                        if (!fin) { mode = edsp::MODE_DONE; if (lane == 0) { sv.failed = 1; sv.done = 1; } }
+                        else { have_cur = 1; acc = -1; if (lane < EDS_RED_N6) sp.cur[lane] = s; if (lane == 0) sv.initial_cost = cost; }
+                        break;
+                    }
+                    const int kk = k + g;
+                    if (!sp.spec[kk].ok) {              // damped matrix not positive definite: Solver6 gives up here (failed only at iteration 0)
+                        decided = true; mode = edsp::MODE_DONE;
+                        if (lane == 0) { sv.failed = (iter == 0); sv.final_cost = cur_cost; sv.done = 1; }
+                        break;
+                    }
+                    const int ok = fin && (cost < cur_cost);
+                    last_ok = ok;
+                    if (lane == 0 && ntrace < EDS_MAX_TRACE) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) sv.tr_xi[ntrace][i] = sp.spec[kk].xi[i];
+                        sv.tr_cost[ntrace] = cost; sv.tr_acc[ntrace] = ok;
+                    }
+                    if (ntrace < EDS_MAX_TRACE) ++ntrace;
+                    ++iter;
+                    if (ok) {
+                        acc = 1 + g;
+                        if (lane < EDS_RED_N6) sp.cur[lane] = s;
+                        lambda *= 0.5;
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) sv.p[i] = sp.spec[kk].p[i];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) sv.q[i] = sp.spec[kk].q[i];
+                        }
+                    } else {
+                        lambda = edsp::next_lambda_after_reject(lambda);
+                    }
+                    if (iter >= max_iters) {            // Solver6::finish with the residuals kept by the caller: done, no extra pass
+                        decided = true; mode = edsp::MODE_DONE;
+                        if (lane == 0) { sv.final_cost = ok ? cost : cur_cost; sv.done = 1; }
+                    } else if (ok) {
+                        decided = true;                 // fresh linearisation: new proposals (everything behind this candidate is discarded)
+                    }
+                }
+                if (!decided && k + GROUPS < EDS_NSPEC) { mode = edsp::MODE_USE; nk = k + GROUPS; }      // a whole round rejected: the next G prepared candidates
+                if (lane == 0) {
+                    sv.lambda = lambda; sv.have_cur = have_cur; sv.iter = iter; sv.ntrace = ntrace; sv.last_accepted = last_ok;
+                    sp.mode = mode; sp.k = nk;
+                    s_accept = acc;
+                    if (mode == edsp::MODE_DONE) s_state = 2;
+                }
+                if (mode == edsp::MODE_SOLVE) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < EDS_NSPEC) edsp::propose(sp.cur, lambda, lane, sv.p, sv.q, sp.spec[lane]);
+                }
+              }
+            } else
             if (wave == 0) {
                 double s = 0.0;
                 if (lane < EDS_RED_N6) {
@@ -733,10 +860,11 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 if (tid == 0) { sv.failed = 2; sv.done = 1; }
                 break;
             }
-            if (s_accept) {
+            if (GROUPS > 1 ? (s_accept < 0 || s_accept == 1 + group) : s_accept != 0) {
 #pragma unroll
                 for (int j = 0; j < NREG; ++j) racc[j] = rcand[j];
             }
+            if (GROUPS > 1 && s_accept != 0) res_owner = s_accept < 0 ? 0 : s_accept - 1;
             if (QUICK) { k_r = sp.k; iter_r = sv.iter; have_cur_r = sv.have_cur; cur_cost_r = sp.cur[EDS_RED_N6 - 1]; }
             if (sp.mode == edsp::MODE_DONE) break;
             if (!sp.spec[sp.k].ok) {                // damped matrix not positive definite: Solver6 gives up here (failed only at iteration 0)
@@ -795,24 +923,24 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll                          // all along: the damped solver needs no extra pass to produce them
         for (int j = 0; j < NREG; ++j) {
             const int i = tid + j * nthr;
-            if (i < N) A.r[base + i] = racc[j];
-            if (TEAM > 1 && A.rmap && i < N) A.rmap[base + i] = racc[j];      // the caller reads them next (Tracker.cpp:223-233)
+            if (i < N && group == res_owner) A.r[base + i] = racc[j];
+            if (TEAM > 1 && A.rmap && i < N && group == res_owner) A.rmap[base + i] = racc[j];      // the caller reads them next (Tracker.cpp:223-233)
         }
     }
 #ifdef EDS_FUSED_STAMPS
     // diagnostic build only: cycles of lane 0 in [point loop | reduction | solver] into the pad words
-    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
+    if (tid == 0 && member == 0 && group == 0) { out[slot].pad[0] = (double)stamp_acc[0]; out[slot].pad[1] = (double)stamp_acc[1]; out[slot].pad[2] = (double)stamp_acc[2]; }
 #if EDS_FUSED_STAMPS == 2
-    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
+    if (tid == 0 && member == 0 && group == 0) { out[slot].pad[0] = (double)stamp2_acc[0]; out[slot].pad[1] = (double)stamp2_acc[1]; out[slot].pad[2] = (double)stamp2_acc[2]; }
 #endif
 #if EDS_FUSED_STAMPS == 3
     __syncthreads();
-    if (tid == 0 && member == 0) { out[slot].pad[0] = (double)s_miss_total; out[slot].pad[1] = (double)s_pass_total; out[slot].pad[2] = (double)N; }
+    if (tid == 0 && member == 0 && group == 0) { out[slot].pad[0] = (double)s_miss_total; out[slot].pad[1] = (double)s_pass_total; out[slot].pad[2] = (double)N; }
 #endif
 #endif
 
     __syncthreads();                    // the solver state as its last writer left it
-    if (TEAM > 1 && member != 0) return;    // every member holds the same result; member 0 reports it
+    if (TEAM > 1 && (member != 0 || group != 0)) return;    // every member holds the same result; member 0 (of group 0) reports it
     if (tid == 0) {
         EdsFusedOut& O = out[slot];
         for (int i = 0; i < 3; ++i) O.p[i] = sv.p[i];
@@ -839,11 +967,22 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 // and the strategy is a per-TU compiler flag: eds_fused_bilinear.o (-DEDS_FUSED_BILINEAR_TU, register-pressure trackers only) holds
 // the SAMPLING = 1 instantiations behind eds_fused6_launch_bilinear(); eds_fused.o holds the rest and the host side.
 #if defined(EDS_FUSED_BILINEAR_TU) || defined(EDS_FUSED_ONE_TU)      // (ONE_TU: the diagnostic builds, one command line for every source)
-void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team) {
+void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team, int groups) {
     edss::Solver6* svp = reinterpret_cast<edss::Solver6*>(L.sv);
 #define EDS_BL(P, T, K)                                                                                                            \
     hipLaunchKernelGGL((eds_fused6_kernel<1, P, T, 0, K>), dim3(L.count * K - L.drop), dim3(L.threads), 0, L.st, *L.A, L.in, L.out, svp,      \
                        L.first, L.iters, L.damped, L.lambda0, L.tau, L.nb, L.mail, L.ticket, L.ticket_base, L.epoch)
+    if (groups > 1) {           // candidate groups (eds_launch_rule.hpp: EDS_FUSED6_BILINEAR_GROUP_INSTANCES)
+#define EDS_BLG_(S_, P_, T_, Q_, K_, G_)                                                                                            \
+        if (ppt == P_ && team == K_ && groups == G_) {                                                                              \
+            hipLaunchKernelGGL((eds_fused6_kernel<S_, P_, T_, Q_, K_, G_>), dim3(L.count * K_ * G_ - L.drop), dim3(L.threads), 0, L.st, *L.A, L.in, L.out, svp, \
+                               L.first, L.iters, L.damped, L.lambda0, L.tau, L.nb, L.mail, L.ticket, L.ticket_base, L.epoch);       \
+            return;                                                                                                                 \
+        }
+        EDS_FUSED6_BILINEAR_GROUP_INSTANCES(EDS_BLG_)
+#undef EDS_BLG_
+        return;
+    }
     if (team > 1) {
         if (ppt == 1) { EDS_BL(1, 512, 4); }
         else if (team == 2) { EDS_BL(2, 512, 2); }
@@ -963,6 +1102,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     eds_lm6_plan_finish(kn, rin, strips ? 1 : 0, pl);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     const int team = pl.kind == EDS_K6_TEAM ? pl.K : 1, damped = pl.damped, threads = pl.threads;
+    const int groups = pl.kind == EDS_K6_TEAM ? pl.G : 1;       // candidate groups: G x K workgroups per alignment
     // test hook for the time-out path: a team launch goes out one workgroup short, so its last team never completes, reports a time-out
     // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
     const int drop = kn.team_drop ? 1 : 0;
@@ -970,18 +1110,19 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
     A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     fb.pending_team = team; fb.pending_level = level;
-    if (pl.kind != EDS_K6_STREAM && !eds_fused6_instance_exists(pl.S, pl.P, pl.T, pl.Q, pl.K, pl.bilinear_tu))
+    if (pl.kind != EDS_K6_STREAM && !eds_fused6_instance_exists(pl.S, pl.P, pl.T, pl.Q, pl.K, pl.bilinear_tu, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
     // one launch of the chosen instantiation over `cnt` alignments from slot `f0` (teams: cnt * K - drop workgroups of 512 threads)
     auto launch = [&](int f0, int cnt, unsigned ticket_base) {
-        const int K = pl.K, wg = cnt * K - (K > 1 ? drop : 0), block = K > 1 ? 512 : threads;
-        std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d>", pl.S, pl.P, pl.note_T, pl.Q, K);
-        fb.last_workgroups = wg; fb.last_team = K; fb.last_layout = pl.Q >= 3 ? 2 : 1;
+        const int K = pl.K, wg = cnt * K * groups - (K > 1 ? drop : 0), block = K > 1 ? 512 : threads;
+        if (groups > 1) std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d, %d>", pl.S, pl.P, pl.note_T, pl.Q, K, groups);
+        else std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused6_kernel<%d, %d, %d, %d, %d>", pl.S, pl.P, pl.note_T, pl.Q, K);
+        fb.last_workgroups = wg; fb.last_team = K * groups; fb.last_layout = pl.Q >= 3 ? 2 : 1;
         if (pl.bilinear_tu) {
             const EdsFused6Launch L{&A, fb.d_in, fb.d_out, fb.d_sv, f0, cnt, block, iters, damped, h->cfg.lambda0, tau, nb,
                                     K > 1 ? fb.d_mail : nullptr, K > 1 ? fb.d_ticket : nullptr, K > 1 ? ticket_base : 0u, K > 1 ? fb.epoch : 0u,
                                     K > 1 ? drop : 0, h->st};
-            eds_fused6_launch_bilinear(L, pl.P, K);
+            eds_fused6_launch_bilinear(L, pl.P, K, groups);
             return;
         }
         unsigned long long* mail = K > 1 ? fb.d_mail : nullptr;
@@ -993,13 +1134,24 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
                                iters, damped, h->cfg.lambda0, tau, nb, mail, ticket, tb, ep);                                        \
             return;                                                                                                                   \
         }
+        if (groups > 1) {
+#define EDS_INST_LAUNCH6_(S_, P_, T_, Q_, K_, G_)                                                                                      \
+            if (pl.S == S_ && pl.P == P_ && pl.T == T_ && pl.Q == Q_ && K == K_ && groups == G_) {                                    \
+                hipLaunchKernelGGL((eds_fused6_kernel<S_, P_, T_, Q_, K_, G_>), dim3(wg), dim3(block), 0, h->st, A, fb.d_in, fb.d_out, svp, f0, \
+                                   iters, damped, h->cfg.lambda0, tau, nb, mail, ticket, tb, ep);                                    \
+                return;                                                                                                               \
+            }
+            EDS_FUSED6_GROUP_INSTANCES(EDS_INST_LAUNCH6_)
+#undef EDS_INST_LAUNCH6_
+            return;
+        }
         EDS_FUSED6_MAIN_INSTANCES(EDS_INST_LAUNCH_)
 #undef EDS_INST_LAUNCH_
     };
     if (pl.kind == EDS_K6_TEAM) {
         // one launch holds EDS_TEAM_MEMBERS workgroups (the mailboxes' capacity); a larger range goes out in several launches, in
         // stream order, each with its own launch number in the granule tags and its own stretch of tickets
-        const int per_launch = EDS_TEAM_MEMBERS / team;
+        const int per_launch = EDS_TEAM_MEMBERS / (team * groups);
         for (int c0 = 0; c0 < count; c0 += per_launch) {
             const int f0 = first + c0, cnt = std::min(per_launch, count - c0);
             if (++fb.epoch >= (1u << 24)) {              // tags are (epoch << 8 | pass): start over with clean mailboxes
@@ -1007,7 +1159,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
                 fb.epoch = 1;
             }
             const unsigned ticket_base = fb.ticket_base;
-            fb.ticket_base += (unsigned)(cnt * team);
+            fb.ticket_base += (unsigned)(cnt * team * groups);
             for (int s = f0; s < f0 + cnt; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
             launch(f0, cnt, ticket_base);
         }

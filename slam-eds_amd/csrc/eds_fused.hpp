@@ -110,7 +110,7 @@ struct EdsFused6Launch {
     int first, count, threads, iters, damped; double lambda0, tau; int nb;
     unsigned long long* mail; int* ticket; unsigned ticket_base, epoch; int drop; hipStream_t st;
 };
-void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team);
+void eds_fused6_launch_bilinear(const EdsFused6Launch& L, int ppt, int team, int groups = 1);
 void eds_stream6_launch(const EdsArrays& A, int sampling, int wide, const EdsFusedIn* d_in, EdsFusedOut* d_out, void* d_sv, int first,
                         int count, int iters, int damped, double lambda0, double huber_tau, int nb, hipStream_t st);
 

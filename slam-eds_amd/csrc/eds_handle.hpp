@@ -10,7 +10,7 @@
 #include "eds_launch_rule.hpp"
 
 static_assert(EDS_RULE_TEAM6_MAX == EDS_TEAM6_MAX && EDS_RULE_TEAM_SLOTS == EDS_TEAM_SLOTS && EDS_RULE_TEAM12_SLOTS == EDS_TEAM12_SLOTS &&
-              EDS_RULE_TEAM12_MEMBERS == EDS_TEAM12_MEMBERS, "eds_launch_rule.hpp repeats these constants of eds_fused.hpp");
+              EDS_RULE_TEAM12_MEMBERS == EDS_TEAM12_MEMBERS && EDS_RULE_TEAM_MEMBERS == EDS_TEAM_MEMBERS, "eds_launch_rule.hpp repeats these constants of eds_fused.hpp");
 
 // Host-side state of one alignment slot: what the reference keeps in Tracker members
 // px,qx,vx,info (Tracker.hpp:46-52) and in kf->residuals (KeyFrame.hpp:88).
@@ -75,6 +75,8 @@ struct eds_trk {
     bool gram_pending = false;          // h_G's refresh is still in flight on the stream (set_idepth does not wait for it)
     bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
     size_t h_f32_elems = 0;
+    void* d_probe = nullptr;            // scratch of the measurement helpers (eds_trk_hbm_probe, eds_trk_bench_kernel_cold): allocated at their first call
+    size_t probe_bytes = 0;
     std::vector<Slot> slots;
 
     EdsArrays arrays() const {

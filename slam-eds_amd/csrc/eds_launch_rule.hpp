@@ -19,7 +19,9 @@
 #define EDS_RULE_TEAM_SLOTS 128        // = EDS_TEAM_SLOTS
 #define EDS_RULE_TEAM12_SLOTS 64       // = EDS_TEAM12_SLOTS
 #define EDS_RULE_TEAM12_MEMBERS 512    // = EDS_TEAM12_MEMBERS
+#define EDS_RULE_TEAM_MEMBERS 4096     // = EDS_TEAM_MEMBERS
 #define EDS_RULE_CACHE_CAP 2048        // = EDS_CACHE_CAP (eds_fused.hip)
+#define EDS_RULE_CUS 256               // compute units of the part (MI355X): candidate groups are formed only while every workgroup of the launch gets a CU of its own
 
 struct EdsKnobs {
     int ref12_exec = -1;        // EDS_REF12_EXEC      device | host            -1: the rule (device wherever the kernel covers the problem)
@@ -44,6 +46,7 @@ struct EdsKnobs {
     int upload_bands = 0;       // EDS_UPLOAD=bands    one launch per band of a host frame (round 2's upload)
     int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
     int reduce_ppl = 4;         // EDS_REDUCE_PPL      4 | 8: points a lane of eds_reduce_kernel<6> folds (16-byte loads)
+    int lm6_groups = 0;         // EDS_LM6_GROUPS      1 | 2 | 4 | 8: candidate groups of a team launch (eds_fused.hip)   0: the rule
 };
 
 // returns 0, or -1 for a name that is not a knob.  value == nullptr or "" resets the knob to its default.
@@ -72,6 +75,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_UPLOAD")) k->upload_bands = is("bands") ? 1 : 0;
     else if (!strcmp(name, "EDS_FRAME_LAYOUT")) k->frame_rowmajor = is("rowmajor") ? 1 : 0;
     else if (!strcmp(name, "EDS_REDUCE_PPL")) k->reduce_ppl = iv == 8 ? 8 : 4;
+    else if (!strcmp(name, "EDS_LM6_GROUPS")) k->lm6_groups = unset ? 0 : iv;
     else return -1;
     return 0;
 }
@@ -80,7 +84,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL")
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS")
 
 // the process environment, read once per handle (eds_trk_create)
 static inline void eds_knobs_from_env(EdsKnobs* k) {
@@ -113,6 +117,7 @@ struct EdsLm6Plan {
     // finish: the launch
     int kind;               // EDS_K6_*
     int S, P, T, Q, K;      // template arguments of eds_fused6_kernel (kind != STREAM); T is MAXT, the block has `threads` threads
+    int G;                  // candidate groups (sixth template argument; 1 unless kind == TEAM): G x K workgroups per alignment
     int bilinear_tu;        // the instantiation lives in eds_fused_bilinear.o (eds_fused6_launch_bilinear)
     int wide_members;       // teams with members of 2 048 points
     int note_T;             // the T eds_trk_last_launch prints (the lane kernel of the bilinear sampler prints the block size)
@@ -200,8 +205,24 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
             else { p.S = 0; p.Q = hub ? 2 : 1; }
         }
         p.note_T = 512;
+        // Candidate groups (the latency regime proper: every workgroup of the launch on a CU of its own, the other CUs idle): G teams
+        // evaluate G prepared candidates at once.  Instantiated for the members of 512 points (one per lane), lane / quad gather on tiles.
+        p.G = 1;
+        if (p.P == 1 && p.K == 4 && !p.wide_members) {
+            // measured (tools/check_groups.py, MI355X): a launch that takes HALF the CUs is faster than one that takes all of them
+            // (8 alignments: 47.9 us with 4 groups on 128 CUs, 50.6 with 8 on 256), and two groups on all 256 still beat none
+            // (32 alignments: 52.5 against 64.1 us); beyond the CU count the workgroups queue and a round waits for the queue
+            int g = 1;
+            for (int c = 8; c >= 2; c >>= 1)
+                if (in.count * p.K * c <= EDS_RULE_CUS / 2) { g = c; break; }
+            if (g == 1 && in.count * p.K * 2 <= EDS_RULE_CUS) g = 2;
+            if (kn.lm6_groups == 1 || kn.lm6_groups == 2 || kn.lm6_groups == 4 || kn.lm6_groups == 8) g = kn.lm6_groups;
+            if (in.count * p.K * g > EDS_RULE_TEAM_MEMBERS) g = 1;                    // the mailboxes' capacity
+            p.G = g;
+        }
         return;
     }
+    p.G = 1;
     if (p.stream) { p.kind = EDS_K6_STREAM; p.S = bic ? 0 : 1; p.T = p.wide ? 512 : 256; p.P = p.wide ? 2048 : 1024; p.K = 1; p.note_T = p.T; return; }
     p.kind = EDS_K6_FUSED; p.K = 1;
     const int Tt = p.threads > 512 ? 1024 : 512;
@@ -244,11 +265,24 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
     X(1, 1, 512, 0, 1) X(1, 1, 1024, 0, 1) X(1, 2, 512, 0, 1) X(1, 2, 1024, 0, 1) X(1, 4, 512, 0, 1) X(1, 4, 1024, 0, 1)             \
     X(1, 0, 512, 0, 1) X(1, 0, 1024, 0, 1) X(1, 1, 512, 0, 4) X(1, 2, 512, 0, 2) X(1, 2, 512, 0, 4) X(1, 2, 512, 0, 8) X(1, 2, 512, 0, 16)
 
-static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu) {
+// ... and the candidate-group instantiations X(S, P, T, Q, K, G), G > 1 (teams of four members of 512 points)
+#define EDS_FUSED6_GROUP_INSTANCES(X)                                                                                                 \
+    X(0, 1, 512, 0, 4, 2) X(0, 1, 512, 0, 4, 4) X(0, 1, 512, 0, 4, 8) X(0, 1, 512, 1, 4, 2) X(0, 1, 512, 1, 4, 4) X(0, 1, 512, 1, 4, 8)
+#define EDS_FUSED6_BILINEAR_GROUP_INSTANCES(X)                                                                                        \
+    X(1, 1, 512, 0, 4, 2) X(1, 1, 512, 0, 4, 4) X(1, 1, 512, 0, 4, 8)
+
+static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G = 1) {
 #define EDS_INST_EQ_(s, p, t, q, k) if (S == s && P == p && T == t && Q == q && K == k) return true;
+#define EDS_INST_EQ6_(s, p, t, q, k, g) if (S == s && P == p && T == t && Q == q && K == k && G == g) return true;
+    if (G > 1) {
+        if (bilinear_tu) { EDS_FUSED6_BILINEAR_GROUP_INSTANCES(EDS_INST_EQ6_) }
+        else { EDS_FUSED6_GROUP_INSTANCES(EDS_INST_EQ6_) }
+        return false;
+    }
     if (bilinear_tu) { EDS_FUSED6_BILINEAR_INSTANCES(EDS_INST_EQ_) }
     else { EDS_FUSED6_MAIN_INSTANCES(EDS_INST_EQ_) }
 #undef EDS_INST_EQ_
+#undef EDS_INST_EQ6_
     return false;
 }
 

@@ -150,7 +150,7 @@ int hl_strips_layout(int Hp, int Wp, int phases, long long* stats) {
 // The launch rule of the product (eds_launch_rule.hpp).  knobs: "NAME=value;NAME=value" (the names of the environment variables).
 // in7 = {maxN, count, bicubic, iters, lm6, huber, H}; flags: bit 0 retry, bit 1 the time-out policy allows teams, bit 2 a cool-down is
 // running, bit 3 the strip copies are (or can be made) current.
-// out = {kind, S, P, T, Q, K, bilinear_tu, wide_members, threads, ppt, strips_eligible, wants_team, instance_exists, note_T}
+// out = {kind, S, P, T, Q, K, bilinear_tu, wide_members, threads, ppt, strips_eligible, wants_team, instance_exists, note_T, G}
 static int parse_knobs(const char* spec, EdsKnobs* kn) {
     std::string s(spec ? spec : "");
     size_t a = 0;
@@ -173,8 +173,8 @@ int hl_lm6_rule(const char* knobs, const int32_t* in7, int flags, int32_t* out) 
     eds_lm6_plan_team(kn, in, team_ok, (flags & 4) ? 1 : 0, p);
     const int strips = p.strips_eligible && (flags & 8);
     eds_lm6_plan_finish(kn, in, strips, p);
-    const int exists = p.kind == EDS_K6_STREAM ? 1 : (eds_fused6_instance_exists(p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu) ? 1 : 0);
-    const int32_t o[14] = {p.kind, p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, p.wide_members, p.threads, p.ppt, p.strips_eligible, p.wants_team, exists, p.note_T};
+    const int exists = p.kind == EDS_K6_STREAM ? 1 : (eds_fused6_instance_exists(p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, p.G) ? 1 : 0);
+    const int32_t o[15] = {p.kind, p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, p.wide_members, p.threads, p.ppt, p.strips_eligible, p.wants_team, exists, p.note_T, p.G};
     std::memcpy(out, o, sizeof(o));
     return 0;
 }

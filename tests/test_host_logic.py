@@ -210,11 +210,11 @@ TEAM_OK, COOLDOWN, STRIPS, RETRY = 2, 4, 8, 1
 
 
 def _lm6(hl, knobs="", maxN=2000, count=4096, bicubic=1, iters=10, lm6=1, huber=0, H=480, flags=TEAM_OK | STRIPS):
-    out = np.zeros(14, dtype=np.int32)
+    out = np.zeros(15, dtype=np.int32)
     rc = hl.hl_lm6_rule(knobs.encode(), np.array([maxN, count, bicubic, iters, lm6, huber, H], dtype=np.int32).ctypes.data_as(_ip), int(flags),
                         out.ctypes.data_as(_ip))
     assert rc == 0
-    keys = ("kind", "S", "P", "T", "Q", "K", "bilinear_tu", "wide_members", "threads", "ppt", "strips_eligible", "wants_team", "exists", "note_T")
+    keys = ("kind", "S", "P", "T", "Q", "K", "bilinear_tu", "wide_members", "threads", "ppt", "strips_eligible", "wants_team", "exists", "note_T", "G")
     return dict(zip(keys, (int(x) for x in out)))
 
 
@@ -284,6 +284,14 @@ def test_launch_rule_pose_only_table(hl):
     assert _lm6(hl, "EDS_LM6_TEAM=8", count=16)["K"] == 8 and _lm6(hl, "EDS_LM6_TEAM=2", maxN=4000, count=16)["K"] == 4
     assert _lm6(hl, "EDS_LM6_TEAM=4", count=16, flags=COOLDOWN | STRIPS)["K"] == 1
     assert _lm6(hl, "EDS_LM6_SPEC=0", count=16)["K"] == 1
+    # candidate groups (round 5): G teams of four evaluate G prepared candidates at once — as many groups as fit HALF the CUs
+    # (G x 4 x count <= 128), two while all workgroups of the launch still get a CU of their own; members of 512 points only; the
+    # knob overrides, 1 switches them off
+    assert [_lm6(hl, count=c)["G"] for c in (1, 4, 5, 8, 9, 16, 17, 32, 33, 64)] == [8, 8, 4, 4, 2, 2, 2, 2, 1, 1]
+    assert _lm6(hl, "EDS_LM6_GROUPS=1", count=1)["G"] == 1 and _lm6(hl, "EDS_LM6_GROUPS=2", count=1)["G"] == 2 and _lm6(hl, "EDS_LM6_GROUPS=3", count=1)["G"] == 8
+    assert _lm6(hl, count=1, bicubic=0)["G"] == 8 and _lm6(hl, count=32)["Q"] == 1 and _lm6(hl, count=32)["exists"]
+    assert _lm6(hl, maxN=8000, count=1, H=720)["G"] == 1 and _lm6(hl, "EDS_LM6_TEAM=2", count=4)["G"] == 1 and _lm6(hl, count=129)["G"] == 1
+    assert _lm6(hl, count=1, flags=RETRY | TEAM_OK | STRIPS)["G"] == 1 and _lm6(hl, count=4, flags=COOLDOWN | STRIPS)["G"] == 1
 
 
 def test_launch_rule_ref12_table(hl):
@@ -310,7 +318,8 @@ def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
     knobs = ["", "EDS_FUSED_LAYOUT=tiles", "EDS_FUSED_GATHER=lane", "EDS_FUSED_GATHER=quad", "EDS_LM6_TEAM=1", "EDS_LM6_TEAM=2", "EDS_LM6_TEAM=4",
              "EDS_LM6_TEAM=8", "EDS_LM6_TEAM=16", "EDS_TEAM_WIDE=1", "EDS_TEAM_WIDE=0", "EDS_LM6_KERNEL=resident", "EDS_LM6_KERNEL=wide",
              "EDS_LM6_KERNEL=paired", "EDS_FUSED_THREADS=256", "EDS_FUSED_THREADS=1024", "EDS_FUSED_PPT=2", "EDS_FUSED_PPT=3", "EDS_FUSED_PPT=0",
-             "EDS_LM6_SPEC=0", "EDS_FUSED_THREADS=1024;EDS_FUSED_PPT=2;EDS_LM6_KERNEL=resident"]
+             "EDS_LM6_SPEC=0", "EDS_FUSED_THREADS=1024;EDS_FUSED_PPT=2;EDS_LM6_KERNEL=resident", "EDS_LM6_GROUPS=1", "EDS_LM6_GROUPS=2",
+             "EDS_LM6_GROUPS=4", "EDS_LM6_GROUPS=8", "EDS_LM6_GROUPS=8;EDS_LM6_TEAM=4"]
     n = 0
     for kn in knobs:
         for _ in range(300):

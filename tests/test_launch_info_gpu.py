@@ -28,8 +28,14 @@ def test_last_launch_names_the_kernel_that_ran(gpu, capi, synth):
     # a handful of alignments: several CUs each, timed from the kernels' own stamps, no digest
     h.set_states(0, P[:8], Q[:8], V[:8]); h.optimize_batch(0, 0, 8)
     li = h.last_launch()
-    assert li["cus_per_alignment"] == 4 and li["workgroups"] == 32 and li["timing_source"] == 1 and li["span_us"] == 0.0
-    assert li["kernel"].startswith("eds_fused6_kernel<0, 1, 512,") and li["kernel"].endswith(", 4>")
+    # (round 5: teams of four in four candidate groups — 16 CUs per alignment, eds_launch_rule.hpp)
+    assert li["cus_per_alignment"] == 16 and li["workgroups"] == 128 and li["timing_source"] == 1 and li["span_us"] == 0.0
+    assert li["kernel"].startswith("eds_fused6_kernel<0, 1, 512,") and li["kernel"].endswith(", 4, 4>")
+    h.set_knob("EDS_LM6_GROUPS", "1")
+    h.set_states(0, P[:8], Q[:8], V[:8]); h.optimize_batch(0, 0, 8)
+    li = h.last_launch()
+    assert li["cus_per_alignment"] == 4 and li["workgroups"] == 32 and li["kernel"].endswith(", 4>") and not li["kernel"].endswith(", 4, 4>")
+    h.set_knob("EDS_LM6_GROUPS", None)
     # the reference problem, and the per-point Huber variant of the pose-only kernel
     h.set_config(capi.default_config(exec=capi.EXEC_DEVICE, max_num_iterations=6, solver=capi.SOLVER_REF12))
     h.set_states(0, P, Q, V); h.optimize_batch(0, 0, 200)
