@@ -12,12 +12,21 @@ solve, the SE(3) update and the accept test — with all inputs already resident
 per-alignment results are gathered across ranks (one small RCCL all-gather).  `value` is the
 whole-job number of tracker iterations per second (weak scaling: the per-GPU batch is fixed).
 
+Round 5: the timed steps solve every frame THE WAY A FRAME IS SOLVED THE FIRST TIME — the reference's call pattern is one optimize
+per event frame (Tracker.cpp:104), and for such a solve the library samples the 4x4 tiles the frame was written in (its rule:
+csrc/eds_strips.hip; the strip copies that make RE-solves of a frame faster cost more than one solve gains).  The bench lets the
+library pick that kernel by itself on the frames' real first solve (an untimed step), checks that the timed steps launch the same
+one, and pins it with the handle's EDS_FUSED_LAYOUT=tiles knob only because the SAME frames are solved again every step.  The rate
+on frames whose strip copies are resident (round 4's headline) is reported beside it as `value_resident_frames`.
+
 The same JSON line carries
-  roofline      the kernel of the timed region (persistent per-alignment solver).  `achieved` / `frac` use SURVEY §8d's
-                crediting (140 B per point-evaluation bicubic: 112 B residual/Jacobian + 28 B reduction, "a fused kernel is
-                credited the same bytes"); `achieved_must_move` / `frac_must_move` count only what a fused kernel has to move
-                (20 B of point constants + 64 B of taps = 84 B): it writes no J planes and reads none back.  Duration from
-                HIP events on the library's own stream; `traffic` = HBM bytes from the committed rocprofv3 PMC passes
+  roofline      the kernel of the timed region (persistent per-alignment solver).  `achieved` / `frac` are PHYSICAL: bytes through the
+                fabric per launch from the committed rocprofv3 PMC passes of this workload (profiles/traffic_r05.json), corrected as
+                MI355X_MICROARCH.md prescribes for gfx950 (2 x FETCH_SIZE + WRITE_SIZE: a 128-byte request is tallied at 64), divided by
+                the kernel's duration measured live (HIP events on the library's own stream) and by the 8 TB/s peak — never above 1.
+                `frac_credit_8d` keeps SURVEY 8d's crediting (140 B per point-evaluation bicubic: 112 B residual/Jacobian + 28 B
+                reduction, J bytes included although a fused kernel never moves them: not a bandwidth fraction); `frac_must_move`
+                counts what a fused kernel has to move (20 B of point constants + 64 B of taps = 84 B per point-evaluation)
   roofline_resjac  the stand-alone residual/Jacobian kernel (the streaming two-kernel path), 112 B per point-evaluation
   reference_problem  the same batch solved as the reference's own 12-parameter Ceres-LM problem (eds_fused12_kernel), with
                 its own roofline block (196 B credited / 92 B must-move per point-evaluation)
@@ -92,9 +101,10 @@ def parse():
 
 
 def pmc_traffic(kernel_prefix, a):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_*.json, produced by
-    tools/profile.sh + tools/summarise_profile.py in separate --pmc runs) — only when they were taken on
-    exactly this workload; otherwise None."""
+    """Bytes through the fabric per launch from the committed rocprofv3 PMC passes (profiles/traffic_*.json, produced by
+    tools/profile.sh + tools/summarise_profile.py in separate --pmc runs) — only when they were taken on exactly this workload;
+    otherwise None.  Corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE tallies a 128-byte request at 64 bytes, so
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024."""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
@@ -107,9 +117,39 @@ def pmc_traffic(kernel_prefix, a):
                 (a.batch, a.points, a.iters, a.solver, a.sampling, a.exec_) or c.get("frame") != [a.height, a.width]:
             continue
         for k, v in t.get("kernels", {}).items():
-            if k.startswith(kernel_prefix) and v.get("raw_hbm_bytes"):
-                best = {"bytes": v["raw_hbm_bytes"], "source": os.path.relpath(f, ROOT)}
+            if k.startswith(kernel_prefix) and v.get("fetch_kb") is not None and v.get("write_kb") is not None:
+                best = {"bytes": (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0, "raw_bytes": (v["fetch_kb"] + v["write_kb"]) * 1024.0,
+                        "read_requests": (v.get("l2") or {}).get("TCC_EA0_RDREQ_sum"), "profiled_avg_us": v.get("avg_us"),
+                        "source": os.path.relpath(f, ROOT)}
     return best
+
+
+def physical_roofline(kernel, k_ms, units, per_unit_credit, per_unit_must_move, a, extra=None):
+    """The roofline block of one kernel: PHYSICAL fraction from the committed counters (never above 1 by construction of what it
+    divides), SURVEY 8d's credit and the must-move figure beside it.  units = point-evaluations per launch."""
+    t = pmc_traffic(kernel, a)
+    cred = units * per_unit_credit / (k_ms * 1e-3) / 1e9
+    mm = units * per_unit_must_move / (k_ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
+         "achieved_credit_8d": cred, "frac_credit_8d": cred / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": units * per_unit_credit,
+         "achieved_must_move": mm, "frac_must_move": mm / HBM_PEAK_GBS, "must_move_bytes_per_launch": units * per_unit_must_move}
+    if t:
+        ach = t["bytes"] / (k_ms * 1e-3) / 1e9
+        r.update({"achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": t["bytes"], "traffic_source": t["source"],
+                  "traffic_read_requests": t["read_requests"], "traffic_profiled_kernel_us": t["profiled_avg_us"],
+                  "basis": "physical: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch from the committed PMC passes / the kernel time measured in this run"})
+    else:                       # no counters of this workload committed: the must-move bytes are the only honest numerator
+        r.update({"achieved": mm, "frac": mm / HBM_PEAK_GBS, "traffic": None,
+                  "basis": "must-move bytes (no rocprofv3 PMC passes of this exact workload under profiles/): a LOWER bound of the physical rate"})
+    if extra:
+        r.update(extra)
+    return r
+
+
+def _under_profiler():
+    """rocprofv3 preloads its tool library, which initialises the GPU before Python starts: such a process must not start children."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
 
 
 def _cpu_info():
@@ -332,8 +372,11 @@ def configs_block(capi, synth, a):
         return float(np.median(t)), r
 
     def roof(points_passes, k_ms):          # points_passes = sum over launches of alignments x points x passes
-        return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms,
-                "achieved": points_passes * per_pt / (k_ms * 1e-3) / 1e9, "frac": points_passes * per_pt / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # (no PMC passes are committed for these workloads: `frac` is the must-move figure — a lower bound of the physical rate, never above 1;
+        # SURVEY 8d's credit beside it)
+        return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": k_ms, "basis": "must-move bytes (no PMC passes of this workload)",
+                "achieved": points_passes * mm / (k_ms * 1e-3) / 1e9, "frac": points_passes * mm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "achieved_credit_8d": points_passes * per_pt / (k_ms * 1e-3) / 1e9, "frac_credit_8d": points_passes * per_pt / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "achieved_must_move": points_passes * mm / (k_ms * 1e-3) / 1e9, "frac_must_move": points_passes * mm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # ---- configs[2] ------------------------------------------------------------------------------------------------------------
@@ -347,28 +390,37 @@ def configs_block(capi, synth, a):
     r0 = h.eval(0, als[0].p0, als[0].q0, als[0].v0, ncols=6, want_jacobian=False)["r"]
     tau = float(1.345 * 1.4826 * np.median(np.abs(r0 - np.median(r0))))            # 1.345 MAD of the start residuals of alignment 0
     h.set_config(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0, huber_tau=tau))
-    h.prepare_frames(0, B2)                         # inputs resident, strip copies included (as for the headline)
     P0 = np.stack([als[b % D2].p0 for b in range(B2)]); Q0 = np.stack([als[b % D2].q0 for b in range(B2)]); V0 = np.stack([als[b % D2].v0 for b in range(B2)])
 
     def step2():
         h.set_states(0, P0, Q0, V0); h.optimize_batch(0, 0, B2, sync=True)
+    h.set_knob("EDS_FUSED_LAYOUT", "tiles")         # as for the headline: every solve as a frame's first solve (the library's rule for a new frame)
     wall, _ = timed(step2)
     tab = h.results(0, B2); launch = h.last_launch(); k_ms = h.info(0)["device_time_us"] * 1e-3
+    h.set_knob("EDS_FUSED_LAYOUT", None)
+    h.prepare_frames(0, B2)                         # ... and on frames whose strip copies exist (re-solved frames)
+    wall_r, _ = timed(step2)
+    launch_r = h.last_launch(); k_ms_r = h.info(0)["device_time_us"] * 1e-3
     its = float(np.mean(tab[:, 14])); passes = a.iters + 1
     worst, mism = 0.0, 0
     for d in range(D2):
         ref = po.Oracle(rounded(als[d])).pose6_lm(als[d].p0, als[d].q0, als[d].v0, iters=a.iters, lambda0=a.lambda0, huber_tau=tau)
         worst = max(worst, po.se3_distance(tab[d, 0:3], tab[d, 3:7], ref["p"], ref["q"])); mism += int(tab[d, 14] != ref["iterations"])
-    out["config2"] = {"workload": f"{B2} alignments x {N2} points on {W2}x{H2}, {a.iters} LM6 iterations, per-point Huber tau = 1.345 MAD = {tau:.4g}",
+    out["config2"] = {"workload": f"{B2} alignments x {N2} points on {W2}x{H2}, {a.iters} LM6 iterations, per-point Huber tau = 1.345 MAD = {tau:.4g}; frames new for the solve",
                       "iterations_per_s": B2 * its / wall, "ms_per_step": 1e3 * wall, "kernel": launch["kernel"], "cus_per_alignment": launch["cus_per_alignment"],
                       "roofline": roof(B2 * N2 * passes, k_ms), "success_fraction": float(np.mean(tab[:, 15])),
+                      "resident_frames": {"iterations_per_s": B2 * its / wall_r, "ms_per_step": 1e3 * wall_r, "kernel": launch_r["kernel"], "roofline": roof(B2 * N2 * passes, k_ms_r)},
                       "parity": {"rows_checked": D2, "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
     h.close()
 
     # ---- configs[3] ------------------------------------------------------------------------------------------------------------
     counts, B3, D3 = [16000, 8000, 4000, 2000], 64, 8
     als = list(pool.map(lambda i: synth.make_alignment(3234 + i, H=480, W=640, N=16000, rot_deg=0.6, trans_norm=0.012, blur_ksize=15, blur_sigma=4.0), range(D3)))
+    saved_layout = os.environ.get("EDS_FUSED_LAYOUT")
+    os.environ["EDS_FUSED_LAYOUT"] = "tiles"        # the level handles read their knobs at create: every solve as a frame's first solve (as for the headline)
     pyr = capi.Pyramid(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0), counts, 480, 640, batch=B3)
+    if saved_layout is None: os.environ.pop("EDS_FUSED_LAYOUT", None)
+    else: os.environ["EDS_FUSED_LAYOUT"] = saved_layout
     for b in range(B3):
         x = als[b % D3]
         for l, n in enumerate(counts):
@@ -384,7 +436,7 @@ def configs_block(capi, synth, a):
         worst = max(worst, po.se3_distance(P[d], Q[d], rp, rq))
         mism += sum(int(infos[l][d]["num_iterations"] != per_level[l]["iterations"]) for l in range(len(counts)))
     out["config3"] = {"workload": f"{B3} coarse-to-fine pyramids, levels 80x60 .. 640x480 with {counts[::-1]} points, {a.iters} LM6 iterations per level, "
-                                  f"one launch per level for all pyramids",
+                                  f"one launch per level for all pyramids; frames new for the solve",
                       "iterations_per_s": B3 * sum(its_l) / wall, "pyramids_per_s": B3 / wall, "ms_per_step": 1e3 * wall,
                       "iterations_per_level_finest_first": its_l, "kernel": "eds_fused6_kernel, teams of 1 024 or 2 048 points per CU above 2 048 points (one launch per level)",
                       "roofline": roof(sum(B3 * n * (a.iters + 1) for n in counts), k_ms),
@@ -546,6 +598,9 @@ def main():
     # spend their time spinning: 158 s instead of seconds on the 256-thread host)
     saved_env = {k: os.environ.get(k) for k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")}
     os.environ.update({k: "1" for k in saved_env})
+    if a.gen_workers != 0 and _under_profiler():
+        sys.stderr.write("[bench] profiler detected (rocprofiler in LD_PRELOAD / ROCP* in the environment): inputs are generated on threads of this process (--gen-workers 0)\n")
+        a.gen_workers = 0
     if a.gen_workers == 0:
         from concurrent.futures import ThreadPoolExecutor
         gen_pool = ThreadPoolExecutor(min(32, os.cpu_count() or 1))
@@ -600,12 +655,10 @@ def main():
         als.append(x); frames32.append(f32)
     gen_pool.shutdown()
     t_gen = time.perf_counter() - t_gen
-    # the contract's timed region starts with the inputs resident: the frames' strip copies (csrc/eds_layout.hpp) are part of that.  Left
-    # to itself the library makes them when a frame is solved a SECOND time (they cost more than one solve gains: eds_strips.hip), which
-    # the warm-up steps would trigger as well; made explicitly here so that no --warmup value moves them into the timed steps.  Their
-    # cost is reported (frame_layout_prep) and so is the rate of solves on frames that are new every time (new_frame_per_solve).
+    # The contract's timed region starts with the inputs resident: keyframes and frames are in HBM, as any frame writer of the library
+    # leaves them (4x4 tiles).  What the timed steps launch is what the library launches for a frame it has not solved before — see
+    # the module docstring; the strip copies are NOT made (the resident-frames leg below makes them, outside the timed region).
     gc.collect(); gc.disable()                       # (see the note at the warm-up loop below)
-    h.prepare_frames(0, B)
     p0 = np.stack([als[b % distinct].p0 for b in range(B)])
     q0 = np.stack([als[b % distinct].q0 for b in range(B)])
     v0 = np.stack([als[b % distinct].v0 for b in range(B)])
@@ -639,6 +692,12 @@ def main():
     # happen to trip (seen as ONE 74.7 ms step in 2 of 5 runs of the strong-scaling block below).  Collect now — BEFORE the warm-up, so that
     # no idle gap separates warm-up and timed steps — and keep the collector off until the clock stops.  (The collection itself sits in
     # front of prepare_frames above, so that the GPU is busy from there to the last timed step.)
+    # the frames' REAL first solve (untimed, not one of the --warmup steps): the library picks the kernel by its own rule ...
+    table = step()
+    first_solve = h.last_launch() if a.exec_ == "device" else None
+    # ... and the handle keeps to that layout from here on (the same frames are solved again every step; left alone the library would
+    # make their strip copies at the second solve — the re-solve regime, reported as value_resident_frames)
+    h.set_knob("EDS_FUSED_LAYOUT", "tiles")
     for _ in range(a.warmup):
         table = step()
         if world > 1 or forced:
@@ -696,61 +755,40 @@ def main():
             in_regs = int(launch["kernel"].split("<")[1].split(",")[1]) > 0
         passes = a.iters + (1 if (a.solver == "lm6" and in_regs) else (2 if a.solver == "lm6" else 1))
         per_pt = BYTES_RESJAC[a.sampling] + BYTES_REDUCE
+        mm = BYTES_MUST_MOVE[a.sampling]
         roof = None
         if a.exec_ == "device":
             k_ms = float(np.mean(dev_us)) * 1e-3
-            ach = B * N * passes * per_pt / (k_ms * 1e-3) / 1e9
-            mm = BYTES_MUST_MOVE[a.sampling]
-            ach_mm = B * N * passes * mm / (k_ms * 1e-3) / 1e9
-            roof = {"kernel": launch["kernel"], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": k_ms,
-                    "algorithmic_bytes_per_launch": B * N * passes * per_pt,
-                    "achieved_must_move": ach_mm, "frac_must_move": ach_mm / HBM_PEAK_GBS, "must_move_bytes_per_launch": B * N * passes * mm,
-                    "frame_layout": {0: "row-major", 1: "4x4 tiles", 2: "strips"}.get(launch["layout"], "?"),
-                    "note": f"achieved/frac: SURVEY 8d credit, {per_pt} B per point-evaluation x {B}x{N} points x {passes} passes per launch "
-                            f"(a fused kernel is credited the J bytes it never moves, so this credit can exceed 1.0 and is NOT the fraction of the "
-                            f"HBM rate in use); *_must_move: {mm} B per point-evaluation (point constants + taps only) - the figure to read as a "
-                            f"fraction of the 8 TB/s peak"}
-            t = pmc_traffic(launch["kernel"], a)
-            if t:
-                roof["traffic"], roof["traffic_source"] = t["bytes"], t["source"]
-                roof["traffic_note"] = ("raw (FETCH_SIZE + WRITE_SIZE) x 1024 of the committed rocprofv3 PMC passes; FETCH_SIZE tallies a fabric request "
-                                        "at 64 B and this kernel's requests are 128-byte line fills (one per gathered patch): bytes through the fabric "
-                                        "~ 2 x FETCH_SIZE + WRITE_SIZE (profiles/r03_summary.md)")
+            roof = physical_roofline(launch["kernel"], k_ms, B * N * passes, per_pt, mm, a, extra={
+                "frame_layout": {0: "row-major", 1: "4x4 tiles", 2: "strips"}.get(launch["layout"], "?"),
+                "first_solve_kernel": first_solve["kernel"], "timed_kernel_is_first_solve_kernel": bool(first_solve["kernel"] == launch["kernel"]),
+                "note": f"achieved / frac: physical bytes through the fabric per launch / kernel time / 8 TB/s; *_credit_8d: SURVEY 8d credit, {per_pt} B per "
+                        f"point-evaluation x {B}x{N} points x {passes} passes per launch (counts J bytes a fused kernel never moves: NOT a bandwidth fraction); "
+                        f"*_must_move: {mm} B per point-evaluation (point constants + taps only)"})
             launch_digest = {k: launch[k] for k in ("workgroups", "span_us", "mean_workgroup_us", "covered", "tail_idle_us")}
-        rj_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
+        # north_star's two streaming kernels, each on its own and COLD (1 GiB streamed through the caches in front of every repetition:
+        # eds_trk_bench_kernel_cold) — back to back the reduction reads planes the previous kernel just left in the Infinity Cache
+        rj_ms = h.bench_kernel_cold(0, B, ncols=6, which=0, reps=10)
+        red_ms = h.bench_kernel_cold(0, B, ncols=6, which=1, reps=10)
+        rj_warm_ms = h.bench_eval(0, B, ncols=6, with_reduction=False, reps=20)
         both_ms = h.bench_eval(0, B, ncols=6, with_reduction=True, reps=20)
-        ach_rj = B * N * BYTES_RESJAC[a.sampling] / (rj_ms * 1e-3) / 1e9
-        roof_rj = {"kernel": "eds_resjac_kernel", "bound": "hbm", "achieved": ach_rj, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": ach_rj / HBM_PEAK_GBS, "traffic": None, "kernel_ms": rj_ms,
-                   "point_evals_per_s": B * N / (rj_ms * 1e-3),
-                   "resjac_plus_reduce_ms": both_ms}
-        t = pmc_traffic("eds_resjac_kernel" + ("<0" if a.sampling == "bicubic" else "<1"), a)
-        if t:
-            roof_rj["traffic"], roof_rj["traffic_source"] = t["bytes"], t["source"]
-        # the wavefront-reduction kernel on its own (north_star's second kernel; SURVEY 8d: "the residual/Jacobian kernel and the reduction
-        # kernel separately"): its time is what the pair costs beyond the first kernel, under the same HIP events
-        red_ms = max(both_ms - rj_ms, 1e-6)
-        ach_red = B * N * BYTES_REDUCE / (red_ms * 1e-3) / 1e9
-        roof_red = {"kernel": "eds_reduce_kernel<6, 4>", "bound": "hbm", "achieved": ach_red, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_red / HBM_PEAK_GBS,
-                    "traffic": None, "kernel_ms": red_ms, "note": f"{BYTES_REDUCE} B per point read once (r + six Jacobian planes, 16-byte loads, four points per lane); "
-                    "time = (resjac + reduce) - resjac under HIP events, launch gap included"}
-        t = pmc_traffic("eds_reduce_kernel", a)
-        if t:
-            roof_red["traffic"], roof_red["traffic_source"] = t["bytes"], t["source"]
-        # what this box's HBM really streams ("confirm on the box ... and report the measured peak beside the nominal"): a plain
-        # device-to-device copy of 1 GiB, read + write counted
+        roof_rj = physical_roofline("eds_resjac_kernel" + ("<0" if a.sampling == "bicubic" else "<1"), rj_ms, B * N, BYTES_RESJAC[a.sampling],
+                                    BYTES_RESJAC[a.sampling], a, extra={"point_evals_per_s": B * N / (rj_ms * 1e-3), "kernel_ms_back_to_back": rj_warm_ms,
+                                                                         "resjac_plus_reduce_ms_back_to_back": both_ms,
+                                                                         "note": f"stand-alone residual/Jacobian pass, cold; credit = must-move = {BYTES_RESJAC[a.sampling]} B per point "
+                                                                                 "(it does write r and J)"})
+        roof_rj["kernel"] = "eds_resjac_kernel"
+        roof_red = physical_roofline("eds_reduce_kernel", red_ms, B * N, BYTES_REDUCE, BYTES_REDUCE, a, extra={
+            "kernel_ms_behind_resjac": max(both_ms - rj_warm_ms, 1e-6),
+            "note": f"{BYTES_REDUCE} B per point read once (r + six Jacobian planes, 16-byte loads, four points per lane), COLD: the planes are evicted in front "
+                    "of every repetition; kernel_ms_behind_resjac = (resjac + reduce) - resjac back to back, where the Infinity Cache still holds what the "
+                    "first kernel wrote"})
+        roof_red["kernel"] = "eds_reduce_kernel<6, 4>"
+        # what this box's HBM really streams ("confirm on the box ... and report the measured peak beside the nominal"): the
+        # library's own plain stream kernel over 1 GiB (16 bytes per lane, grid-stride; csrc/eds_capi_solve.hip: eds_probe_kernel)
         try:
-            x_ = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); y_ = torch.empty_like(x_)
-            y_.copy_(x_); torch.cuda.synchronize()
-            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0_.record()
-            for _ in range(10):
-                y_.copy_(x_)
-            e1_.record(); torch.cuda.synchronize()
-            hbm_probe = {"copy_GBps": 10 * 2 * x_.numel() * 4 / (e0_.elapsed_time(e1_) * 1e-3) / 1e9, "bytes_per_copy": int(x_.numel() * 4),
-                         "note": "device-to-device copy of 1 GiB (read + write counted), 10 repetitions under events; nominal peak 8 000 GB/s"}
-            del x_, y_
+            hbm_probe = dict(h.hbm_probe(1 << 30, 10), note="library's own stream kernel over 1 GiB, 10 repetitions under HIP events on its stream: read-only pass, "
+                                                            "and copy with read + write counted; nominal peak 8 000 GB/s, the guide's achievable ~6 300")
         except Exception as ex_:                     # never fail the bench over the probe
             hbm_probe = {"error": str(ex_)}
         if roof is None:
@@ -770,46 +808,33 @@ def main():
             "median_translation_error": pose_err,
             "roofline": roof, "roofline_resjac": roof_rj, "roofline_reduce": roof_red, "hbm_probe": hbm_probe,
         }
-        if a.exec_ == "device" and a.sampling == "bicubic":
-            # what the frame layout of the timed kernel costs to make: the strip copies of all B frames converted again (HIP events)
-            prep_ms = h.prepare_frames(0, B, force=True)
-            out["frame_layout_prep"] = {"ms_for_batch": prep_ms, "us_per_frame": 1e3 * prep_ms / B,
-                                        "note": "outside the timed region (inputs resident): one conversion launch per new frame set, tiles -> strip copies "
-                                                "(csrc/eds_layout.hpp); it is paid once per event frame, not per solve"}
-            if world == 1 and a.solver == "lm6":
-                # a frame that is solved ONCE (a live tracker's event frame): the library samples the tiles it was written in — the
-                # kernel a first solve launches (the handle's EDS_FUSED_LAYOUT knob forces it here)
-                h.set_knob("EDS_FUSED_LAYOUT", "tiles")
-                try:
-                    n_ms, n_dev = [], []
-                    for k in range(4):
-                        h.set_states(0, p0, q0, v0)
-                        t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); n_ms.append(1e3 * (time.perf_counter() - t1))
-                        n_dev.append(h.info(0)["device_time_us"] * 1e-3)
-                    nt = h.results(0, B); nk = h.last_launch()["kernel"]
-                finally:
-                    h.set_knob("EDS_FUSED_LAYOUT", None)
-                its_n = float(np.mean(nt[:, 14]))
-                out["new_frame_per_solve"] = {
-                    "iterations_per_s": B * its_n / (float(np.median(n_ms[1:])) * 1e-3), "kernel_ms": float(np.median(n_dev[1:])), "kernel": nk,
-                    "roofline_frac": B * N * passes * per_pt / (float(np.median(n_dev[1:])) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "with_strip_copies_made_for_every_frame_iterations_per_s": B * its_n / ((float(np.median(dev_us)) * 1e-3 + prep_ms) * 1e-3),
-                    "max_abs_pose_difference_to_the_strip_kernel": float(np.abs(nt[:, :7] - table[:B, :7]).max()) if table.shape[0] >= B else None,
-                    "note": "NOT the headline (whose inputs are resident, strip copies included): every solve on a frame the GPU has not solved before. "
-                            "The library's own rule (eds_strips.hip) uses the 4x4 tiles for such a solve — the copies pay from the ~12th solve of a frame — "
-                            "so this is the rate a stream of new event frames gets; the second figure is what making the copies for every frame would give"}
-                # ... promoted next to `value` (Next #1): the reference's own call pattern is ONE optimize per event frame
-                # (Tracker.cpp:104), so this — not the resident-input headline — is the rate a stream of new event frames gets
-                nf_ms = float(np.median(n_dev[1:]))
-                nf_ach = B * N * passes * per_pt / (nf_ms * 1e-3) / 1e9
-                nf_mm = B * N * passes * BYTES_MUST_MOVE[a.sampling] / (nf_ms * 1e-3) / 1e9
-                out["value_new_frame_per_solve"] = out["new_frame_per_solve"]["iterations_per_s"]
-                out["roofline_new_frame_per_solve"] = {"kernel": nk, "bound": "hbm", "achieved": nf_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nf_ach / HBM_PEAK_GBS,
-                                                       "achieved_must_move": nf_mm, "frac_must_move": nf_mm / HBM_PEAK_GBS, "traffic": None, "kernel_ms": nf_ms,
-                                                       "frame_layout": "4x4 tiles", "algorithmic_bytes_per_launch": B * N * passes * per_pt}
-                t_nf = pmc_traffic(nk, a)
-                if t_nf:
-                    out["roofline_new_frame_per_solve"]["traffic"], out["roofline_new_frame_per_solve"]["traffic_source"] = t_nf["bytes"], t_nf["source"]
+        h.set_knob("EDS_FUSED_LAYOUT", None)             # the library's own layout rule again from here on
+        out["config"]["workload"] += ("; every timed solve samples its frame as a frame's FIRST solve does (4x4 tiles: the library's rule for a frame it has not "
+                                      "solved before; Tracker.cpp:104 is one optimize per frame)")
+        out["config"]["frame_regime"] = "new frame per solve (first-solve kernel)"
+        if a.exec_ == "device":
+            # RE-solved frames (round 4's headline regime): the strip copies of the frames are made (outside any timed region: their
+            # cost is reported) and the same batch is solved from them
+            h.prepare_frames(0, B)                          # (allocates the copies at its first call: not part of the conversion's cost)
+            prep_ms = h.prepare_frames(0, B, force=True)     # the conversion of all B frames again, under HIP events
+            r_ms, r_dev = [], []
+            for k in range(6):
+                h.set_states(0, p0, q0, v0)
+                t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); r_ms.append(1e3 * (time.perf_counter() - t1))
+                r_dev.append(h.info(0)["device_time_us"] * 1e-3)
+            rtab = h.results(0, B); rl = h.last_launch()
+            its_r = float(np.mean(rtab[:, 14])); rk_ms_ = float(np.median(r_dev[1:])); rw_ms = float(np.median(r_ms[1:]))
+            out["value_resident_frames"] = B * its_r / (rw_ms * 1e-3)
+            out["resident_frames"] = {
+                "iterations_per_s": B * its_r / (rw_ms * 1e-3), "ms_per_step": rw_ms, "kernel": rl["kernel"],
+                "roofline": physical_roofline(rl["kernel"], rk_ms_, B * N * passes, per_pt, mm, a,
+                                              extra={"frame_layout": {0: "row-major", 1: "4x4 tiles", 2: "strips"}.get(rl["layout"], "?")}),
+                "max_abs_pose_difference_to_the_timed_kernel": float(np.abs(rtab[:, :7] - table[:B, :7]).max()) if table.shape[0] >= B else None,
+                "frame_layout_prep": {"ms_for_batch": prep_ms, "us_per_frame": 1e3 * prep_ms / B},
+                "with_strip_copies_made_for_every_frame_iterations_per_s": B * its_r / ((rk_ms_ + prep_ms) * 1e-3),
+                "note": "NOT `value`: the same batch on frames that were solved before — the library has made their strip copies (one 128-byte line per "
+                        "bicubic patch; csrc/eds_layout.hpp) by one conversion launch per frame set, which costs more than one solve gains and pays from "
+                        "about the 12th solve of a frame: several keyframes / hypotheses against one frame, not the reference's call pattern"}
         if world == 1 and a.exec_ == "device" and a.solver == "lm6" and not a.no_configs:
             # The boundary takes HOST buffers (the reference hands `optimize` a std::vector<double>): what a batch costs when its frames
             # cross PCIe inside the timed region — never `value` (the contract's inputs are resident).  256 alignments, frames new for
@@ -833,7 +858,7 @@ def main():
             hb["note"] = ("NOT `value`: every frame is handed over as a host buffer inside the timed region (one eds_trk_set_event_frame per alignment, then one "
                           "launch): the upload, not the solve, is what this measures")
             out["host_buffers_inclusive"] = hb
-            h.prepare_frames(0, B)                        # (the legs below solve resident frames again)
+            h.prepare_frames(0, B)                        # (the legs below solve resident frames)
         if strong is not None:
             out["strong_scaling_config4"] = strong
         out["input_generation_s"] = t_gen
@@ -862,57 +887,32 @@ def main():
                                         "success_fraction": float(np.mean(bt[:, 15])), "kernel": h.last_launch()["kernel"]}
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device" and N <= 2048 and not a.no_ref12:
-            # the reference's own problem on the same batch (12 local parameters, Ceres-LM rules; one residual block, no
-            # loss): informational, outside the timed region
+            # the reference's own problem on the same batch (12 local parameters, Ceres-LM rules; one residual block, no loss):
+            # informational, outside the timed region.  Main figures: frames new for the solve (what a first solve launches), as for
+            # `value`; `resident_frames`: the same on frames whose strip copies exist.
             h.set_config(capi.default_config(device=0, sampling=cfg.sampling, solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE,
                                              max_num_iterations=a.iters, num_blocks=1))
-            r_ms, r_dev = [], []
-            for k in range(4):
-                h.set_states(0, p0, q0, v0)
-                t1 = time.perf_counter()
-                h.optimize_batch(0, 0, B, sync=True)
-                r_ms.append(1e3 * (time.perf_counter() - t1))
-                r_dev.append(h.info(0)["device_time_us"] * 1e-3)
-            rt = h.results(0, B)
-            r_it = float(np.mean(rt[:, 14]))
-            rk_ms = float(np.median(r_dev[1:]))
-            r_evals = r_it + 1.0                     # evaluations per solve: the initial one + one per LM iteration (residuals kept as it goes)
             r_cred, r_mm = BYTES_REF12["credited"][a.sampling], BYTES_REF12["must_move"][a.sampling]
-            out["reference_problem"] = {"solver": "ref12", "lm_iterations_per_s": B * r_it / (float(np.median(r_ms[1:])) * 1e-3),
-                                        "ms_per_step": float(np.median(r_ms[1:])), "kernel": "eds_fused12_kernel",
-                                        "kernel_ms": rk_ms, "iterations_per_alignment": r_it,
-                                        "success_fraction": float(np.mean(rt[:, 15])),
-                                        "roofline": {"kernel": "eds_fused12_kernel", "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                     "achieved": B * N * r_evals * r_cred / (rk_ms * 1e-3) / 1e9,
-                                                     "frac": B * N * r_evals * r_cred / (rk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     "achieved_must_move": B * N * r_evals * r_mm / (rk_ms * 1e-3) / 1e9,
-                                                     "frac_must_move": B * N * r_evals * r_mm / (rk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                     "traffic": None, "kernel_ms": rk_ms,
-                                                     "note": f"{r_cred} B credited / {r_mm} B must-move per point-evaluation x {B}x{N} points x "
-                                                             f"{r_evals:.2f} evaluations per solve"}}
-            k12 = h.last_launch()["kernel"]
-            out["reference_problem"]["kernel"] = out["reference_problem"]["roofline"]["kernel"] = k12
-            # ... and on frames that are new for every solve (the tiles: what a first solve launches, as for new_frame_per_solve)
+
+            def ref12_leg():
+                w_ms, d_ms = [], []
+                for k in range(4):
+                    h.set_states(0, p0, q0, v0)
+                    t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); w_ms.append(1e3 * (time.perf_counter() - t1))
+                    d_ms.append(h.info(0)["device_time_us"] * 1e-3)
+                tab_ = h.results(0, B); it_ = float(np.mean(tab_[:, 14])); kms = float(np.median(d_ms[1:])); kern = h.last_launch()["kernel"]
+                ev_ = it_ + 1.0              # evaluations per solve: the initial one + one per LM iteration (residuals kept as it goes)
+                return {"lm_iterations_per_s": B * it_ / (float(np.median(w_ms[1:])) * 1e-3), "ms_per_step": float(np.median(w_ms[1:])), "kernel": kern,
+                        "kernel_ms": kms, "iterations_per_alignment": it_, "success_fraction": float(np.mean(tab_[:, 15])),
+                        "roofline": physical_roofline(kern, kms, B * N * ev_, r_cred, r_mm, a, extra={
+                            "note": f"{r_cred} B credited / {r_mm} B must-move per point-evaluation x {B}x{N} points x {ev_:.2f} evaluations per solve"})}
+
             h.set_knob("EDS_FUSED_LAYOUT", "tiles")
             try:
-                n_ms = []
-                for k in range(3):
-                    h.set_states(0, p0, q0, v0)
-                    t1 = time.perf_counter(); h.optimize_batch(0, 0, B, sync=True); n_ms.append(1e3 * (time.perf_counter() - t1))
-                nk_ms = h.info(0)["device_time_us"] * 1e-3
-                out["reference_problem"]["new_frame_per_solve"] = {"lm_iterations_per_s": B * float(np.mean(h.results(0, B)[:, 14])) / (float(np.median(n_ms[1:])) * 1e-3),
-                                                                   "kernel_ms": nk_ms, "kernel": h.last_launch()["kernel"],
-                                                                   "frac": B * N * r_evals * r_cred / (nk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                                   "frac_must_move": B * N * r_evals * r_mm / (nk_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                tn = pmc_traffic(h.last_launch()["kernel"], a)
-                if tn:
-                    out["reference_problem"]["new_frame_per_solve"]["traffic"] = tn["bytes"]
+                out["reference_problem"] = dict(ref12_leg(), solver="ref12", frame_regime="new frame per solve (first-solve kernel, 4x4 tiles)")
             finally:
                 h.set_knob("EDS_FUSED_LAYOUT", None)
-            t = pmc_traffic(k12, a)
-            if t:
-                out["reference_problem"]["roofline"]["traffic"] = t["bytes"]
-                out["reference_problem"]["roofline"]["traffic_source"] = t["source"]
+            out["reference_problem"]["resident_frames"] = ref12_leg()
             h.set_config(cfg)
         if world == 1 and a.exec_ == "device":
             out["latency"] = latency_block(capi, synth, als[0], a)

@@ -8,7 +8,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_${1:-r02}
 rm -rf "$OUT"; mkdir -p "$OUT"
 # (--gen-workers 0: a process the profiler has attached to must not start children; 256 distinct alignments keep the in-process generation short)
-ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu --no-shared --no-configs --distinct 256 --gen-workers 0}"
+# (--gen-workers 0 is ALWAYS appended — also behind a BENCH_ARGS override; bench.py forces it by itself when it sees the profiler)
+ARGS="${BENCH_ARGS:---steps 10 --warmup 2 --no-cpu --no-shared --no-configs --distinct 256} --gen-workers 0"
 python3 bench.py --steps 10 --warmup 2 --no-cpu --no-shared --no-configs > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_fetch.json" 2> "$OUT/fetch.err"

@@ -56,8 +56,8 @@ lines = [f"# rocprofv3 digest {tag}", "",
          f"command: `python3 bench.py {os.environ.get('BENCH_ARGS', '--steps 10 --warmup 2 --no-cpu --no-shared --no-configs')}` "
          f"({cfg['alignments_per_gpu']} alignments x {cfg['points']} points, {cfg['iterations']} {cfg['solver']} iterations, {cfg['sampling']})",
          f"bench value (un-profiled run): {bench['value']:.4g} {bench['unit']}", "",
-         "| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | raw HBM bytes/launch | raw GB/s |",
-         "|---|---|---|---|---|---|---|"]
+         "| kernel | calls | avg us (kernel-trace) | FETCH_SIZE KB/launch | WRITE_SIZE KB/launch | raw bytes/launch | corrected bytes/launch (2 x FETCH + WRITE) | corrected GB/s | of 8 TB/s |",
+         "|---|---|---|---|---|---|---|---|---|"]
 for k, r in stats.items():
     if not k.startswith("eds_"):
         continue
@@ -67,15 +67,17 @@ for k, r in stats.items():
     fkb = sum(f) / len(f) if f else None
     wkb = sum(w) / len(w) if w else None
     raw = (fkb + wkb) * 1024 if (fkb is not None and wkb is not None) else None
-    out["kernels"][k] = {"calls": int(r["Calls"]), "avg_us": avg_us, "fetch_kb": fkb, "write_kb": wkb, "raw_hbm_bytes": raw}
+    corr = (2.0 * fkb + wkb) * 1024 if (fkb is not None and wkb is not None) else None      # MI355X_MICROARCH.md: FETCH_SIZE tallies a 128-byte request at 64 B on gfx950
+    out["kernels"][k] = {"calls": int(r["Calls"]), "avg_us": avg_us, "fetch_kb": fkb, "write_kb": wkb, "raw_hbm_bytes": raw, "hbm_bytes_corrected": corr,
+                         "corrected_GBps": None if corr is None else corr / avg_us / 1e3, "frac_of_8TBps": None if corr is None else corr / avg_us / 1e3 / 8000.0}
     if k in l2:
         m = {c: sum(v) / len(v) for c, v in l2[k].items()}
         if m.get("TCC_REQ_sum"):
             m["hit_fraction"] = m.get("TCC_HIT_sum", 0.0) / m["TCC_REQ_sum"]
         out["kernels"][k]["l2"] = m
     lines.append(f"| {k} | {r['Calls']} | {avg_us:.1f} | {fkb if fkb is None else round(fkb, 1)} | "
-                 f"{wkb if wkb is None else round(wkb, 1)} | {raw if raw is None else int(raw)} | "
-                 f"{'' if raw is None else round(raw / avg_us / 1e3, 1)} |")
+                 f"{wkb if wkb is None else round(wkb, 1)} | {raw if raw is None else int(raw)} | {corr if corr is None else int(corr)} | "
+                 f"{'' if corr is None else round(corr / avg_us / 1e3, 1)} | {'' if corr is None else round(corr / avg_us / 1e3 / 8000.0, 3)} |")
 lines += ["", "L2 (separate `--pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum` pass; per launch, chip-wide sums):", "",
           "| kernel | TCC_REQ | TCC_HIT | TCC_MISS | TCC_EA0_RDREQ | hit fraction |", "|---|---|---|---|---|---|"]
 for k, v in out["kernels"].items():
@@ -92,7 +94,9 @@ lines += ["",
           "  `--pmc FETCH_SIZE`: 64 Mi random locations -> 4.32 GB whether 16, 32 or 64 B are read per location), i.e. correctly,",
           "  except that two sectors of one 128-B line fetched together are tallied once;",
           "* WRITE_SIZE of the residual/Jacobian kernel is exactly 28 B/point (r + six Jacobian planes).",
-          "So raw is a lower bound of the true HBM traffic and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 an upper bound.",
+          "So raw is a lower bound of the true traffic through the fabric and (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — the guide's gfx950 correction, what",
+          "bench.py's `roofline.traffic` / `roofline.frac` use — an upper bound; for the gather kernels the two bounds meet the request counts:",
+          "TCC_EA0_RDREQ x 128 B = 2 x FETCH_SIZE to within a percent (every request of these kernels is a 128-byte line fill).",
           "`eds_fused12_kernel` (bench.py's REF12 measurement) writes the candidate residuals of every evaluation (8 KB per alignment and",
           "evaluation) plus the accepted copies: that is its WRITE_SIZE; `eds_fused6_kernel` (the headline) keeps them in registers and writes",
           "the residuals once."]
