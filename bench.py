@@ -164,73 +164,51 @@ def _cpu_info():
     return {"cpu_model": model, "nproc": os.cpu_count() or 1}
 
 
-def _timed_pool(fn, cores, budget_s):
-    """Calls fn(i) from `cores` threads for about budget_s seconds; returns (sum of results, elapsed)."""
-    from concurrent.futures import ThreadPoolExecutor
-    done, k = 0, 0
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:           # ctypes releases the GIL inside the oracle
-        while time.perf_counter() - t0 < budget_s:
-            done += sum(ex.map(fn, range(k, k + cores * 4)))
-            k += cores * 4
-    return done, time.perf_counter() - t0
-
-
 def cpu_baselines(als, iters, sampling, budget_s):
     """Oracle (test infrastructure) timed as the CPU baseline on this host's cores: (1) the same LM6 iterations as the headline,
-    (2) the optimised fp32 analytic-row variant of them, (3) the reference problem the way the reference runs it."""
+    (2) the optimised variant of them (fp32 SoA, analytic rows, AVX2 over points), (3) the reference problem the way the reference
+    runs it.  Round 5: the all-core figures are driven from C (oracle/eds_oracle_capi.cpp: eds_oracle_bench_lm6 — persistent
+    std::threads taking solves off an atomic counter, no interpreter in the loop), and the block evaluations of the REF12 leg run on
+    a persistent pool like Ceres' (oracle/eds_oracle.hpp: EvalPool)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     samp = po.BICUBIC if sampling == "bicubic" else po.BILINEAR
     info = _cpu_info()
     cores = info["nproc"]
     oracles = [po.Oracle(a, sampling=samp) for a in als]
+    starts = [(a.p0, a.q0, a.v0) for a in als]
     out = {}
-
-    def solve(i):
-        a = als[i % len(als)]
-        return oracles[i % len(als)].pose6_lm(a.p0, a.q0, a.v0, iters=iters, lambda0=0.01)["iterations"]
-
-    solve(0)                                        # page in
-    t0 = time.perf_counter(); n1 = 0
-    while time.perf_counter() - t0 < budget_s * 0.12:
-        n1 += solve(n1)
-    one_core = n1 / (time.perf_counter() - t0)
-    done, dt = _timed_pool(solve, cores, budget_s * 0.3)
-    out["cpu_baseline"] = {"value": done / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
-                           "sample": f"{done // max(iters, 1)} alignments x {iters} LM6 iterations (640x480-class, same inputs) over {dt:.1f} s on "
-                                     f"{cores} threads; one core: {one_core:.1f} iterations/s",
-                           "one_core_value": one_core, **info}
+    one = po.bench_lm6(oracles, starts, iters=iters, lambda0=0.01, threads=1, budget_s=budget_s * 0.1)
+    allc = po.bench_lm6(oracles, starts, iters=iters, lambda0=0.01, threads=cores, budget_s=budget_s * 0.25)
+    out["cpu_baseline"] = {"value": allc["iterations_per_s"], "unit": "iterations/s", "cores": cores, "kind": "port",
+                           "sample": f"{allc['solves']} alignments x {iters} LM6 iterations (640x480-class, same inputs; oracle pose6_lm, Jet autodiff) over "
+                                     f"{allc['seconds']:.1f} s on {cores} threads driven from C; one core: {one['iterations_per_s']:.1f} iterations/s",
+                           "one_core_value": one["iterations_per_s"], "scaling_vs_one_core": allc["iterations_per_s"] / max(one["iterations_per_s"], 1e-9), **info}
     if sampling == "bicubic":
         fast = [po.FastLM6(o, a.v0) for o, a in zip(oracles, als)]
-
-        def solve_fast(i):
-            a = als[i % len(als)]
-            return fast[i % len(als)].solve(a.p0, a.q0, iters=iters, lambda0=0.01)["iterations"]
-
-        solve_fast(0)
-        t0 = time.perf_counter(); n1 = 0
-        while time.perf_counter() - t0 < budget_s * 0.08:
-            n1 += solve_fast(n1)
-        one_fast = n1 / (time.perf_counter() - t0)
-        done, dt = _timed_pool(solve_fast, cores, budget_s * 0.2)
-        out["cpu_baseline_fast"] = {"value": done / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
-                                    "sample": f"optimised CPU variant (fp32 sampling, analytic 1x6 rows, SoA, inputs converted once): "
-                                              f"{done // max(iters, 1)} alignments x {iters} LM6 iterations over {dt:.1f} s on {cores} threads; "
-                                              f"one core: {one_fast:.1f} iterations/s", "one_core_value": one_fast}
+        one_f = po.bench_lm6(oracles, starts, iters=iters, lambda0=0.01, threads=1, budget_s=budget_s * 0.08, fast=fast)
+        all_f = po.bench_lm6(oracles, starts, iters=iters, lambda0=0.01, threads=cores, budget_s=budget_s * 0.2, fast=fast)
+        out["cpu_baseline_fast"] = {"value": all_f["iterations_per_s"], "unit": "iterations/s", "cores": cores, "kind": "port",
+                                    "sample": f"optimised CPU variant (fp32 sampling, analytic 1x6 rows, SoA, "
+                                              f"{'AVX2 over points' if po.fast_is_vectorised() else 'scalar'}, inputs converted once): {all_f['solves']} alignments x {iters} LM6 "
+                                              f"iterations over {all_f['seconds']:.1f} s on {cores} threads driven from C; one core: {one_f['iterations_per_s']:.1f} iterations/s",
+                                    "one_core_value": one_f["iterations_per_s"], "scaling_vs_one_core": all_f["iterations_per_s"] / max(one_f["iterations_per_s"], 1e-9),
+                                    "vectorised": po.fast_is_vectorised()}
     # the reference-faithful leg: 12 parameters, Jet<13> autodiff, Ceres-LM rules, `num_threads` = T residual blocks evaluated by
     # T threads (Tracker.cpp:178-195), ONE alignment at a time like Tracker::optimize
     ref = {}
     a0 = als[0]
     for T in sorted({1, min(8, cores), cores}):
         o12 = po.Oracle(a0, sampling=samp, num_blocks=T, eval_threads=T, max_num_iterations=iters)
-        o12.solve_lm(a0.p0, a0.q0, a0.v0)
+        tw = time.perf_counter()
+        while time.perf_counter() - tw < 0.3:          # warm-up: the pool's workers exist and are spread over the cores
+            o12.solve_lm(a0.p0, a0.q0, a0.v0)
         t0 = time.perf_counter(); its = 0; n = 0
         while time.perf_counter() - t0 < budget_s * 0.1 or n < 2:
             its += o12.solve_lm(a0.p0, a0.q0, a0.v0)["num_iterations"]; n += 1
         dt = time.perf_counter() - t0
         ref[f"T{T}"] = {"lm_iterations_per_s": its / dt, "ms_per_alignment": 1e3 * dt / n, "threads": T, "solves": n}
-    out["cpu_baseline_ref12"] = {"kind": "port", "unit": "LM iterations/s (one alignment at a time, T blocks on T threads)", **ref, **info,
+    out["cpu_baseline_ref12"] = {"kind": "port", "unit": "LM iterations/s (one alignment at a time, T blocks on T threads of a persistent pool)", **ref, **info,
                                  "sample": f"oracle solve_lm (Jet<13>, Ceres-LM restatement), 640x480-class / {a0.N} points, {iters} iterations"}
     return out
 

@@ -25,10 +25,14 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -358,49 +362,102 @@ inline void evaluate_block_jets(const Problem& pb, const SolveConfig& cfg, int s
     }
 }
 
+// Persistent worker pool of the block evaluations.  Ceres keeps a pool of options.num_threads workers for the whole solve
+// (Tracker.cpp:138 sets it; the T residual blocks of Tracker.cpp:178-195 are evaluated on it); spawning T std::threads per
+// evaluation — what this file did until round 4 — cost more than the evaluation itself from 8 threads up (REF12 on the CPU got
+// SLOWER with threads).  One pool per process, grown on demand; the caller takes part in the work.
+class EvalPool {
+  public:
+    static EvalPool& instance() { static EvalPool p; return p; }
+    // runs f(b) for b in [0, n) on up to T threads (the caller is one of them)
+    void run(int n, int T, const std::function<void(int)>& f) {
+        const int helpers = std::min(T, n) - 1;
+        if (helpers <= 0) { for (int b = 0; b < n; ++b) f(b); return; }
+        std::lock_guard<std::mutex> serial(run_m_);          // one parallel section at a time
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while ((int)workers_.size() < helpers) { const int id = (int)workers_.size(); workers_.emplace_back([this, id]() { worker(id); }); }
+            job_ = &f; n_ = n; next_.store(0, std::memory_order_relaxed); want_.store(helpers, std::memory_order_relaxed);
+            active_.store(helpers, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        if (sleepers_.load(std::memory_order_acquire) > 0) cv_.notify_all();
+        for (int b; (b = next_.fetch_add(1, std::memory_order_relaxed)) < n;) f(b);
+        for (int spin = 0; active_.load(std::memory_order_acquire) != 0; ++spin) { if (spin > 64) std::this_thread::yield(); }
+    }
+    ~EvalPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_.store(true); }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+
+  private:
+    // A worker SPINS for its next section for a while (the evaluations of a solve follow each other within a fraction of a millisecond:
+    // a sleeping worker's wake-up costs as much as its share of the work) and only then blocks on the condition variable.
+    void worker(int id) {
+        unsigned long seen = 0;
+        for (;;) {
+            int spins = 0;
+            while (!stop_.load(std::memory_order_relaxed) && !(gen_.load(std::memory_order_acquire) != seen && id < want_.load(std::memory_order_relaxed))) {
+                if (++spins < 40000) { __builtin_ia32_pause(); continue; }
+                std::unique_lock<std::mutex> lk(m_);
+                sleepers_.fetch_add(1, std::memory_order_release);
+                cv_.wait(lk, [&] { return stop_.load() || (gen_.load() != seen && id < want_.load()); });
+                sleepers_.fetch_sub(1, std::memory_order_release);
+                break;
+            }
+            if (stop_.load()) return;
+            const std::function<void(int)>* job; int n;
+            { std::lock_guard<std::mutex> lk(m_); if (gen_.load() == seen || id >= want_.load()) continue; seen = gen_.load(); job = job_; n = n_; }
+            for (int b; (b = next_.fetch_add(1, std::memory_order_relaxed)) < n;) (*job)(b);
+            active_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, run_m_;
+    std::condition_variable cv_;
+    const std::function<void(int)>* job_ = nullptr;
+    std::atomic<int> next_{0}, active_{0}, sleepers_{0};
+    std::atomic<unsigned long> gen_{0};
+    std::atomic<bool> stop_{false};
+    std::atomic<int> want_{0};
+    int n_ = 0;
+};
+
 inline void evaluate(const Problem& pb, const SolveConfig& cfg, const double* p, const double* q,
                      const double* v, bool want_jacobian, Evaluation* ev) {
     const int N = pb.N, B = std::max(1, cfg.num_blocks);
     ev->residuals.assign(N, 0.0);
     ev->raw_residuals.assign(N, 0.0);
     if (want_jacobian) { ev->jac_global.assign(static_cast<size_t>(N) * 13, 0.0); ev->jac_local.assign(static_cast<size_t>(N) * 12, 0.0); }
+    // everything that belongs to one residual block runs on the worker that evaluates the block — functor, chain rule through the local
+    // parameterisations, loss and corrector — as Ceres' evaluator does it; only the block costs are added up afterwards, in block order
+    double Jq[12], Jv[36];
+    quat_plus_jacobian(q, Jq);
+    unit_plus_jacobian(v, Jv);
+    if (want_jacobian) ev->jac_local_raw.assign(static_cast<size_t>(N) * 12, 0.0);
+    std::vector<double> block_cost(B, 0.0);
+    std::vector<char> block_ok(B, 1);
     auto run_block = [&](int b) {
         int start, n; block_range(N, B, b, &start, &n);
         evaluate_block_jets(pb, cfg, start, n, p, q, v, ev->raw_residuals.data() + start,
                             want_jacobian ? ev->jac_global.data() + static_cast<size_t>(start) * 13 : nullptr);
-    };
-    if (cfg.eval_threads > 1 && B > 1) {
-        std::vector<std::thread> th;
-        const int T = std::min(cfg.eval_threads, B);
-        for (int t = 0; t < T; ++t) th.emplace_back([&, t]() { for (int b = t; b < B; b += T) run_block(b); });
-        for (auto& t : th) t.join();
-    } else {
-        for (int b = 0; b < B; ++b) run_block(b);
-    }
-    double Jq[12], Jv[36];
-    quat_plus_jacobian(q, Jq);
-    unit_plus_jacobian(v, Jv);
-    if (want_jacobian) {
-        for (int i = 0; i < N; ++i) {
-            const double* g = &ev->jac_global[static_cast<size_t>(i) * 13];
-            double* l = &ev->jac_local[static_cast<size_t>(i) * 12];
-            for (int k = 0; k < 3; ++k) l[k] = g[k];
-            for (int k = 0; k < 3; ++k) { double s = 0; for (int m = 0; m < 4; ++m) s += g[3 + m] * Jq[3 * m + k]; l[3 + k] = s; }
-            for (int k = 0; k < 6; ++k) { double s = 0; for (int m = 0; m < 6; ++m) s += g[7 + m] * Jv[6 * m + k]; l[6 + k] = s; }
+        if (want_jacobian) {
+            for (int i = start; i < start + n; ++i) {
+                const double* g = &ev->jac_global[static_cast<size_t>(i) * 13];
+                double* l = &ev->jac_local[static_cast<size_t>(i) * 12];
+                for (int k = 0; k < 3; ++k) l[k] = g[k];
+                for (int k = 0; k < 3; ++k) { double s = 0; for (int m = 0; m < 4; ++m) s += g[3 + m] * Jq[3 * m + k]; l[3 + k] = s; }
+                for (int k = 0; k < 6; ++k) { double s = 0; for (int m = 0; m < 6; ++m) s += g[7 + m] * Jv[6 * m + k]; l[6 + k] = s; }
+            }
+            std::memcpy(&ev->jac_local_raw[static_cast<size_t>(start) * 12], &ev->jac_local[static_cast<size_t>(start) * 12], sizeof(double) * 12 * n);
         }
-        ev->jac_local_raw = ev->jac_local;
-    }
-    ev->residuals = ev->raw_residuals;
-    ev->cost = 0.0;
-    ev->ok = true;
-    for (int b = 0; b < B; ++b) {
-        int start, n; block_range(N, B, b, &start, &n);
         double s = 0.0;
-        for (int i = 0; i < n; ++i) { const double r = ev->raw_residuals[start + i]; s += r * r; if (!std::isfinite(r)) ev->ok = false; }
-        if (cfg.loss_type == LOSS_NONE) { ev->cost += 0.5 * s; continue; }
+        for (int i = 0; i < n; ++i) { const double r = ev->raw_residuals[start + i]; ev->residuals[start + i] = r; s += r * r; if (!std::isfinite(r)) block_ok[b] = 0; }
+        if (cfg.loss_type == LOSS_NONE) { block_cost[b] = 0.5 * s; return; }
         double rho[3];
         loss_eval(cfg.loss_type, cfg.loss_param, s, rho);
-        ev->cost += 0.5 * rho[0];
+        block_cost[b] = 0.5 * rho[0];
         Corrector c(s, rho);
         if (want_jacobian) {
             for (int i = 0; i < n; ++i) {
@@ -417,7 +474,16 @@ inline void evaluate(const Problem& pb, const SolveConfig& cfg, const double* p,
             }
         }
         for (int i = 0; i < n; ++i) ev->residuals[start + i] *= c.residual_scaling;
+    };
+    if (cfg.eval_threads > 1 && B > 1) {
+        const std::function<void(int)> job = run_block;
+        EvalPool::instance().run(B, std::min(cfg.eval_threads, B), job);
+    } else {
+        for (int b = 0; b < B; ++b) run_block(b);
     }
+    ev->cost = 0.0;
+    ev->ok = true;
+    for (int b = 0; b < B; ++b) { ev->cost += block_cost[b]; if (!block_ok[b]) ev->ok = false; }
     if (want_jacobian) {
         for (int k = 0; k < 12; ++k) ev->gradient[k] = 0.0;
         for (int i = 0; i < N; ++i) for (int k = 0; k < 12; ++k) {
@@ -492,7 +558,9 @@ inline void solve_lm(const Problem& pb, const SolveConfig& cfg, double p[3], dou
         x_cost = ev.cost;
         J = ev.jac_local;
         if (first) {
-            for (int k = 0; k < NP; ++k) { double s = 0; for (int i = 0; i < pb.N; ++i) s += J[static_cast<size_t>(i) * NP + k] * J[static_cast<size_t>(i) * NP + k]; scale[k] = 1.0 / (1.0 + std::sqrt(s)); }
+            double ss[12] = {0};
+            for (int i = 0; i < pb.N; ++i) for (int k = 0; k < NP; ++k) ss[k] += J[static_cast<size_t>(i) * NP + k] * J[static_cast<size_t>(i) * NP + k];
+            for (int k = 0; k < NP; ++k) scale[k] = 1.0 / (1.0 + std::sqrt(ss[k]));
             first = false;
         }
         for (int i = 0; i < pb.N; ++i) for (int k = 0; k < NP; ++k) J[static_cast<size_t>(i) * NP + k] *= scale[k];
@@ -538,16 +606,26 @@ inline void solve_lm(const Problem& pb, const SolveConfig& cfg, double p[3], dou
 
         // ComputeTrustRegionStep (LevenbergMarquardtStrategy::ComputeStep)
         if (!reuse_diagonal) {
-            for (int k = 0; k < NP; ++k) {
-                double s = 0; for (int i = 0; i < pb.N; ++i) s += J[static_cast<size_t>(i) * NP + k] * J[static_cast<size_t>(i) * NP + k];
-                diagonal[k] = std::min(std::max(s, min_diag), max_diag);
+            double ss[12] = {0};
+            for (int i = 0; i < pb.N; ++i) for (int k = 0; k < NP; ++k) ss[k] += J[static_cast<size_t>(i) * NP + k] * J[static_cast<size_t>(i) * NP + k];
+            for (int k = 0; k < NP; ++k) diagonal[k] = std::min(std::max(ss[k], min_diag), max_diag);
+        }
+        // normal equations J^T J, J^T r: one sweep over the rows of J (every entry is still the sum over the points in point order; the
+        // column-strided form of round 1 walked the 192 KB of J 156 times and was most of a solve on one core)
+        double A[144], g[12], step[12];
+        for (int k = 0; k < 144; ++k) A[k] = 0.0;
+        for (int k = 0; k < NP; ++k) g[k] = 0.0;
+        for (int i = 0; i < pb.N; ++i) {
+            const double* Ji = &J[static_cast<size_t>(i) * NP];
+            const double ri = ev.residuals[i];
+            for (int a = 0; a < NP; ++a) {
+                const double ja = Ji[a];
+                g[a] += ja * ri;
+                for (int b = a; b < NP; ++b) A[a * NP + b] += ja * Ji[b];
             }
         }
-        double A[144], g[12], step[12];
         for (int a = 0; a < NP; ++a) {
-            for (int b = 0; b < NP; ++b) { double s = 0; for (int i = 0; i < pb.N; ++i) s += J[static_cast<size_t>(i) * NP + a] * J[static_cast<size_t>(i) * NP + b]; A[a * NP + b] = s; }
-            double s = 0; for (int i = 0; i < pb.N; ++i) s += J[static_cast<size_t>(i) * NP + a] * ev.residuals[i];
-            g[a] = s;
+            for (int b = 0; b < a; ++b) A[a * NP + b] = A[b * NP + a];
             A[a * NP + a] += diagonal[a] / radius;   // lm_diagonal^2
         }
         reuse_diagonal = true;

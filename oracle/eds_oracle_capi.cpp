@@ -4,7 +4,9 @@
 #include "eds_oracle.hpp"
 #include "eds_cpu_fast.hpp"
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 
 using namespace eds_oracle;
 
@@ -148,6 +150,56 @@ int eds_oracle_fast_lm6(const void* h, double* px, double* qx, int iters, double
     const int n = eds_cpu_fast::lm6(*static_cast<const eds_cpu_fast::Prepared*>(h), px, qx, iters, lambda0, accepted);
     if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return n;
+}
+
+int eds_oracle_fast_lm6_scalar(const void* h, double* px, double* qx, int iters, double lambda0, int32_t* accepted) {
+    return eds_cpu_fast::lm6(*static_cast<const eds_cpu_fast::Prepared*>(h), px, qx, iters, lambda0, accepted, true);
+}
+int eds_oracle_fast_is_vectorised(void) {
+#ifdef EDS_CPU_FAST_AVX2
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+// All-core throughput of the pose-only solve for bench.py's cpu_baseline leg, WITHOUT the interpreter in the loop (round 4 drove the
+// threads from a Python ThreadPoolExecutor with a barrier every cores x 4 tasks: 256 threads reached 10x one core).  `threads`
+// std::threads are started once; each takes solves off a shared atomic counter — solve k works on problem k % nprob from its start
+// pose — until `budget_s` seconds have passed.  mode 0: the oracle's pose6_lm (Jet autodiff), 1: the optimised variant on handles of
+// eds_oracle_fast_prepare.  Returns the number of solves; iterations / elapsed seconds through the pointers.
+long long eds_oracle_bench_lm6(int nprob, const eds_oracle_problem* problems, const void* const* fast_handles, const eds_oracle_config* c,
+                               const double* p0 /*nprob x 3*/, const double* q0 /*nprob x 4*/, const double* v0 /*nprob x 6*/, int iters,
+                               double lambda0, int threads, double budget_s, int mode, long long* iterations, double* elapsed_s) {
+    if (nprob < 1 || threads < 1 || iters < 0) return -1;
+    std::atomic<long long> next{0}, its{0}, done{0};
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        std::vector<double> inc((size_t)std::max(iters, 1) * 6), costs(std::max(iters, 1));
+        std::vector<int> acc(std::max(iters, 1));
+        long long my_its = 0, my_done = 0;
+        while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < budget_s) {
+            const int k = (int)(next.fetch_add(1) % nprob);
+            double p[3], q[4];
+            std::memcpy(p, p0 + 3 * k, sizeof(p)); std::memcpy(q, q0 + 4 * k, sizeof(q));
+            if (mode == 1) {
+                my_its += eds_cpu_fast::lm6(*static_cast<const eds_cpu_fast::Prepared*>(fast_handles[k]), p, q, iters, lambda0, acc.data());
+            } else {
+                Problem pb = to_problem(&problems[k]); SolveConfig cfg = to_config(c);
+                double c0 = 0.0;
+                my_its += pose6_lm(pb, cfg, p, q, v0 + 6 * k, 0.0, iters, lambda0, inc.data(), costs.data(), acc.data(), &c0);
+            }
+            ++my_done;
+        }
+        its += my_its; done += my_done;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (iterations) *iterations = its.load();
+    if (elapsed_s) *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return done.load();
 }
 
 double eds_oracle_loss_param(double* residuals, int n, int method, double current) {

@@ -155,10 +155,38 @@ class FastLM6:
                                       acc.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(sec))
         return dict(p=p, q=q, iterations=n, accepted=acc[:n], seconds=sec.value)
 
+    def solve_scalar(self, p, q, iters=10, lambda0=0.01):
+        """The scalar point loop (the checker of the vectorised one)."""
+        p, q = _f64(p).copy(), _f64(q).copy()
+        acc = np.zeros(iters, dtype=np.int32)
+        n = lib().eds_oracle_fast_lm6_scalar(self._h, _p(p), _p(q), int(iters), C.c_double(lambda0), acc.ctypes.data_as(C.POINTER(C.c_int32)))
+        return dict(p=p, q=q, iterations=n, accepted=acc[:n])
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().eds_oracle_fast_free(self._h)
             self._h = None
+
+
+def fast_is_vectorised() -> bool:
+    return bool(lib().eds_oracle_fast_is_vectorised())
+
+
+def bench_lm6(oracles, starts, iters=10, lambda0=0.01, threads=1, budget_s=1.0, fast=None):
+    """All-core throughput of the pose-only solve, driven from C (eds_oracle_bench_lm6: persistent std::threads, no interpreter in the
+    loop).  oracles: Oracle objects; starts: (p0, q0, v0) per oracle; fast: FastLM6 handles of the same alignments (the optimised
+    variant) or None (the oracle's autodiff solve).  Returns dict(solves, iterations, seconds, iterations_per_s)."""
+    n = len(oracles)
+    probs = (_Problem * n)(*[o.pb for o in oracles])
+    p0 = np.ascontiguousarray(np.stack([_f64(s[0]) for s in starts])); q0 = np.ascontiguousarray(np.stack([_f64(s[1]) for s in starts]))
+    v0 = np.ascontiguousarray(np.stack([_f64(s[2]) for s in starts]))
+    handles = (C.c_void_p * n)(*[f._h for f in fast]) if fast is not None else None
+    its, el = C.c_longlong(0), C.c_double(0.0)
+    L = lib()
+    L.eds_oracle_bench_lm6.restype = C.c_longlong
+    done = L.eds_oracle_bench_lm6(n, probs, handles, C.byref(oracles[0].cfg), _p(p0), _p(q0), _p(v0), int(iters), C.c_double(lambda0), int(threads),
+                                  C.c_double(budget_s), 1 if fast is not None else 0, C.byref(its), C.byref(el))
+    return dict(solves=int(done), iterations=int(its.value), seconds=el.value, iterations_per_s=its.value / max(el.value, 1e-9))
 
 
 def loss_param(residuals, method, current=0.0):

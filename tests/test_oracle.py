@@ -399,3 +399,38 @@ def test_fast_cpu_variant_matches_pose6_lm(synth, po):
         got = po.FastLM6(o, al.v0).solve(al.p0, al.q0, iters=10, lambda0=0.01)
         assert got["iterations"] == ref["iterations"] and np.array_equal(got["accepted"], ref["accepted"])
         assert po.se3_distance(got["p"], got["q"], ref["p"], ref["q"]) <= 1e-5
+
+
+def test_vectorised_cpu_variant_equals_its_scalar_loop_and_the_oracle(synth, po):
+    """Round 5: eds_cpu_fast.hpp's point loop over eight points at a time (AVX2: fp64 projection, gathered taps, packed splines, fp32 lanes
+    flushed to fp64 every 256 points) against its scalar form and the autodiff oracle — odd point counts included (the padded lanes carry
+    weight 0), and points pushed over the frame border (the replicated margin = Grid2D's clamp)."""
+    assert po.fast_is_vectorised()
+    for seed, kw in ((41, dict(H=120, W=160, N=301)), (43, dict(H=96, W=128, N=7)), (5001, {})):
+        al = synth.make_alignment(seed, **kw)
+        o = po.Oracle(al)
+        f = po.FastLM6(o, al.v0)
+        # the second start throws many points outside the frame, all still in front of the camera (not for the 7-point case: with 6 unknowns it is
+        # ill-conditioned enough for the fp32 sums' rounding to change its accept pattern — the autodiff oracle's differs from both there)
+        for p0 in (al.p0,) + ((al.p0 + np.array([0.3, -0.2, 0.0]),) if al.N > 100 else ()):
+            ref = o.pose6_lm(p0, al.q0, al.v0, iters=8, lambda0=0.01)
+            v, s = f.solve(p0, al.q0, iters=8, lambda0=0.01), f.solve_scalar(p0, al.q0, iters=8, lambda0=0.01)
+            assert np.array_equal(v["accepted"], s["accepted"]) and po.se3_distance(v["p"], v["q"], s["p"], s["q"]) <= 1e-6
+            if np.array_equal(p0, al.p0):
+                assert np.array_equal(v["accepted"], ref["accepted"]) and po.se3_distance(v["p"], v["q"], ref["p"], ref["q"]) <= 1e-5
+
+
+def test_all_core_driver_and_eval_pool(synth, po):
+    """The C-driven throughput loop of bench.py's cpu_baseline (eds_oracle_bench_lm6) counts what it solves, and the persistent pool of
+    the REF12 block evaluations (EvalPool; Ceres keeps such a pool, Tracker.cpp:138) gives the same solve as the serial evaluation."""
+    als = [synth.make_alignment(60 + i, H=96, W=128, N=200) for i in range(3)]
+    os_ = [po.Oracle(a) for a in als]
+    st = [(a.p0, a.q0, a.v0) for a in als]
+    for fast in (None, [po.FastLM6(o, a.v0) for o, a in zip(os_, als)]):
+        r = po.bench_lm6(os_, st, iters=5, threads=3, budget_s=0.2, fast=fast)
+        assert r["solves"] >= 3 and r["iterations"] == 5 * r["solves"] and 0.2 <= r["seconds"] < 5.0
+    a = als[0]
+    base = po.Oracle(a, num_blocks=4, eval_threads=1, max_num_iterations=10).solve_lm(a.p0, a.q0, a.v0)
+    for rep in range(3):
+        par = po.Oracle(a, num_blocks=4, eval_threads=4, max_num_iterations=10).solve_lm(a.p0, a.q0, a.v0)
+        assert par["num_iterations"] == base["num_iterations"] and par["final_cost"] == base["final_cost"] and np.array_equal(par["p"], base["p"])

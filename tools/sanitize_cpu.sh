@@ -19,6 +19,6 @@ restore() {
 trap restore EXIT
 trap 'exit 130' INT TERM
 g++ $FLAGS -o tests/host_logic/libhost_logic.so tests/host_logic/harness.cpp || exit 1
-g++ $FLAGS -o oracle/libeds_oracle.so oracle/eds_oracle_capi.cpp || exit 1
+g++ $FLAGS -march=x86-64-v3 -o oracle/libeds_oracle.so oracle/eds_oracle_capi.cpp || exit 1
 LD_PRELOAD=$PRE ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_logic.py tests/test_oracle.py tests/test_oracle_properties.py -q -x
 exit $?
