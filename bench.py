@@ -820,21 +820,26 @@ def main():
             nhb = min(B, 256)
             hb = {}
             for nm, fr in (("fp64", [frames32[b % distinct].astype(np.float64) for b in range(nhb)]), ("fp32", [frames32[b % distinct] for b in range(nhb)])):
-                ts = []
-                for k in range(3):
-                    t1 = time.perf_counter()
-                    for b in range(nhb):
-                        h.set_event_frame(b, fr[b])
-                    h.set_states(0, p0[:nhb], q0[:nhb], v0[:nhb])
-                    h.optimize_batch(0, 0, nhb, sync=True)
-                    ts.append(time.perf_counter() - t1)
-                its_hb = float(np.mean(h.results(0, nhb)[:, 14]))
-                hb[nm] = {"iterations_per_s": nhb * its_hb / float(np.median(ts)), "ms_per_batch": 1e3 * float(np.median(ts)),
-                          "host_GB_per_s": nhb * fr[0].nbytes / float(np.median(ts)) / 1e9, "kernel": h.last_launch()["kernel"]}
+                for mode in ("batch_call", "one_call_per_frame"):
+                    ts = []
+                    for k in range(3):
+                        t1 = time.perf_counter()
+                        if mode == "batch_call":
+                            h.set_event_frames(0, fr)                 # ABI 5: one call, narrowed on a few host threads, PCIe-bound
+                        else:
+                            for b in range(nhb):
+                                h.set_event_frame(b, fr[b])
+                        h.set_states(0, p0[:nhb], q0[:nhb], v0[:nhb])
+                        h.optimize_batch(0, 0, nhb, sync=True)
+                        ts.append(time.perf_counter() - t1)
+                    its_hb = float(np.mean(h.results(0, nhb)[:, 14]))
+                    hb[nm if mode == "batch_call" else nm + "_one_call_per_frame"] = {
+                        "iterations_per_s": nhb * its_hb / float(np.median(ts)), "ms_per_batch": 1e3 * float(np.median(ts)),
+                        "host_GB_per_s": nhb * fr[0].nbytes / float(np.median(ts)) / 1e9, "kernel": h.last_launch()["kernel"]}
                 del fr
             hb["alignments"] = nhb
-            hb["note"] = ("NOT `value`: every frame is handed over as a host buffer inside the timed region (one eds_trk_set_event_frame per alignment, then one "
-                          "launch): the upload, not the solve, is what this measures")
+            hb["note"] = ("NOT `value`: every frame is handed over as a host buffer inside the timed region (eds_trk_set_event_frames: one call for all of them — or one "
+                          "eds_trk_set_event_frame per alignment —, then one launch): the upload, not the solve, is what this measures")
             out["host_buffers_inclusive"] = hb
             h.prepare_frames(0, B)                        # (the legs below solve resident frames)
         if strong is not None:

@@ -170,6 +170,13 @@ int eds_trk_set_idepth_strided(eds_trk* h, int slot, int N, const double* idp, i
  * next solve and not waited for. */
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
+/* ABI 5.  MANY host frames in one call: frames[i] (H x W row-major, caller-owned, needed only for the call) goes to slot first + i.
+ * The fp64 -> fp32 narrowing runs on a few host threads (knob EDS_UPLOAD_THREADS, default 8) into a ring of pinned staging slots while
+ * the store kernels of earlier frames read theirs over PCIe: a batch is bound by PCIe, not by one host thread.  The slots end up
+ * bit-identical to `count` calls of eds_trk_set_event_frame (reference: the frames Tracker::optimize is handed, Tracker.hpp:80-81,
+ * EventFrame.hpp:59).  Asynchronous on the handle's stream like the one-frame call. */
+int eds_trk_set_event_frames(eds_trk* h, int first, int count, const double* const* frames);
+int eds_trk_set_event_frames_f32(eds_trk* h, int first, int count, const float* const* frames);
 /* Slot `slot` samples slot `src_slot`'s frame storage from now on (no copy) — several alignments against ONE event frame (pose
  * hypotheses, several keyframes).  Alignments that share a frame and are launched together re-use each other's lines in the L2 when
  * their slots are congruent modulo 8 (workgroup b of a launch runs on XCD b % 8).  A later frame written INTO `slot` (set / build)

@@ -32,7 +32,7 @@ EXPORTS = (
     "eds_abi_version", "eds_device_count", "eds_last_error", "eds_trk_cfg_default", "eds_trk_cfg_size",
     "eds_trk_info_size",
     "eds_trk_create", "eds_trk_destroy", "eds_trk_set_config", "eds_trk_get_config",
-    "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_idepth_strided", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32",
+    "eds_trk_set_keyframe", "eds_trk_set_idepth", "eds_trk_set_idepth_strided", "eds_trk_set_event_frame", "eds_trk_set_event_frame_f32", "eds_trk_set_event_frames", "eds_trk_set_event_frames_f32",
     "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos", "eds_trk_build_event_frames_aos_timed", "eds_event_times_aos",
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
@@ -160,6 +160,8 @@ def lib():
         L.eds_trk_set_idepth_strided.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int]
         L.eds_trk_set_event_frame.argtypes = [C.c_void_p, C.c_int, _dp]
         L.eds_trk_set_event_frame_f32.argtypes = [C.c_void_p, C.c_int, _fp]
+        L.eds_trk_set_event_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.eds_trk_set_event_frames_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.eds_trk_set_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.eds_trk_get_state.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
         L.eds_trk_set_undistort_map.argtypes = [C.c_void_p, _fp, _fp]
@@ -322,6 +324,19 @@ class Handle:
         else:
             fr = _f64(fr)
             _check(lib().eds_trk_set_event_frame(self._h, slot, _p(fr)))
+
+    def set_event_frames(self, first, frames):
+        """Many host frames in ONE call (eds_trk_set_event_frames / _f32): frames[i] -> slot first + i; all fp64 or all fp32, each H x W."""
+        arrs = [np.ascontiguousarray(f) for f in frames]
+        f32 = all(a.dtype == np.float32 for a in arrs)
+        if not f32:
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+        for a in arrs:
+            if a.size != self.H * self.W:
+                raise ValueError("frame size does not match the handle")
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        fn = lib().eds_trk_set_event_frames_f32 if f32 else lib().eds_trk_set_event_frames
+        _check(fn(self._h, int(first), len(arrs), ptrs))
 
     def set_undistort_map(self, mapx=None, mapy=None):
         if mapx is None:

@@ -103,7 +103,8 @@ void free_all(eds_trk* h) {
     eds_frame_free(&h->frame_build);
     eds_points_free(&h->point_ops);
     eds_keyframe_free(&h->kf_build);
-    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap, h->h_idp, h->h_fprog};
+    void* hptrs[] = {h->h_pose, h->h_part, h->h_G, h->h_f32, h->h_r, h->h_fstage, h->h_rmap, h->h_idp, h->h_fprog, h->h_bstage};
+    for (hipEvent_t e : h->ev_bstage) hipEventDestroy(e);
     for (void* p : hptrs) if (p) hipHostFree(p);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);

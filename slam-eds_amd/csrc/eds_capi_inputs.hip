@@ -2,12 +2,14 @@
 // (Tracker.cpp:167 re-reads them on every optimize), event frames as host buffers (the reference hands optimize a std::vector<double>)
 // or built on the device from events (EventFrame.cpp:302-389), shared frames.  Nothing here waits for the GPU on the live path.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "eds_capi_internal.hpp"
@@ -111,6 +113,66 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
     h->stage_busy = true;
     h->slots[slot].has_frame = true;
     ++h->slots[slot].frame_version;             // its strip copy (eds_strips.hip) is out of date
+    return EDS_OK;
+}
+
+// MANY host frames in one call (round 5; VERDICT r4 Next #5): eds_trk_set_event_frame spends its time in ONE host thread narrowing
+// fp64 to fp32 (34 us per VGA frame against ~25 us of PCIe), so a batch of 256 took 20 ms.  Here `threads` workers narrow the frames
+// into a ring of pinned, device-mapped staging slots; this thread launches one store kernel per frame as it becomes ready (the kernel
+// reads the staging slot over PCIe and writes the slot's tiles) and hands a staging slot back to the workers when the kernel that read
+// it has finished (HIP events).  Only this thread talks to HIP.  Frames land bit-identical to the one-frame path (same narrowing, same
+// store kernel).
+template <class T>
+static int upload_frames_batch(eds_trk* h, int first, int count, const T* const* frames) {
+    { int rc_ = unshare_frames(h, first, count); if (rc_) return rc_; }
+    const size_t fe = (size_t)h->H * h->W;
+    const int S = std::min(count, 16);
+    if (h->bstage_slots < S) {
+        if (h->h_bstage) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); hipHostFree(h->h_bstage); h->h_bstage = nullptr; h->bstage_slots = 0; }
+        EDS_HIP_TRY(hipHostMalloc((void**)&h->h_bstage, (size_t)S * fe * sizeof(float), hipHostMallocMapped));
+        EDS_HIP_TRY(hipHostGetDevicePointer((void**)&h->d_bstage, h->h_bstage, 0));
+        h->bstage_slots = S;
+    }
+    while ((int)h->ev_bstage.size() < S) { hipEvent_t e; EDS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_bstage.push_back(e); }
+    if (h->bstage_busy) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); h->bstage_busy = false; }      // an earlier batch's last reads of the ring
+    int nthr = h->knobs.upload_threads > 0 ? h->knobs.upload_threads : 8;
+    nthr = std::max(1, std::min(nthr, std::min(count, (int)std::max(1u, std::thread::hardware_concurrency()))));
+    std::atomic<int> next{0}, released{S};
+    std::vector<std::atomic<unsigned char>> ready(count);
+    for (auto& r : ready) r.store(0, std::memory_order_relaxed);
+    std::atomic<bool> abort{false};
+    float* const stage = h->h_bstage;
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= count) return;
+            for (int spin = 0; i >= released.load(std::memory_order_acquire); ++spin) {
+                if (abort.load(std::memory_order_relaxed)) return;
+                if (spin > 256) std::this_thread::yield();
+            }
+            narrow_band(frames[i], stage + (size_t)(i % S) * fe, fe);
+            ready[i].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
+    int completed = 0;
+    hipError_t err = hipSuccess;
+    for (int i = 0; i < count && err == hipSuccess; ++i) {
+        for (int spin = 0; !ready[i].load(std::memory_order_acquire); ++spin) if (spin > 256) std::this_thread::yield();
+        eds_frame_store_rowmajor(h, first + i, h->d_bstage + (size_t)(i % S) * fe, 0, h->H);
+        err = hipEventRecord(h->ev_bstage[i % S], h->st);
+        // staging slots whose kernel has finished go back to the workers; when none is free and frames are still to be staged: wait for the oldest
+        while (completed <= i && hipEventQuery(h->ev_bstage[completed % S]) == hipSuccess) ++completed;
+        if (completed + S <= i + 1 && i + 1 < count && err == hipSuccess) { err = hipEventSynchronize(h->ev_bstage[completed % S]); ++completed; }
+        released.store(completed + S, std::memory_order_release);
+    }
+    if (err != hipSuccess) abort.store(true);
+    for (auto& t : pool) t.join();
+    if (err != hipSuccess) { hipStreamSynchronize(h->st); return fail(EDS_ERR_HIP, hipGetErrorString(err)); }
+    EDS_HIP_TRY(hipGetLastError());
+    h->bstage_busy = true;
+    for (int s = first; s < first + count; ++s) { h->slots[s].has_frame = true; ++h->slots[s].frame_version; }
     return EDS_OK;
 }
 
@@ -230,6 +292,22 @@ int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame) {
     if (!frame) return fail(EDS_ERR_INVALID, "null frame");
     EDS_HIP_TRY(hipSetDevice(h->dev));
     return upload_frame(h, slot, frame);
+}
+
+int eds_trk_set_event_frames(eds_trk* h, int first, int count, const double* const* frames) {
+    if (!h || !frames) return fail(EDS_ERR_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > h->B) return fail(EDS_ERR_INVALID, "bad slot range");
+    for (int i = 0; i < count; ++i) if (!frames[i]) return fail(EDS_ERR_INVALID, "null frame");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return upload_frames_batch(h, first, count, frames);
+}
+
+int eds_trk_set_event_frames_f32(eds_trk* h, int first, int count, const float* const* frames) {
+    if (!h || !frames) return fail(EDS_ERR_INVALID, "null argument");
+    if (first < 0 || count < 1 || first + count > h->B) return fail(EDS_ERR_INVALID, "bad slot range");
+    for (int i = 0; i < count; ++i) if (!frames[i]) return fail(EDS_ERR_INVALID, "null frame");
+    EDS_HIP_TRY(hipSetDevice(h->dev));
+    return upload_frames_batch(h, first, count, frames);
 }
 
 int eds_trk_set_undistort_map(eds_trk* h, const float* mapx, const float* mapy) {

@@ -75,6 +75,10 @@ struct eds_trk {
     bool gram_pending = false;          // h_G's refresh is still in flight on the stream (set_idepth does not wait for it)
     bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
     size_t h_f32_elems = 0;
+    float *h_bstage = nullptr, *d_bstage = nullptr;   // pinned, device-mapped ring of staging slots of eds_trk_set_event_frames (allocated at its first call)
+    int bstage_slots = 0;
+    bool bstage_busy = false;           // the last batch's store kernels may still read the ring
+    std::vector<hipEvent_t> ev_bstage;  // one per staging slot: recorded behind the kernel that read it
     void* d_probe = nullptr;            // scratch of the measurement helpers (eds_trk_hbm_probe, eds_trk_bench_kernel_cold): allocated at their first call
     size_t probe_bytes = 0;
     std::vector<Slot> slots;
