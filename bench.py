@@ -152,6 +152,27 @@ def _under_profiler():
     return "rocprof" in pre or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ)
 
 
+def _usable_cpus():
+    """CPUs this process may really use: the scheduler affinity, capped by the cgroup's CPU quota (cpu.max: the GPU boxes of the pool
+    show 256 hardware threads and a quota of 16 CPUs — 256 busy threads there share 16 CPUs' worth of time and are throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def _cpu_info():
     model = "unknown"
     try:
@@ -161,7 +182,8 @@ def _cpu_info():
                 break
     except OSError:
         pass
-    return {"cpu_model": model, "nproc": os.cpu_count() or 1}
+    usable, quota = _usable_cpus()
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_cpus": usable, "cgroup_cpu_quota": quota}
 
 
 def cpu_baselines(als, iters, sampling, budget_s):
@@ -174,7 +196,7 @@ def cpu_baselines(als, iters, sampling, budget_s):
     import pyoracle as po
     samp = po.BICUBIC if sampling == "bicubic" else po.BILINEAR
     info = _cpu_info()
-    cores = info["nproc"]
+    cores = info["usable_cpus"]                   # threads actually used: what the box lets this process have (affinity and cgroup quota), not its thread count
     oracles = [po.Oracle(a, sampling=samp) for a in als]
     starts = [(a.p0, a.q0, a.v0) for a in als]
     out = {}
@@ -583,7 +605,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         gen_pool = ThreadPoolExecutor(min(32, os.cpu_count() or 1))
     else:
-        nw = a.gen_workers if a.gen_workers > 0 else max(4, min(96, (os.cpu_count() or 8) // max(world, 1)))
+        nw = a.gen_workers if a.gen_workers > 0 else max(4, min(96, _usable_cpus()[0] // max(world, 1)))
         gen_pool = ProcessPoolExecutor(max_workers=nw, mp_context=multiprocessing.get_context("spawn"))
     gen_jobs = [gen_pool.submit(_gen_alignment, (5000 + ((rank * a.batch + i) % max(distinct * world, 1)), a.height, a.width, a.points, i < KEEP_WHOLE))
                 for i in range(distinct)]

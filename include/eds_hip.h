@@ -171,7 +171,7 @@ int eds_trk_set_idepth_strided(eds_trk* h, int slot, int N, const double* idp, i
 int eds_trk_set_event_frame(eds_trk* h, int slot, const double* frame);
 int eds_trk_set_event_frame_f32(eds_trk* h, int slot, const float* frame);
 /* ABI 5.  MANY host frames in one call: frames[i] (H x W row-major, caller-owned, needed only for the call) goes to slot first + i.
- * The fp64 -> fp32 narrowing runs on a few host threads (knob EDS_UPLOAD_THREADS, default 8) into a ring of pinned staging slots while
+ * The fp64 -> fp32 narrowing runs on a few host threads (knob EDS_UPLOAD_THREADS, default 4) into a ring of pinned staging slots while
  * the store kernels of earlier frames read theirs over PCIe: a batch is bound by PCIe, not by one host thread.  The slots end up
  * bit-identical to `count` calls of eds_trk_set_event_frame (reference: the frames Tracker::optimize is handed, Tracker.hpp:80-81,
  * EventFrame.hpp:59).  Asynchronous on the handle's stream like the one-frame call. */

@@ -96,7 +96,7 @@ void free_all(eds_trk* h) {
     if (!h) return;
     hipSetDevice(h->dev);
     void* dptrs[] = {h->dkf, h->dpose, h->dG, h->dpart, h->dncstat,
-                     h->dmhat, h->dframe, h->dr, h->dJ, h->d_probe};
+                     h->dmhat, h->dframe, h->dr, h->dJ, h->d_probe, h->d_bdev};
     for (void* p : dptrs) if (p) hipFree(p);
     eds_fused_free(&h->fused);
     eds_strips_free(h);
@@ -110,6 +110,8 @@ void free_all(eds_trk* h) {
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev_stage) hipEventDestroy(h->ev_stage);
     if (h->ev_idp) hipEventDestroy(h->ev_idp);
+    if (h->ev_up) hipEventDestroy(h->ev_up);
+    if (h->st_up) hipStreamDestroy(h->st_up);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }

@@ -133,9 +133,17 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
         EDS_HIP_TRY(hipHostGetDevicePointer((void**)&h->d_bstage, h->h_bstage, 0));
         h->bstage_slots = S;
     }
+    const bool dma = h->knobs.upload_dma != 0;
+    const bool two_streams = !dma && h->knobs.upload_streams != 1 && count > 1;
+    if (two_streams) {                  // the second stream starts behind everything the handle's stream holds so far ...
+        if (!h->st_up) { EDS_HIP_TRY(hipStreamCreateWithFlags(&h->st_up, hipStreamNonBlocking)); EDS_HIP_TRY(hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming)); }
+        EDS_HIP_TRY(hipEventRecord(h->ev_up, h->st));
+        EDS_HIP_TRY(hipStreamWaitEvent(h->st_up, h->ev_up, 0));
+    }
+    if (dma && !h->d_bdev) EDS_HIP_TRY(hipMalloc((void**)&h->d_bdev, 2 * fe * sizeof(float)));
     while ((int)h->ev_bstage.size() < S) { hipEvent_t e; EDS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->ev_bstage.push_back(e); }
     if (h->bstage_busy) { EDS_HIP_TRY(hipStreamSynchronize(h->st)); h->bstage_busy = false; }      // an earlier batch's last reads of the ring
-    int nthr = h->knobs.upload_threads > 0 ? h->knobs.upload_threads : 8;
+    int nthr = h->knobs.upload_threads > 0 ? h->knobs.upload_threads : 4;      // measured (tools/bench_upload_batch.py): two threads already keep PCIe busy; more only contend
     nthr = std::max(1, std::min(nthr, std::min(count, (int)std::max(1u, std::thread::hardware_concurrency()))));
     std::atomic<int> next{0}, released{S};
     std::vector<std::atomic<unsigned char>> ready(count);
@@ -160,8 +168,15 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
     hipError_t err = hipSuccess;
     for (int i = 0; i < count && err == hipSuccess; ++i) {
         for (int spin = 0; !ready[i].load(std::memory_order_acquire); ++spin) if (spin > 256) std::this_thread::yield();
-        eds_frame_store_rowmajor(h, first + i, h->d_bstage + (size_t)(i % S) * fe, 0, h->H);
-        err = hipEventRecord(h->ev_bstage[i % S], h->st);
+        if (dma) {          // copy engine: pinned staging slot -> row-major scratch in HBM, then the store kernel reads HBM
+            err = hipMemcpyAsync(h->d_bdev + (size_t)(i % 2) * fe, stage + (size_t)(i % S) * fe, fe * sizeof(float), hipMemcpyHostToDevice, h->st);
+            if (err == hipSuccess) err = hipEventRecord(h->ev_bstage[i % S], h->st);      // the staging slot is free once the copy is through
+            eds_frame_store_whole(h, first + i, h->d_bdev + (size_t)(i % 2) * fe, h->st);
+        } else {            // the store kernel reads the staging slot over PCIe; consecutive frames alternate between two streams, so that one
+            hipStream_t sx = two_streams && (i & 1) ? h->st_up : h->st;                  // kernel's tail overlaps the next one's ramp-up
+            eds_frame_store_whole(h, first + i, h->d_bstage + (size_t)(i % S) * fe, sx);
+            err = hipEventRecord(h->ev_bstage[i % S], sx);
+        }
         // staging slots whose kernel has finished go back to the workers; when none is free and frames are still to be staged: wait for the oldest
         while (completed <= i && hipEventQuery(h->ev_bstage[completed % S]) == hipSuccess) ++completed;
         if (completed + S <= i + 1 && i + 1 < count && err == hipSuccess) { err = hipEventSynchronize(h->ev_bstage[completed % S]); ++completed; }
@@ -169,6 +184,10 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
     }
     if (err != hipSuccess) abort.store(true);
     for (auto& t : pool) t.join();
+    if (two_streams && err == hipSuccess) {      // ... and the handle's stream goes on behind the second one's last kernel
+        err = hipEventRecord(h->ev_up, h->st_up);
+        if (err == hipSuccess) err = hipStreamWaitEvent(h->st, h->ev_up, 0);
+    }
     if (err != hipSuccess) { hipStreamSynchronize(h->st); return fail(EDS_ERR_HIP, hipGetErrorString(err)); }
     EDS_HIP_TRY(hipGetLastError());
     h->bstage_busy = true;

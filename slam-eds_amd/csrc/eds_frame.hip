@@ -330,6 +330,31 @@ void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_
                        h->dframe + (size_t)slot * h->Hp * h->Wp, h->H, h->W, h->Hp, h->Wp, h->tiled, lo);
 }
 
+// A WHOLE frame, 16 bytes per lane (the batch upload, eds_trk_set_event_frames): thread (tile column, row) moves the four pixels of one
+// tile row — one float4 read from the row-major source (pinned host memory read over PCIe: the wider the requests, the fewer of
+// them are in flight per byte), one float4 store into the tile.  Pieces that touch the replicated margin or the padding go pixel by
+// pixel through the clamp.  Tiled frames with W a multiple of 4 only (the caller falls back to k_store_rowmajor otherwise).
+__global__ __launch_bounds__(256) void k_store_frame4(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int Hp, int Wp) {
+    const int tc = (int)(blockIdx.x * blockDim.x + threadIdx.x), r = (int)blockIdx.y - EDS_FRAME_MARGIN;
+    if (tc >= (Wp >> 2)) return;
+    const int c = 4 * tc - EDS_FRAME_MARGIN, rs = min(max(r, 0), H - 1);
+    float4 v;
+    if (c >= 0 && c + 3 < W) {
+        v = *reinterpret_cast<const float4*>(src + (size_t)rs * W + c);
+    } else {
+        const float* row = src + (size_t)rs * W;
+        v = make_float4(row[min(max(c, 0), W - 1)], row[min(max(c + 1, 0), W - 1)], row[min(max(c + 2, 0), W - 1)], row[min(max(c + 3, 0), W - 1)]);
+    }
+    *reinterpret_cast<float4*>(dst + eds_frame_index(r, c, Wp, 1)) = v;
+}
+void eds_frame_store_whole(eds_trk* h, int slot, const float* d_src, hipStream_t st) {
+    float* dst = h->dframe + (size_t)slot * h->Hp * h->Wp;
+    if (h->tiled && (h->W & 3) == 0)
+        hipLaunchKernelGGL(k_store_frame4, dim3(((h->Wp >> 2) + 255) / 256, h->Hp), dim3(256), 0, st, d_src, dst, h->H, h->W, h->Hp, h->Wp);
+    else
+        hipLaunchKernelGGL(k_store_rowmajor, dim3((h->Wp + 255) / 256, h->Hp), dim3(256), 0, st, d_src, dst, h->H, h->W, h->Hp, h->Wp, h->tiled, -EDS_FRAME_MARGIN);
+}
+
 // One launch that follows the host through the staging buffer (k_store_follow); the caller publishes its progress in h->h_fprog[0].
 void eds_frame_store_follow(eds_trk* h, int slot, unsigned seq, int rows_per) {
     const int nbands = (h->H + rows_per - 1) / rows_per;

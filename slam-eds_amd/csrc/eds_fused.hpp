@@ -148,6 +148,7 @@ int  eds_frame_build_batch(eds_trk* h, int first_slot, int count, const int* off
 // them back (Tracker.cpp:223-230) costs no copy call and no second wait; false: not mirrored (fetch as usual)
 bool eds_mirror_residuals(eds_trk* h, int first, int count);
 void eds_frame_store_rowmajor(eds_trk* h, int slot, const float* d_src, int row_b, int row_e);     // row-major fp32 H x W in HBM -> the slot's tiled frame
+void eds_frame_store_whole(eds_trk* h, int slot, const float* d_src, hipStream_t st);          // a whole row-major fp32 frame (device-visible) -> the slot's frame, on stream st
 void eds_frame_store_follow(eds_trk* h, int slot, unsigned seq, int rows_per);     // ONE launch that follows the host through h_fstage (h_fprog[0]: rows narrowed so far)
 int  eds_frame_set_map(eds_trk* h, const float* mapx, const float* mapy, int mH, int mW);
 // events as an array of structs (what the reference holds: std::vector<base::samples::Event>): stride and field offsets in bytes

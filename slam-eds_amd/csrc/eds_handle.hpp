@@ -76,6 +76,9 @@ struct eds_trk {
     bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
     size_t h_f32_elems = 0;
     float *h_bstage = nullptr, *d_bstage = nullptr;   // pinned, device-mapped ring of staging slots of eds_trk_set_event_frames (allocated at its first call)
+    hipStream_t st_up = nullptr;        // second stream of the batch upload (alternate frames), created at its first call
+    hipEvent_t ev_up = nullptr;
+    float* d_bdev = nullptr;            // two row-major H x W scratch frames in HBM (the copy-engine variant of the batch upload: EDS_UPLOAD_DMA)
     int bstage_slots = 0;
     bool bstage_busy = false;           // the last batch's store kernels may still read the ring
     std::vector<hipEvent_t> ev_bstage;  // one per staging slot: recorded behind the kernel that read it

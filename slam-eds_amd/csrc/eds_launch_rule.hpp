@@ -46,7 +46,9 @@ struct EdsKnobs {
     int upload_bands = 0;       // EDS_UPLOAD=bands    one launch per band of a host frame (round 2's upload)
     int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
     int reduce_ppl = 4;         // EDS_REDUCE_PPL      4 | 8: points a lane of eds_reduce_kernel<6> folds (16-byte loads)
-    int upload_threads = 0;     // EDS_UPLOAD_THREADS  1 .. 64: host threads that narrow the frames of eds_trk_set_event_frames   0: the rule (8)
+    int upload_threads = 0;     // EDS_UPLOAD_THREADS  1 .. 64: host threads that narrow the frames of eds_trk_set_event_frames   0: the rule (4)
+    int upload_streams = 0;     // EDS_UPLOAD_STREAMS  1: the batch upload keeps to the handle's stream (default: alternate frames on a second one)
+    int upload_dma = 0;         // EDS_UPLOAD_DMA      1: the batch upload moves the staged frames with the copy engine (hipMemcpyAsync) instead of kernels reading pinned memory
     int lm6_groups = 0;         // EDS_LM6_GROUPS      1 | 2 | 4 | 8: candidate groups of a team launch (eds_fused.hip)   0: the rule
 };
 
@@ -77,6 +79,8 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_FRAME_LAYOUT")) k->frame_rowmajor = is("rowmajor") ? 1 : 0;
     else if (!strcmp(name, "EDS_REDUCE_PPL")) k->reduce_ppl = iv == 8 ? 8 : 4;
     else if (!strcmp(name, "EDS_LM6_GROUPS")) k->lm6_groups = unset ? 0 : iv;
+    else if (!strcmp(name, "EDS_UPLOAD_STREAMS")) k->upload_streams = unset ? 0 : (iv == 1 ? 1 : 0);
+    else if (!strcmp(name, "EDS_UPLOAD_DMA")) k->upload_dma = unset ? 0 : (value[0] != '0');
     else if (!strcmp(name, "EDS_UPLOAD_THREADS")) k->upload_threads = (iv >= 1 && iv <= 64) ? iv : 0;
     else return -1;
     return 0;
@@ -86,7 +90,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS")
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS")
 
 // the process environment, read once per handle (eds_trk_create)
 static inline void eds_knobs_from_env(EdsKnobs* k) {

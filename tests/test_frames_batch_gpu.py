@@ -7,8 +7,9 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("dma", [False, True])
 @pytest.mark.parametrize("H,W,count,threads", [(120, 160, 40, None), (61, 83, 17, 3), (480, 640, 33, 16), (48, 64, 1, None), (120, 160, 16, 1)])
-def test_batch_upload_equals_one_frame_uploads(gpu, capi, H, W, count, threads):
+def test_batch_upload_equals_one_frame_uploads(gpu, capi, H, W, count, threads, dma):
     rng = np.random.default_rng(H * 1000 + count)
     frames = [rng.standard_normal((H, W)) * 1e-2 for _ in range(count)]
     frames[0][0, :] = np.array([1e-300, -1e-300, 1e38, -3.4e38] * (W // 4) + [0.0] * (W % 4))      # denormal / huge values narrow the same way
@@ -17,6 +18,7 @@ def test_batch_upload_equals_one_frame_uploads(gpu, capi, H, W, count, threads):
     ha, hb = capi.Handle(cfg, B, 64, H, W), capi.Handle(cfg, B, 64, H, W)
     if threads:
         hb.set_knob("EDS_UPLOAD_THREADS", str(threads))
+    hb.set_knob("EDS_UPLOAD_DMA", "1" if dma else "0")
     for dt in (np.float64, np.float32):
         fr = [np.ascontiguousarray(f, dtype=dt) for f in frames]
         for i, f in enumerate(fr):
@@ -48,6 +50,7 @@ def test_batch_upload_then_solve_equals_single_uploads(gpu, capi, synth, po):
             if not batch:
                 h.set_event_frame(b, a.frame)
         if batch:
+            h.set_event_frame(2, als[2].frame)
             h.share_event_frame(7, 2)                                           # a shared slot gets a frame of its own again
             h.set_event_frames(0, [als[b % 5].frame for b in range(B)])
         h.set_states(0, np.stack([als[b % 5].p0 for b in range(B)]), np.stack([als[b % 5].q0 for b in range(B)]), np.stack([als[b % 5].v0 for b in range(B)]))
