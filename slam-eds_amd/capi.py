@@ -41,7 +41,7 @@ EXPORTS = (
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
     "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_last_launch", "eds_trk_prepare_frames",
-    "eds_trk_set_knob", "eds_trk_get_strips_info", "eds_trk_bench_kernel_cold", "eds_trk_hbm_probe",
+    "eds_trk_set_knob", "eds_trk_get_strips_info", "eds_trk_bench_kernel_cold", "eds_trk_hbm_probe", "eds_trk_kernel_instances",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
     "eds_pyr_get_residuals", "eds_pyr_create_batch", "eds_pyr_set_keyframe_slot", "eds_pyr_set_event_frame_slot", "eds_pyr_optimize_batch",
@@ -655,6 +655,18 @@ class Handle:
         r, c = C.c_float(0.0), C.c_float(0.0)
         _check(lib().eds_trk_hbm_probe(self._h, int(nbytes), reps, C.byref(r), C.byref(c)))
         return {"read_GBps": r.value, "copy_GBps": c.value, "bytes": int(nbytes), "reps": reps}
+
+
+def kernel_instances(family: int):
+    """The compiled instantiations of eds_fused6_kernel (family 0: S, P, T, Q, K, G) / eds_fused12_kernel (1: S, T, CAP, NC, K, Q)."""
+    L = lib()
+    n = L.eds_trk_kernel_instances(int(family), -1, None)
+    out = []
+    for i in range(max(n, 0)):
+        a = (C.c_int32 * 6)()
+        L.eds_trk_kernel_instances(int(family), i, a)
+        out.append(tuple(int(x) for x in a))
+    return out
 
 
 class Pyramid:

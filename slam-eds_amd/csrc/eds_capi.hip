@@ -426,9 +426,44 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
 int eds_trk_set_knob(eds_trk* h, const char* name, const char* value) {
     if (!h || !name) return fail(EDS_ERR_INVALID, "null argument");
     if (std::strcmp(name, "EDS_FRAME_LAYOUT") == 0) return fail(EDS_ERR_STATE, "EDS_FRAME_LAYOUT decides the allocation: environment at eds_trk_create only");
-    if (eds_knobs_set(&h->knobs, name, value) != 0) return fail(EDS_ERR_INVALID, std::string("unknown knob ") + name);
-    if (std::strncmp(name, "EDS_STRIPS_", 11) == 0) h->strips_unavailable = false;       // a new budget / phase count: ask again
+    //  a solve in flight reads the knobs between its launch and its collection: no changes under it
+    if (h->fused.pending_count > 0) return fail(EDS_ERR_STATE, "a batch is in flight: call eds_trk_sync before changing a knob");
+    const int rc = eds_knobs_set(&h->knobs, name, value);
+    if (rc == -1) return fail(EDS_ERR_INVALID, std::string("unknown knob ") + name);
+    if (rc != 0) return fail(EDS_ERR_INVALID, std::string("knob ") + name + " does not take the value '" + (value ? value : "") + "'");
+    if (std::strncmp(name, "EDS_STRIPS_", 11) == 0) {
+        // a new budget / phase count / policy: the copies are allocated again (with the new row phases) by the next solve that wants them
+        h->strips_unavailable = false;
+        if (h->dstrips && (std::strcmp(name, "EDS_STRIPS_PHASES") == 0 || std::strcmp(name, "EDS_STRIPS_BUDGET_PCT") == 0)) {
+            EDS_HIP_TRY(hipSetDevice(h->dev));
+            EDS_HIP_TRY(hipStreamSynchronize(h->st));
+            eds_strips_free(h);
+            for (Slot& sl : h->slots) sl.strips_version = 0;
+        }
+    }
     return EDS_OK;
+}
+
+// The instantiations of the persistent kernels this library was compiled with (csrc/eds_launch_rule.hpp's X-macro lists: the launchers
+// dispatch over the same lists).  family 0: eds_fused6_kernel<S, P, T, Q, K, G> (both translation units, candidate groups included),
+// 1: eds_fused12_kernel<S, T, CAP, NC, K, Q>.  Returns the number of instantiations of the family (or -1); when 0 <= index < count and
+// args6 is not NULL the six template arguments of instantiation `index` are written to it.
+int eds_trk_kernel_instances(int family, int index, int32_t* args6) {
+    static const int32_t f6[][6] = {
+#define EDS_I5_(s, p, t, q, k) {s, p, t, q, k, 1},
+#define EDS_I6_(s, p, t, q, k, g) {s, p, t, q, k, g},
+        EDS_FUSED6_MAIN_INSTANCES(EDS_I5_) EDS_FUSED6_BILINEAR_INSTANCES(EDS_I5_) EDS_FUSED6_GROUP_INSTANCES(EDS_I6_) EDS_FUSED6_BILINEAR_GROUP_INSTANCES(EDS_I6_)
+#undef EDS_I5_
+#undef EDS_I6_
+    };
+    static const int32_t f12[][6] = {
+#define EDS_I12_(s, t, c, n, k, q) {s, t, c, n ? 1 : 0, k, q},
+        EDS_FUSED12_INSTANCES(EDS_I12_)
+#undef EDS_I12_
+    };
+    const int n = family == 0 ? (int)(sizeof(f6) / sizeof(f6[0])) : (family == 1 ? (int)(sizeof(f12) / sizeof(f12[0])) : -1);
+    if (n > 0 && args6 && index >= 0 && index < n) std::memcpy(args6, family == 0 ? f6[index] : f12[index], 6 * sizeof(int32_t));
+    return n;
 }
 
 int eds_trk_get_strips_info(eds_trk* h, int64_t* bytes, int32_t* row_phases, int32_t* unavailable) {

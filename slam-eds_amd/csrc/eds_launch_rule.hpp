@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <initializer_list>
+
 #define EDS_RULE_TEAM6_MAX 16          // = EDS_TEAM6_MAX (eds_fused.hpp; static_assert there)
 #define EDS_RULE_TEAM_SLOTS 128        // = EDS_TEAM_SLOTS
 #define EDS_RULE_TEAM12_SLOTS 64       // = EDS_TEAM12_SLOTS
@@ -47,41 +49,66 @@ struct EdsKnobs {
     int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
     int reduce_ppl = 4;         // EDS_REDUCE_PPL      4 | 8: points a lane of eds_reduce_kernel<6> folds (16-byte loads)
     int upload_threads = 0;     // EDS_UPLOAD_THREADS  1 .. 64: host threads that narrow the frames of eds_trk_set_event_frames   0: the rule (4)
+    int force6_set = 0, force6[6] = {0, 0, 0, 0, 0, 0};        // EDS_FORCE_FUSED6   "S,P,T,Q,K,G": launch exactly this instantiation of eds_fused6_kernel
+    int force12_set = 0, force12[6] = {0, 0, 0, 0, 0, 0};      // EDS_FORCE_FUSED12  "S,T,CAP,NC,K,Q": ... of eds_fused12_kernel.  Test hooks (tests/test_instances_gpu.py
+                                                               // walks the compiled lists with them); honoured only where the instantiation exists and fits the range
     int upload_streams = 0;     // EDS_UPLOAD_STREAMS  1: the batch upload keeps to the handle's stream (default: alternate frames on a second one)
     int upload_dma = 0;         // EDS_UPLOAD_DMA      1: the batch upload moves the staged frames with the copy engine (hipMemcpyAsync) instead of kernels reading pinned memory
     int lm6_groups = 0;         // EDS_LM6_GROUPS      1 | 2 | 4 | 8: candidate groups of a team launch (eds_fused.hip)   0: the rule
 };
 
-// returns 0, or -1 for a name that is not a knob.  value == nullptr or "" resets the knob to its default.
+// returns 0, -1 for a name that is not a knob, -2 for a value the knob does not take (nothing is changed then).  value == nullptr or ""
+// resets the knob to its default.  (Round 5, ADVICE r4: values used to be coerced silently — EDS_REDUCE_PPL=abc became 4.)
 static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value) {
     const EdsKnobs d;
     const bool unset = !value || !value[0];
-    const int iv = unset ? 0 : atoi(value);
     auto is = [&](const char* w) { return !unset && strcmp(value, w) == 0; };
-    if (!strcmp(name, "EDS_REF12_EXEC")) k->ref12_exec = unset ? d.ref12_exec : (is("device") ? 1 : 0);
-    else if (!strcmp(name, "EDS_FUSED_THREADS")) k->fused_threads = unset ? 0 : iv;
-    else if (!strcmp(name, "EDS_FUSED_PPT")) { k->fused_ppt_set = unset ? 0 : 1; k->fused_ppt = iv; }
-    else if (!strcmp(name, "EDS_LM6_SPEC")) k->lm6_spec = unset ? 1 : (value[0] == '0' ? 0 : 1);
-    else if (!strcmp(name, "EDS_LM6_KERNEL")) k->lm6_kernel = unset ? 0 : (is("wide") ? 3 : ((is("paired") || is("stream")) ? 2 : 1));
-    else if (!strcmp(name, "EDS_FUSED_LAYOUT")) k->layout_tiles = is("tiles") ? 1 : 0;
-    else if (!strcmp(name, "EDS_TEAM_TEST_DROP_MEMBER")) k->team_drop = unset ? 0 : 1;
-    else if (!strcmp(name, "EDS_LM6_TEAM")) k->lm6_team = unset ? 0 : iv;
-    else if (!strcmp(name, "EDS_TEAM_WIDE")) k->team_wide = unset ? -1 : (iv != 0);
-    else if (!strcmp(name, "EDS_FUSED_GATHER")) k->gather = unset ? 0 : (is("lane") ? 2 : 1);
-    else if (!strcmp(name, "EDS_FUSED_REPORT")) k->report = unset ? 0 : 1;
-    else if (!strcmp(name, "EDS_REF12_KERNEL")) k->ref12_kernel = is("wide") ? 1 : (is("paired") ? 2 : 0);
-    else if (!strcmp(name, "EDS_REF12_TEAM")) k->ref12_team = unset ? 0 : iv;
-    else if (!strcmp(name, "EDS_STRIPS_PHASES")) k->strips_phases = (iv == 1 || iv == 2 || iv == 4) ? iv : 0;
-    else if (!strcmp(name, "EDS_STRIPS_POLICY")) k->strips_policy = is("eager") ? 1 : (is("never") ? 2 : 0);
-    else if (!strcmp(name, "EDS_STRIPS_BUDGET_PCT")) k->strips_budget_pct = (iv >= 1 && iv <= 95) ? iv : d.strips_budget_pct;
-    else if (!strcmp(name, "EDS_NO_SPIN")) k->no_spin = unset ? 0 : 1;
-    else if (!strcmp(name, "EDS_UPLOAD")) k->upload_bands = is("bands") ? 1 : 0;
-    else if (!strcmp(name, "EDS_FRAME_LAYOUT")) k->frame_rowmajor = is("rowmajor") ? 1 : 0;
-    else if (!strcmp(name, "EDS_REDUCE_PPL")) k->reduce_ppl = iv == 8 ? 8 : 4;
-    else if (!strcmp(name, "EDS_LM6_GROUPS")) k->lm6_groups = unset ? 0 : iv;
-    else if (!strcmp(name, "EDS_UPLOAD_STREAMS")) k->upload_streams = unset ? 0 : (iv == 1 ? 1 : 0);
-    else if (!strcmp(name, "EDS_UPLOAD_DMA")) k->upload_dma = unset ? 0 : (value[0] != '0');
-    else if (!strcmp(name, "EDS_UPLOAD_THREADS")) k->upload_threads = (iv >= 1 && iv <= 64) ? iv : 0;
+    // a whole decimal integer, or "not a number"
+    bool num = false; long iv = 0;
+    if (!unset) { char* e = nullptr; iv = strtol(value, &e, 10); num = e != value && *e == 0; }
+    auto one_of = [&](std::initializer_list<long> ok) { if (!num) return false; for (long v : ok) if (v == iv) return true; return false; };
+    auto flag = [&](int* dst, int dflt) { if (unset) { *dst = dflt; return 0; } if (!one_of({0, 1})) return -2; *dst = (int)iv; return 0; };
+    if (!strcmp(name, "EDS_REF12_EXEC")) { if (unset) k->ref12_exec = d.ref12_exec; else if (is("device")) k->ref12_exec = 1; else if (is("host")) k->ref12_exec = 0; else return -2; }
+    else if (!strcmp(name, "EDS_FUSED_THREADS")) { if (unset) k->fused_threads = 0; else if (num && iv >= 64 && iv <= 1024 && iv % 64 == 0) k->fused_threads = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_FUSED_PPT")) { if (unset) { k->fused_ppt_set = 0; k->fused_ppt = 0; } else if (num && iv >= 0 && iv <= 64) { k->fused_ppt_set = 1; k->fused_ppt = (int)iv; } else return -2; }
+    else if (!strcmp(name, "EDS_LM6_SPEC")) return flag(&k->lm6_spec, 1);
+    else if (!strcmp(name, "EDS_LM6_KERNEL")) { if (unset) k->lm6_kernel = 0; else if (is("wide")) k->lm6_kernel = 3; else if (is("paired") || is("stream")) k->lm6_kernel = 2; else if (is("resident")) k->lm6_kernel = 1; else return -2; }
+    else if (!strcmp(name, "EDS_FUSED_LAYOUT")) { if (unset || is("strips")) k->layout_tiles = 0; else if (is("tiles")) k->layout_tiles = 1; else return -2; }
+    else if (!strcmp(name, "EDS_TEAM_TEST_DROP_MEMBER")) return flag(&k->team_drop, 0);
+    else if (!strcmp(name, "EDS_LM6_TEAM")) { if (unset) k->lm6_team = 0; else if (one_of({1, 2, 4, 8, 16})) k->lm6_team = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_TEAM_WIDE")) return flag(&k->team_wide, -1);
+    else if (!strcmp(name, "EDS_FUSED_GATHER")) { if (unset) k->gather = 0; else if (is("lane")) k->gather = 2; else if (is("quad")) k->gather = 1; else return -2; }
+    else if (!strcmp(name, "EDS_FUSED_REPORT")) return flag(&k->report, 0);
+    else if (!strcmp(name, "EDS_REF12_KERNEL")) { if (unset) k->ref12_kernel = 0; else if (is("wide")) k->ref12_kernel = 1; else if (is("paired")) k->ref12_kernel = 2; else return -2; }
+    else if (!strcmp(name, "EDS_REF12_TEAM")) { if (unset) k->ref12_team = 0; else if (one_of({1, 2, 4, 8, 16})) k->ref12_team = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_STRIPS_PHASES")) { if (unset) k->strips_phases = 0; else if (one_of({1, 2, 4})) k->strips_phases = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_STRIPS_POLICY")) { if (unset || is("reuse")) k->strips_policy = 0; else if (is("eager")) k->strips_policy = 1; else if (is("never")) k->strips_policy = 2; else return -2; }
+    else if (!strcmp(name, "EDS_STRIPS_BUDGET_PCT")) { if (unset) k->strips_budget_pct = d.strips_budget_pct; else if (num && iv >= 1 && iv <= 95) k->strips_budget_pct = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_NO_SPIN")) return flag(&k->no_spin, 0);
+    else if (!strcmp(name, "EDS_UPLOAD")) { if (unset) k->upload_bands = 0; else if (is("bands")) k->upload_bands = 1; else return -2; }
+    else if (!strcmp(name, "EDS_FRAME_LAYOUT")) { if (unset || is("tiles")) k->frame_rowmajor = 0; else if (is("rowmajor")) k->frame_rowmajor = 1; else return -2; }
+    else if (!strcmp(name, "EDS_REDUCE_PPL")) { if (unset) k->reduce_ppl = 4; else if (one_of({4, 8})) k->reduce_ppl = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_LM6_GROUPS")) { if (unset) k->lm6_groups = 0; else if (one_of({1, 2, 4, 8})) k->lm6_groups = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_UPLOAD_THREADS")) { if (unset) k->upload_threads = 0; else if (num && iv >= 1 && iv <= 64) k->upload_threads = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_UPLOAD_DMA")) return flag(&k->upload_dma, 0);
+    else if (!strcmp(name, "EDS_UPLOAD_STREAMS")) { if (unset) k->upload_streams = 0; else if (one_of({1, 2})) k->upload_streams = iv == 1 ? 1 : 0; else return -2; }
+    else if (!strcmp(name, "EDS_FORCE_FUSED6") || !strcmp(name, "EDS_FORCE_FUSED12")) {
+        int* dst = name[15] == '6' ? k->force6 : k->force12;
+        int* set = name[15] == '6' ? &k->force6_set : &k->force12_set;
+        if (unset) { *set = 0; return 0; }
+        int v[6], n = 0;
+        const char* c = value;
+        while (n < 6) {
+            char* e = nullptr;
+            v[n] = (int)strtol(c, &e, 10);
+            if (e == c) break;
+            ++n; c = e;
+            if (*c == ',') ++c; else break;
+        }
+        if (n != 6 || *c) return -2;                    // not six integers
+        for (int i = 0; i < 6; ++i) dst[i] = v[i];
+        *set = 1;
+    }
     else return -1;
     return 0;
 }
@@ -90,7 +117,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS")
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12")
 
 // the process environment, read once per handle (eds_trk_create)
 static inline void eds_knobs_from_env(EdsKnobs* k) {
@@ -128,6 +155,12 @@ struct EdsLm6Plan {
     int wide_members;       // teams with members of 2 048 points
     int note_T;             // the T eds_trk_last_launch prints (the lane kernel of the bilinear sampler prints the block size)
 };
+
+static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G);
+static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q);
+struct EdsRef12In;
+static inline bool eds_lm6_force_feasible(const EdsKnobs& kn, const EdsLm6In& in, const EdsLm6Plan& p);
+static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In& in);
 
 static inline void eds_lm6_plan_begin(const EdsKnobs& kn, const EdsLm6In& in, EdsLm6Plan& p) {
     memset(&p, 0, sizeof(p));
@@ -169,6 +202,7 @@ static inline void eds_lm6_plan_team(const EdsKnobs& kn, const EdsLm6In& in, int
     }
     if (team > 1) { p.stream = 0; p.wide = 0; }
     p.team = team;
+    if (kn.force6_set && kn.force6[3] >= 3 && eds_lm6_force_feasible(kn, in, p)) { p.strips_eligible = 1; return; }      // (the launcher then asks for the copies)
     const bool want_strips = !kn.layout_tiles;
     if (team > 1) {
         p.qany = in.count * team >= 128 && in.H < 8000;              // enough gathers in flight for the quad-cooperative form to pay
@@ -183,9 +217,34 @@ static inline void eds_lm6_plan_team(const EdsKnobs& kn, const EdsLm6In& in, int
     }
 }
 
+// EDS_FORCE_FUSED6: is the forced instantiation one the library holds AND one that can solve this range?  (sampler and Huber variant are
+// the configuration's, every point needs a lane slot, teams need prepared-candidate LM6, the quad gather its 13-bit row field)
+static inline bool eds_lm6_force_feasible(const EdsKnobs& kn, const EdsLm6In& in, const EdsLm6Plan& p) {
+    if (!kn.force6_set) return false;
+    const int S = kn.force6[0], P = kn.force6[1], T = kn.force6[2], Q = kn.force6[3], K = kn.force6[4], G = kn.force6[5];
+    const int btu = (S == 1 && Q == 0) ? 1 : 0;
+    if (G < 1 || K < 1 || !eds_fused6_instance_exists(S, P, T, Q, K, btu, G)) return false;
+    if (S != (in.bicubic ? 0 : 1)) return false;
+    if ((Q == 2 || Q == 4) != (in.huber != 0) && Q != 0) return false;            // Q = 0 takes the threshold at run time
+    if (P > 0 && (long long)P * (K > 1 ? 512 : T) * K < in.maxN) return false;
+    if (K > 1 && (p.damped != 1 || in.iters <= 0 || in.retry)) return false;
+    if (K > 1 && (long long)in.count * K * G > EDS_RULE_TEAM_MEMBERS && G > 1) return false;
+    if (Q != 0 && in.H >= 8000) return false;
+    return true;
+}
+
 // strips: the copies of the range are current (asked only when strips_eligible)
 static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, int strips, EdsLm6Plan& p) {
     strips = strips && p.strips_eligible;
+    if (eds_lm6_force_feasible(kn, in, p) && (kn.force6[3] < 3 || strips)) {      // the strip instantiations only on current copies
+        const int S = kn.force6[0], P = kn.force6[1], T = kn.force6[2], Q = kn.force6[3], K = kn.force6[4], G = kn.force6[5];
+        p.kind = K > 1 ? EDS_K6_TEAM : EDS_K6_FUSED;
+        p.S = S; p.P = P; p.T = T; p.Q = Q; p.K = K; p.G = G; p.team = K; p.stream = 0; p.wide = 0;
+        p.bilinear_tu = (S == 1 && Q == 0) ? 1 : 0; p.wide_members = (K > 1 && P == 4) ? 1 : 0;
+        if (K == 1) p.threads = T;
+        p.note_T = T;
+        return;
+    }
     const int bic = in.bicubic, hub = in.huber;
     p.bilinear_tu = 0; p.wide_members = 0;
     if (p.team > 1) {
@@ -277,7 +336,7 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
 #define EDS_FUSED6_BILINEAR_GROUP_INSTANCES(X)                                                                                        \
     X(1, 1, 512, 0, 4, 2) X(1, 1, 512, 0, 4, 4) X(1, 1, 512, 0, 4, 8)
 
-static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G = 1) {
+static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G) {
 #define EDS_INST_EQ_(s, p, t, q, k) if (S == s && P == p && T == t && Q == q && K == k) return true;
 #define EDS_INST_EQ6_(s, p, t, q, k, g) if (S == s && P == p && T == t && Q == q && K == k && G == g) return true;
     if (G > 1) {
@@ -331,6 +390,12 @@ static inline void eds_ref12_plan_team(const EdsKnobs& kn, const EdsRef12In& in,
         if (v == 1 || ((v == 2 || v == 4 || v == 8 || v == 16) && p.wide && !in.nc && in.count <= EDS_RULE_TEAM12_SLOTS &&
                        in.count * v <= EDS_RULE_TEAM12_MEMBERS && !in.retry && !cooldown_active)) team = v;
     }
+    if (eds_ref12_force_feasible(kn, in) && (kn.force12[4] == 1 || (team_ok && !cooldown_active) || kn.force12[4] == team)) {
+        p.team = kn.force12[4];
+        p.quad = kn.force12[5] != 0;
+        p.strips_eligible = kn.force12[5] == 2;
+        return;
+    }
     p.team = team;
     // the quad-cooperative gather pays once the gather, not the instruction stream, bounds the point phase: on the tiles from 1 024
     // alignments, on the strips (one load per row, no shift) from 64
@@ -343,8 +408,22 @@ static inline void eds_ref12_plan_team(const EdsKnobs& kn, const EdsRef12In& in,
     p.strips_eligible = quad && want_strips && team <= 4;
 }
 
+static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In& in) {
+    if (!kn.force12_set) return false;
+    const int S = kn.force12[0], T = kn.force12[1], CAP = kn.force12[2], NC = kn.force12[3], K = kn.force12[4], Q = kn.force12[5];
+    if (K < 1 || !eds_fused12_instance_exists(S, T, CAP, NC, K, Q)) return false;
+    if (S != (in.bicubic ? 0 : 1) || (NC != 0) != (in.nc != 0)) return false;
+    if (K > 1 && (in.nc || in.retry || in.count > EDS_RULE_TEAM12_SLOTS || in.count * K > EDS_RULE_TEAM12_MEMBERS)) return false;
+    if (Q != 0 && in.H >= 8000) return false;
+    return true;
+}
+
 static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& in, int strips, EdsRef12Plan& p) {
     strips = strips && p.strips_eligible;
+    if (eds_ref12_force_feasible(kn, in) && (kn.force12[5] != 2 || strips) && p.team == kn.force12[4]) {
+        p.S = kn.force12[0]; p.T = kn.force12[1]; p.CAP = kn.force12[2]; p.NC = kn.force12[3]; p.K = kn.force12[4]; p.Q = kn.force12[5];
+        return;
+    }
     const bool want_strips = !in.nc && !kn.layout_tiles;
     bool quad = p.quad;
     if (want_strips && !strips && in.count < 1024) quad = false;     // (no copies to read: the tiles' rule)

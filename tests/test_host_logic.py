@@ -288,10 +288,35 @@ def test_launch_rule_pose_only_table(hl):
     # (G x 4 x count <= 128), two while all workgroups of the launch still get a CU of their own; members of 512 points only; the
     # knob overrides, 1 switches them off
     assert [_lm6(hl, count=c)["G"] for c in (1, 4, 5, 8, 9, 16, 17, 32, 33, 64)] == [8, 8, 4, 4, 2, 2, 2, 2, 1, 1]
-    assert _lm6(hl, "EDS_LM6_GROUPS=1", count=1)["G"] == 1 and _lm6(hl, "EDS_LM6_GROUPS=2", count=1)["G"] == 2 and _lm6(hl, "EDS_LM6_GROUPS=3", count=1)["G"] == 8
+    assert _lm6(hl, "EDS_LM6_GROUPS=1", count=1)["G"] == 1 and _lm6(hl, "EDS_LM6_GROUPS=2", count=1)["G"] == 2 and _lm6(hl, "EDS_LM6_GROUPS=8", count=16)["G"] == 8
     assert _lm6(hl, count=1, bicubic=0)["G"] == 8 and _lm6(hl, count=32)["Q"] == 1 and _lm6(hl, count=32)["exists"]
     assert _lm6(hl, maxN=8000, count=1, H=720)["G"] == 1 and _lm6(hl, "EDS_LM6_TEAM=2", count=4)["G"] == 1 and _lm6(hl, count=129)["G"] == 1
     assert _lm6(hl, count=1, flags=RETRY | TEAM_OK | STRIPS)["G"] == 1 and _lm6(hl, count=4, flags=COOLDOWN | STRIPS)["G"] == 1
+
+
+def test_launch_rule_force_knobs(hl):
+    """EDS_FORCE_FUSED6 / EDS_FORCE_FUSED12 (test hooks of tests/test_instances_gpu.py): honoured where the instantiation exists and can solve
+    the range, ignored (the rule stands) where not."""
+    FUSED, TEAM = 0, 1
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,2,1024,1,1,1", maxN=2000, count=8)) == (FUSED, 0, 2, 1024, 1, 1)
+    assert _lm6(hl, "EDS_FORCE_FUSED6=0,2,1024,1,1,1", maxN=2000, count=8)["threads"] == 1024
+    d = _lm6(hl, "EDS_FORCE_FUSED6=0,2,512,3,16,1", maxN=16000, count=2)
+    assert _k6(d) == (TEAM, 0, 2, 512, 3, 16) and d["G"] == 1 and d["strips_eligible"]
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,2,512,3,16,1", maxN=16000, count=2, flags=TEAM_OK)) != (TEAM, 0, 2, 512, 3, 16)       # no current copies: the rule stands
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,1,512,0,4,8", maxN=2000, count=2))[5] == 4 and _lm6(hl, "EDS_FORCE_FUSED6=0,1,512,0,4,8", maxN=2000, count=2)["G"] == 8
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,2,512,1,1,1", maxN=2000, count=8)) != (FUSED, 0, 2, 512, 1, 1)                       # 1 024 lane slots for 2 000 points
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=1,4,512,3,1,1", maxN=2000, count=8)) != (FUSED, 1, 4, 512, 3, 1)                       # the other sampler
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,4,512,4,1,1", maxN=2000, count=8)) != (FUSED, 0, 4, 512, 4, 1)                       # the Huber variant without a threshold
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,4,512,4,1,1", maxN=2000, count=8, huber=1)) == (FUSED, 0, 4, 512, 4, 1)
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,3,512,1,1,1", maxN=1000, count=8)) == _k6(_lm6(hl, maxN=1000, count=8))                # not compiled: ignored
+    assert _k6(_lm6(hl, "EDS_FORCE_FUSED6=0,1,512,0,4,1", maxN=2000, count=2, lm6=0))[0] == FUSED                                # teams need the damped solver
+    K = lambda d: (d["S"], d["T"], d["CAP"], d["NC"], d["K"], d["Q"])
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,256,320,0,1,0", count=4)) == (0, 256, 320, 0, 1, 0)
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,0,16,0", count=4)) == (0, 512, 1408, 0, 16, 0)
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,0,4,2", count=4)) == (0, 512, 1408, 0, 4, 2) and K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,0,4,2", count=4, flags=TEAM_OK)) != (0, 512, 1408, 0, 4, 2)
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,1,1,1", count=4, nc=1)) == (0, 512, 1408, 1, 1, 1) and K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,1,1,1", count=4)) != (0, 512, 1408, 1, 1, 1)
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,1408,0,8,0", count=4, flags=STRIPS)) != (0, 512, 1408, 0, 8, 0)                  # the time-out policy says no
+    assert all(_ref12(hl, f"EDS_FORCE_FUSED12={f}", count=4)["exists"] for f in ("0,256,320,0,1,2", "1,512,1408,0,2,0", "0,512,1408,0,1,7"))
 
 
 def test_launch_rule_ref12_table(hl):
@@ -344,10 +369,20 @@ def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
 
 
 def test_knob_names_and_strip_budget(hl):
-    for name in ("EDS_REF12_EXEC", "EDS_FUSED_THREADS", "EDS_FUSED_PPT", "EDS_LM6_SPEC", "EDS_LM6_KERNEL", "EDS_FUSED_LAYOUT", "EDS_TEAM_TEST_DROP_MEMBER",
-                 "EDS_LM6_TEAM", "EDS_TEAM_WIDE", "EDS_FUSED_GATHER", "EDS_FUSED_REPORT", "EDS_REF12_KERNEL", "EDS_REF12_TEAM", "EDS_STRIPS_PHASES",
-                 "EDS_STRIPS_POLICY", "EDS_STRIPS_BUDGET_PCT", "EDS_NO_SPIN", "EDS_UPLOAD", "EDS_FRAME_LAYOUT", "EDS_REDUCE_PPL"):
-        assert hl.hl_knob_set(name.encode(), b"1") == 0 and hl.hl_knob_set(name.encode(), None) == 0
+    # every knob with a value it takes and one it does not: invalid values are REFUSED (-2) instead of coerced, unknown names -1
+    table = {"EDS_REF12_EXEC": ("device", "gpu"), "EDS_FUSED_THREADS": ("256", "100"), "EDS_FUSED_PPT": ("2", "-1"), "EDS_LM6_SPEC": ("0", "yes"),
+             "EDS_LM6_KERNEL": ("paired", "fast"), "EDS_FUSED_LAYOUT": ("tiles", "rows"), "EDS_TEAM_TEST_DROP_MEMBER": ("1", "2"), "EDS_LM6_TEAM": ("4", "3"),
+             "EDS_TEAM_WIDE": ("0", "wide"), "EDS_FUSED_GATHER": ("lane", "1"), "EDS_FUSED_REPORT": ("1", "on"), "EDS_REF12_KERNEL": ("wide", "1"),
+             "EDS_REF12_TEAM": ("8", "5"), "EDS_STRIPS_PHASES": ("2", "3"), "EDS_STRIPS_POLICY": ("never", "always"), "EDS_STRIPS_BUDGET_PCT": ("30", "0"),
+             "EDS_NO_SPIN": ("1", "x"), "EDS_UPLOAD": ("bands", "1"), "EDS_FRAME_LAYOUT": ("rowmajor", "1"), "EDS_REDUCE_PPL": ("8", "abc"),
+             "EDS_LM6_GROUPS": ("4", "3"), "EDS_UPLOAD_THREADS": ("6", "0"), "EDS_UPLOAD_DMA": ("1", "2"), "EDS_UPLOAD_STREAMS": ("1", "3"),
+             "EDS_FORCE_FUSED6": ("0,4,512,3,1,1", "0,4,512"), "EDS_FORCE_FUSED12": ("0,256,320,0,1,2", "a,b")}
+    for name, (good, bad) in table.items():
+        assert hl.hl_knob_set(name.encode(), good.encode()) == 0, name
+        assert hl.hl_knob_set(name.encode(), bad.encode()) == -2, name
+        assert hl.hl_knob_set(name.encode(), None) == 0 and hl.hl_knob_set(name.encode(), b"") == 0
+    names = open(os.path.join(HERE, "..", "slam-eds_amd", "csrc", "eds_launch_rule.hpp")).read().split("#define EDS_KNOB_NAMES(X)")[1].split("\n\n")[0]
+    assert sorted(table) == sorted(set(__import__("re").findall(r'X\("(EDS_[A-Z0-9_]+)"\)', names)))      # the table above covers every knob the library has
     assert hl.hl_knob_set(b"EDS_NO_SUCH_KNOB", b"1") == -1
     f = hl.hl_strips_phases_for_budget
     f.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]

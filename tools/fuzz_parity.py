@@ -167,3 +167,4 @@ for c in range(cases):
                 else:
                     print(tag, f"tau={tau}: default path differs from the oracle by {from_dev:.2e}"); bad += 1
 print(f"{cases} cases ({stats}), {bad} disagreements" + (f", {chaotic} differences on ill-conditioned cases (the oracle itself moves as much)" if chaotic else ""))
+sys.exit(1 if bad else 0)

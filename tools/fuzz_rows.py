@@ -101,3 +101,4 @@ for c in range(cases):
         print(tag, f"update_points N={N}: coord diff {np.abs(out['coord'] - refp['coord']).max():.2e}"); bad += 1
     h.close()
 print(f"{cases} cases, {bad} disagreements")
+sys.exit(1 if bad else 0)
