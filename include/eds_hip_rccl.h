@@ -13,7 +13,9 @@
  * The communicator is the CALLER's (ncclCommInitRank / ncclCommInitAll: the component that owns the process layout owns the
  * rendezvous) and is passed as an opaque pointer, as is the stream the collective is queued on (hipStream_t; NULL: a stream the
  * context creates for itself).  Plain pointers and sizes otherwise; every function returns 0 or a negative eds_status-like code
- * (-1 invalid argument, -2 HIP or RCCL failure: eds_gather_last_error()).
+ * (-1 invalid argument, -2 HIP or RCCL failure: eds_gather_last_error()).  The calling thread's current HIP device is left as it was
+ * found: every call runs on the communicator's device and restores the caller's.  A start that fails after it has queued work drains
+ * its stream before it returns, so the context can be started again (or destroyed) safely.
  */
 #ifndef EDS_HIP_RCCL_H_
 #define EDS_HIP_RCCL_H_
@@ -32,6 +34,10 @@ const char* eds_gather_last_error(void);    /* thread-local message of the last 
 
 /* contiguous shard [first, first + count) of `total` alignments for `rank` of `nranks` (the same rule everywhere: batch.py shard_range) */
 void eds_gather_shard(int total, int nranks, int rank, int* first, int* count);
+
+/* the unpack step of eds_gather_finish on its own (pure, no HIP): `gathered` = nranks blocks of ceil(total / nranks) rows, rank r's rows
+ * first and its padding behind them (what ncclAllGather leaves); table = [total][16] in alignment order */
+void eds_gather_unpack(const double* gathered, int total, int nranks, double* table);
 
 /* One-shot form (Next #3c): all-gather this rank's `count` rows (HOST memory, row-major [count][16]) into `table`
  * (HOST memory, [total][16]; every rank receives all rows, in alignment order).  nccl_comm: ncclComm_t; hip_stream: hipStream_t or

@@ -325,6 +325,11 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                             __builtin_amdgcn_global_load_lds((glb_ptr)(sbase + ((unsigned)oq[q] + row_add)), (lds_ptr)(zone + (4 * j + q) * ZSLOT), 16, 0, 0);
                         if (EDS_GATHER_STAGES > 1) nld[j] += __ballot(need) != 0ull ? 1 : 0;
                     }
+                    // The counted waits below rely on the row loads being ISSUED in point order (loads return in order: "at most n
+                    // outstanding" then means the earlier points' rows have landed).  Today that order follows from the M0 dependency
+                    // chain of global_load_lds; this barrier pins it in the source as well — no load of point j + 1 may be
+                    // moved in front of a load of point j.  tests/test_gather_stages_gpu.py compares against an EDS_GATHER_STAGES=1 build.
+                    asm volatile("" ::: "memory");
                 }
             }
             // Loads return in order, so "at most n outstanding" with n = the loads issued for LATER points means this point's rows have

@@ -16,7 +16,17 @@ thread_local std::string g_err;
 int fail(int code, const std::string& m) { g_err = m; return code; }
 }  // namespace
 
+// the caller's current device is left as it was found: every entry point that touches HIP runs on the communicator's device inside
+// one of these (a one-process, many-GPU caller — ncclCommInitAll — has a different device current for every context)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; ok = hipSetDevice(dev) == hipSuccess; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct eds_gather {
+    int dev = 0;
     ncclComm_t comm = nullptr;
     hipStream_t st = nullptr;
     bool own_stream = false;
@@ -39,9 +49,22 @@ void eds_gather_shard(int total, int nranks, int rank, int* first, int* count) {
     if (count) *count = c;
 }
 
+// Pure: rank r's padded block of `per` rows inside the gathered buffer -> its rows [first, first + count) of the table.  (Table-tested
+// on the CPU for ragged totals and worlds of 2, 3, 8: tests/test_gather_capi.py through eds_gather_unpack.)
+void eds_gather_unpack(const double* gathered, int total, int nranks, double* table) {
+    if (nranks < 1) nranks = 1;
+    const int per = (total + nranks - 1) / nranks;
+    for (int r = 0; r < nranks; ++r) {
+        int first = 0, cnt = 0;
+        eds_gather_shard(total, nranks, r, &first, &cnt);
+        if (cnt > 0) std::memcpy(table + (size_t)first * EDS_GATHER_ROW, gathered + (size_t)r * per * EDS_GATHER_ROW, sizeof(double) * EDS_GATHER_ROW * (size_t)cnt);
+    }
+}
+
 void eds_gather_destroy(eds_gather* g) {
     if (!g) return;
-    if (g->pending && g->ev) (void)hipEventSynchronize(g->ev);
+    DeviceGuard guard(g->dev);
+    if (g->st) (void)hipStreamSynchronize(g->st);        // whatever was queued (also by a start that failed half-way) is done with the buffers
     if (g->d_in) (void)hipFree(g->d_in);
     if (g->d_out) (void)hipFree(g->d_out);
     if (g->h_in) (void)hipHostFree(g->h_in);
@@ -62,7 +85,9 @@ int eds_gather_create(void* nccl_comm, void* hip_stream, int total, eds_gather**
     if (ncclCommCount(g->comm, &g->nranks) != ncclSuccess || ncclCommUserRank(g->comm, &g->rank) != ncclSuccess || ncclCommCuDevice(g->comm, &dev) != ncclSuccess) {
         delete g; return fail(-2, "the communicator does not answer (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)");
     }
-    if (hipSetDevice(dev) != hipSuccess) { delete g; return fail(-2, "hipSetDevice(communicator's device) failed"); }
+    g->dev = dev;
+    DeviceGuard guard(dev);
+    if (!guard.ok) { delete g; return fail(-2, "hipSetDevice(communicator's device) failed"); }
     g->per = (total + g->nranks - 1) / g->nranks;
     const size_t in_b = sizeof(double) * EDS_GATHER_ROW * (size_t)(g->per > 0 ? g->per : 1), out_b = in_b * (size_t)g->nranks;
     hipError_t e = hipSuccess;
@@ -90,13 +115,18 @@ int eds_gather_start(eds_gather* g, const double* local, int count) {
     const size_t row = sizeof(double) * EDS_GATHER_ROW;
     if (count > 0) std::memcpy(g->h_in, local, row * (size_t)count);
     if (count < g->per) std::memset(reinterpret_cast<char*>(g->h_in) + row * (size_t)count, 0, row * (size_t)(g->per - count));     // ragged last shard: padded
+    DeviceGuard guard(g->dev);
+    if (!guard.ok) return fail(-2, "eds_gather_start: hipSetDevice(communicator's device) failed");
+    // From the first enqueue on, a failure must not leave work in flight over buffers the next start would overwrite:
+    // the stream is drained before the error is reported.
+    auto bail = [&](const std::string& m) { (void)hipStreamSynchronize(g->st); return fail(-2, m); };
     hipError_t e = hipMemcpyAsync(g->d_in, g->h_in, row * (size_t)g->per, hipMemcpyHostToDevice, g->st);
-    if (e != hipSuccess) return fail(-2, std::string("eds_gather_start: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return bail(std::string("eds_gather_start: ") + hipGetErrorString(e));
     const ncclResult_t r = ncclAllGather(g->d_in, g->d_out, (size_t)g->per * EDS_GATHER_ROW, ncclDouble, g->comm, g->st);
-    if (r != ncclSuccess) return fail(-2, std::string("ncclAllGather: ") + ncclGetErrorString(r));
+    if (r != ncclSuccess) return bail(std::string("ncclAllGather: ") + ncclGetErrorString(r));
     e = hipMemcpyAsync(g->h_out, g->d_out, row * (size_t)g->per * (size_t)g->nranks, hipMemcpyDeviceToHost, g->st);
     if (e == hipSuccess) e = hipEventRecord(g->ev, g->st);
-    if (e != hipSuccess) return fail(-2, std::string("eds_gather_start: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return bail(std::string("eds_gather_start: ") + hipGetErrorString(e));
     g->pending = true;
     return 0;
 }
@@ -106,15 +136,10 @@ int eds_gather_finish(eds_gather* g, double* table) {
     if (!g->pending) return fail(-1, "eds_gather_finish: nothing was started");
     g->pending = false;
     if (g->per == 0) return 0;
+    DeviceGuard guard(g->dev);
     const hipError_t e = hipEventSynchronize(g->ev);
     if (e != hipSuccess) return fail(-2, std::string("eds_gather_finish: ") + hipGetErrorString(e));
-    if (!table) return 0;
-    const size_t row = sizeof(double) * EDS_GATHER_ROW;
-    for (int r = 0; r < g->nranks; ++r) {       // rank r's padded block -> its rows of the table
-        int first = 0, cnt = 0;
-        eds_gather_shard(g->total, g->nranks, r, &first, &cnt);
-        if (cnt > 0) std::memcpy(table + (size_t)first * EDS_GATHER_ROW, g->h_out + (size_t)r * g->per * EDS_GATHER_ROW, row * (size_t)cnt);
-    }
+    if (table) eds_gather_unpack(g->h_out, g->total, g->nranks, table);
     return 0;
 }
 

@@ -39,6 +39,36 @@ def test_gather_library_exports_what_its_header_declares(capi):
     assert "librccl" in subprocess.run(["readelf", "-d", LIB], capture_output=True, text=True).stdout
 
 
+def test_gather_unpack_table_for_ragged_totals():
+    """eds_gather_finish's unpack step as a pure function (the path with more than one rank and a ragged last shard has never
+    run on hardware): for worlds of 2, 3 and 8 and totals that do not divide, the padded blocks ncclAllGather would leave come apart
+    into the table in alignment order, padding dropped, nothing else touched.  Child process: the library pulls RCCL in."""
+    code = ("import ctypes as C, json, sys\n"
+            "import numpy as np\n"
+            f"L = C.CDLL({LIB!r})\n"
+            "dp = C.POINTER(C.c_double)\n"
+            "bad = []\n"
+            "for total in (0, 1, 5, 7, 10, 64, 65, 1000):\n"
+            "    for world in (1, 2, 3, 8):\n"
+            "        per = -(-total // world)\n"
+            "        g = np.full((world, max(per, 1), 16), -7.0)\n"          # -7: padding that must never reach the table
+            "        for r in range(world):\n"
+            "            f, c = C.c_int(), C.c_int()\n"
+            "            L.eds_gather_shard(total, world, r, C.byref(f), C.byref(c))\n"
+            "            for i in range(c.value):\n"
+            "                g[r, i, :] = 1000.0 * (f.value + i) + np.arange(16)\n"
+            "        t = np.full((total + 1, 16), -1.0)\n"                  # one row of slack behind the table: must stay untouched
+            "        L.eds_gather_unpack(g.ctypes.data_as(dp), total, world, t.ctypes.data_as(dp))\n"
+            "        want = 1000.0 * np.arange(total)[:, None] + np.arange(16)[None, :]\n"
+            "        if not (np.array_equal(t[:total], want) and np.all(t[total] == -1.0)):\n"
+            "            bad.append([total, world])\n"
+            "print('UNPACK ' + json.dumps(bad))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    line = [l for l in r.stdout.splitlines() if l.startswith("UNPACK ")]
+    assert r.returncode == 0 and line, r.stderr[-2000:]
+    assert json.loads(line[0][7:]) == []
+
+
 def test_gather_shard_rule_is_batch_py_s(capi):
     """eds_gather_shard (C) == batch.shard_range (Python): one partition rule on both sides of the boundary.  Loaded in a child process
     (the library pulls RCCL in)."""

@@ -1,0 +1,61 @@
+"""The counted waits of the strip kernels (csrc/eds_fused.hip: the lane's points are consumed in two groups, each behind
+`s_waitcnt vmcnt(n)` with n = the row loads issued for the LATER group) are correct only if the row loads are issued in point order.
+ADVICE r4 asked for a required A/B: the same solves through a build with ONE wait for all rows (EDS_GATHER_STAGES=1,
+csrc/libeds_hip_stages1.so) must give bit-identical tables, residuals and traces — first solves after the copies are made and
+warm-started re-solves (where most points skip their loads: the cache-hit path changes how many loads are in flight)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "slam-eds_amd", "csrc")
+
+CHILD = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+capi = importlib.import_module("slam-eds_amd.capi"); synth = importlib.import_module("slam-eds_amd.synth")
+out = {}
+for name, samp, N, B, tau in (("bicubic_p4", capi.SAMPLE_BICUBIC, 2000, 70, 0.0), ("bicubic_p2_huber", capi.SAMPLE_BICUBIC, 900, 40, 0.004), ("bilinear_p4", capi.SAMPLE_BILINEAR, 1900, 48, 0.0)):
+    als = [synth.make_alignment(8100 + i, H=240, W=320, N=N) for i in range(5)]
+    h = capi.Handle(capi.default_config(sampling=samp, solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10, huber_tau=tau), B, N, 240, 320)
+    for b in range(B):
+        h.set_alignment(b, als[b % 5])
+    h.prepare_frames(0, B)
+    P = np.stack([als[b % 5].p0 for b in range(B)]); Q = np.stack([als[b % 5].q0 for b in range(B)]); V = np.stack([als[b % 5].v0 for b in range(B)])
+    h.set_states(0, P, Q, V); h.optimize_batch(0, 0, B)
+    t1 = h.results(0, B).copy(); k1 = h.last_launch()["kernel"]
+    r1 = np.stack([h.residuals(b) for b in range(5)]); c1 = np.stack([h.trace(b)["costs"] for b in range(5)])
+    h.set_states(0, t1[:, 0:3].copy(), t1[:, 3:7].copy(), V); h.optimize_batch(0, 0, B)       # warm start: small steps, most patches stay cached
+    t2 = h.results(0, B).copy(); r2 = np.stack([h.residuals(b) for b in range(5)])
+    out[name] = dict(kernel=k1, t1=t1, r1=r1, c1=c1, t2=t2, r2=r2)
+    h.close()
+np.savez(sys.argv[2], **{f"{k}_{kk}": vv for k, v in out.items() for kk, vv in v.items() if kk != "kernel"})
+print("KERNELS " + " | ".join(v["kernel"] for v in out.values()))
+'''
+
+
+def _run(lib, path):
+    env = dict(os.environ)
+    if lib:
+        env["EDS_HIP_LIB"] = lib
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, path], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [l for l in r.stdout.splitlines() if l.startswith("KERNELS ")][0]
+
+
+def test_counted_waits_equal_one_wait_bit_for_bit(gpu, capi, tmp_path):
+    ab = os.path.join(CSRC, "libeds_hip_stages1.so")
+    assert os.path.exists(ab), "csrc/libeds_hip_stages1.so is built by __graft_entry__.build() (make libeds_hip_stages1.so)"
+    ka = _run(None, str(tmp_path / "a.npz"))
+    kb = _run(ab, str(tmp_path / "b.npz"))
+    assert ka == kb and "eds_fused6_kernel<0, 4, 512, 3, 1>" in ka and "eds_fused6_kernel<0, 2, 512, 4, 1>" in ka and "eds_fused6_kernel<1, 4, 512, 3, 1>" in ka, (ka, kb)
+    a, b = np.load(str(tmp_path / "a.npz")), np.load(str(tmp_path / "b.npz"))
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 15
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
