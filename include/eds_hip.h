@@ -431,13 +431,14 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
  * EDS_STRIPS_BUDGET_PCT=1..95 (share of the FREE device memory the strip copies may take when they are first allocated; default 50),
  * EDS_REDUCE_PPL=4|8 (points a lane of the 6-column reduction folds: measured equal), EDS_NO_SPIN, EDS_UPLOAD=bands, EDS_FUSED_REPORT,
  * EDS_TEAM_TEST_DROP_MEMBER (test hook); round 5: EDS_LM6_GROUPS=1|2|4|8 (candidate groups of the team kernel), EDS_UPLOAD_THREADS=1..64,
- * EDS_UPLOAD_DMA=0|1, EDS_UPLOAD_STREAMS=1|2 (eds_trk_set_event_frames), EDS_FORCE_FUSED6 / EDS_FORCE_FUSED12 (below).
+ * EDS_REF12_GROUPS=1|2|4 (the same for the REF12 team kernel), EDS_UPLOAD_DMA=0|1, EDS_UPLOAD_STREAMS=1|2 (eds_trk_set_event_frames), EDS_FORCE_FUSED6 / EDS_FORCE_FUSED12 (below).
  * EDS_FRAME_LAYOUT=rowmajor decides the allocation and is honoured at create only (EDS_ERR_STATE here).  Unknown name, or a value the
  * knob does not take: EDS_ERR_INVALID (nothing changes).  While a batch is in flight (eds_trk_optimize_batch without wait): EDS_ERR_STATE.
  * An EDS_STRIPS_PHASES / EDS_STRIPS_BUDGET_PCT change frees the strip copies: the next solve that wants them allocates them anew. */
 int eds_trk_set_knob(eds_trk* h, const char* name, const char* value);
 /* ABI 5.  The instantiations of the persistent kernels the library was compiled with (the launchers dispatch over exactly these lists).
- * family 0: eds_fused6_kernel<S, P, T, Q, K, G>, 1: eds_fused12_kernel<S, T, CAP, NC, K, Q>.  Returns how many the family has (-1:
+ * family 0: eds_fused6_kernel<S, P, T, Q, K, G>, 1: eds_fused12_kernel<S, T, CAP, NC, K, Q>, 2: its candidate-group instantiations as
+ * {S, T, NC, K, Q, G} (CAP = 512 for all of them; reached with EDS_FORCE_FUSED12 + EDS_REF12_GROUPS).  Returns how many the family has (-1:
  * no such family); with 0 <= index < count and args6 != NULL, writes the six template arguments of instantiation `index`.  The knobs
  * EDS_FORCE_FUSED6 / EDS_FORCE_FUSED12 = "a,b,c,d,e,f" launch one of them wherever it can solve the range (test hooks: tests/
  * test_instances_gpu.py checks every one against the CPU oracle). */

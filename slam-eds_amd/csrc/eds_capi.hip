@@ -461,8 +461,13 @@ int eds_trk_kernel_instances(int family, int index, int32_t* args6) {
         EDS_FUSED12_INSTANCES(EDS_I12_)
 #undef EDS_I12_
     };
-    const int n = family == 0 ? (int)(sizeof(f6) / sizeof(f6[0])) : (family == 1 ? (int)(sizeof(f12) / sizeof(f12[0])) : -1);
-    if (n > 0 && args6 && index >= 0 && index < n) std::memcpy(args6, family == 0 ? f6[index] : f12[index], 6 * sizeof(int32_t));
+    static const int32_t f12g[][6] = {              // family 2: the candidate-group instantiations of eds_fused12_kernel as {S, T, NC, K, Q, G} (CAP = 512 for all of them)
+#define EDS_I12G_(s, t, c, n, k, q, g) {s, t, n ? 1 : 0, k, q, g},
+        EDS_FUSED12_GROUP_INSTANCES(EDS_I12G_)
+#undef EDS_I12G_
+    };
+    const int n = family == 0 ? (int)(sizeof(f6) / sizeof(f6[0])) : (family == 1 ? (int)(sizeof(f12) / sizeof(f12[0])) : (family == 2 ? (int)(sizeof(f12g) / sizeof(f12g[0])) : -1));
+    if (n > 0 && args6 && index >= 0 && index < n) std::memcpy(args6, family == 0 ? f6[index] : (family == 1 ? f12[index] : f12g[index]), 6 * sizeof(int32_t));
     return n;
 }
 

@@ -53,7 +53,19 @@ typedef double acc4d __attribute__((ext_vector_type(4)));
 // four patches, the row splines run where the rows landed, a DPP transpose returns them to the point's own lane.  QUAD = 2 (round 3):
 // the same on the STRIP copies of the frames (eds_layout.hpp) — one 16-byte read per patch row at a 4-byte-aligned address instead of
 // two aligned pieces and a barrel shift, 2.5 instead of 3.06 sectors per patch.
-template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD>
+//
+// GROUPS = G > 1 (round 5; teams only): SPECULATIVE CANDIDATE GROUPS, as in eds_fused6_kernel.  Ceres rejects more than half of its steps on
+// this problem, and the steps a run of rejections would walk through (the radius halved, quartered, ...) are prepared side by side
+// whenever a linearisation is solved (EDS_NCAND of them, eds_solver12_coop.hpp).  G teams of K CUs evaluate prepared steps k .. k + G - 1 at
+// the same time; every workgroup then reads the BLOCK COSTS of all G x K members (one number per residual block: all a rejection
+// needs), replays Solver12's decisions over them in order (coop12_decide_head / coop12_walk / coop12_take), and only for the step that
+// was accepted fetches the 157 sums per block of that group's K members for the linearisation.  (Collecting ALL groups' sums in one
+// round of granules — no second trip — was measured slower: 111.6 against 106.8 us for one alignment, 150 against 126 with four
+// residual blocks: G x K x 314 polled granules per workgroup cost more than the trip they save.)  Same decisions, radii and counters
+// as one team alone; the sums are added in the same member order (inside a member the wavefronts' tiles meet in LDS by fp64 atomics, so
+// the last bits vary from run to run — with and without groups).  12 evaluations become 6-7 rounds.  The residuals of the accepted point stay in
+// the registers of the group that evaluated it, which writes them at the end.
+template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD, int GROUPS = 1>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
                                                               double loss_a, double ftol, double gtol, double ptol, int nb,
@@ -61,16 +73,20 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int tid = threadIdx.x;
     constexpr int nthr = NTHR;
     static_assert(TEAM == 1 || !NC, "the NC residual needs a second exchange (block norm of the sampled brightness): no teams");
+    static_assert(GROUPS == 1 || (TEAM > 1 && GROUPS <= EDS_NCAND), "candidate groups: teams only, at most one per prepared step");
+    constexpr int VTEAM = TEAM * GROUPS;              // workgroups per alignment
     __shared__ int s_ticket, s_timeout;
-    int team_slot = blockIdx.x, member = 0;
+    __shared__ double s_gcost[GROUPS][EDS_DEV_MAX_BLOCKS];      // GROUPS > 1: ||r_b||^2 of every group's candidate (summed over its members)
+    __shared__ int s_gacc, s_kacc, s_linmode;                   // ... the group / prepared step that was accepted this round (-1: none), how
+    int team_slot = blockIdx.x, member = 0, group = 0, res_owner = 0;
     if (TEAM > 1) {
         if (tid == 0) { s_ticket = (int)((unsigned)atomicAdd(ticket, 1) - ticket_base); s_timeout = 0; }   // the counter is never reset: the host knows how many tickets earlier launches took
         __syncthreads();
         if ((unsigned)s_ticket >= gridDim.x) return;      // counters out of step: see eds_fused6_kernel
-        team_slot = s_ticket / TEAM; member = s_ticket % TEAM;
+        team_slot = s_ticket / VTEAM; member = s_ticket % TEAM; group = (s_ticket % VTEAM) / TEAM;
     }
     const int slot = first + team_slot;
-    if (tid == 0 && member == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && member == 0 && group == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
     unsigned pass_no = 0;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
@@ -162,9 +178,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #define EDS12_PSTAMP(k) do { } while (0)
 #endif
     float rkeep[2] = {0.0f, 0.0f};                           // candidate residuals of this lane's first two points (all sweeps write them)
+    float racc[2] = {0.0f, 0.0f};                            // GROUPS > 1: ... of the accepted point, in the group that evaluated it
     for (;;) {
         EDS12_PSTAMP(5);                                     // residual copy of an accepted evaluation, loop back
-        const double* __restrict__ s_pose = s_pb[s_k];      // the pose block under evaluation
+        // the pose block under evaluation (candidate groups: group g takes prepared step s_k + g; the first round has one point, the start)
+        const int k_eval = GROUPS > 1 ? (sv.started ? (s_k + group < EDS_NCAND ? s_k + group : EDS_NCAND - 1) : s_k) : s_k;
+        const double* __restrict__ s_pose = s_pb[k_eval];
         PoseF ps;
         load_pose(s_pose, ps);
         float vf[6];
@@ -420,7 +439,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         for (int k = 0; k < 6; ++k) x[k] = w * (st7[k * jplane] * inv_e - E * (float)nk[1 + k]);
                         x[12] = w * (m * inv_n - E * inv_e);
                     }
-                    if (valid) {                                      // candidate residual
+                    if (valid && GROUPS == 1) {                       // candidate residual (candidate groups: registers only — the groups share the plane)
                         if (RC_CAP > 0 && i - lo < RC_CAP) s_rc[i - lo] = x[12]; else A.mhat[base + i] = x[12];
                     }
                     if (j0 == lo) rkeep[jj] = x[12];                  // (the first two of a lane also stay in registers: see the accept copy)
@@ -478,7 +497,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             // every thread publishes "its" entries of this member's sums, then collects the same entries of all members and leaves
             // their total (added in member order: identical on every member) in place
             const unsigned tag = (epoch << 8) | ((pass_no & 0x7f) + 1);
-            unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * ((size_t)TEAM * EDS_TEAM12_GRANULES);
+            unsigned long long* mb = mail + ((size_t)team_slot * 2 + (pass_no & 1)) * ((size_t)VTEAM * EDS_TEAM12_GRANULES);
+            const int me = group * TEAM + member;
             const int nval = nb * EDS_TEAM12_VALUES;
             auto entry = [&](int e) -> double* {
                 const int b = e / EDS_TEAM12_VALUES, r = e - b * EDS_TEAM12_VALUES;
@@ -486,11 +506,95 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             };
             for (int e = tid; e < nval; e += nthr) {
                 const unsigned long long bits = (unsigned long long)__double_as_longlong(*entry(e));
-                unsigned long long* g = mb + (size_t)member * EDS_TEAM12_GRANULES + 2 * e;
+                unsigned long long* g = mb + (size_t)me * EDS_TEAM12_GRANULES + 2 * e;
                 __hip_atomic_store(g, ((unsigned long long)tag << 32) | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(g + 1, ((unsigned long long)tag << 32) | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            // sums entry e of the K members of group `grp`, added in member order (polls until every granule carries this round's tag)
+            auto collect = [&](int grp, int e, double& tot) {
+                const unsigned long long* gb = mb + (size_t)grp * TEAM * EDS_TEAM12_GRANULES;
+                tot = 0.0;
+                constexpr int GM = TEAM < 4 ? TEAM : (TEAM == 16 ? 8 : 4);
+#pragma unroll
+                for (int m0 = 0; m0 < TEAM; m0 += GM) {
+                    unsigned long long v[2 * GM];
+#pragma unroll
+                    for (int k = 0; k < 2 * GM; ++k)
+                        v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        bool late = false;
+#pragma unroll
+                        for (int k = 0; k < 2 * GM; ++k) late |= (unsigned)(v[k] >> 32) != tag;
+                        if (!late) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int k = 0; k < 2 * GM; ++k)
+                            if ((unsigned)(v[k] >> 32) != tag)
+                                v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int m = 0; m < GM; ++m)
+                        tot += __longlong_as_double((long long)(((v[2 * m + 1] & 0xffffffffull) << 32) | (v[2 * m] & 0xffffffffull)));
+                }
+            };
+            if constexpr (GROUPS > 1) {
+                // ---- phase 1: the block costs of every group -----------------------------------------------------------------------------
+                for (int idx = tid; idx < GROUPS * nb; idx += nthr) {
+                    const int g = idx / nb, b = idx - g * nb;
+                    double tot;
+                    collect(g, b * EDS_TEAM12_VALUES, tot);
+                    s_gcost[g][b] = tot;
+                }
+                ++pass_no;
+                __syncthreads();
+                if (s_timeout) {
+                    if (tid == 0) { sv.termination = edss::TERM_FAILURE; sv.num_unsuccessful = -2; }
+                    break;
+                }
+                EDS12_STAMP(1);
+                // ---- Solver12's decisions replayed over the G candidates, in order (wavefront 0) ---------------------------------------------
+                if (wave == 0) {
+                    const int kbase = edsc::uniform_int(s_k);
+                    int kcur = kbase, gacc = -1, walk = edsc::W_EVAL, mode = edsc::M_RETURN, head = 0;
+                    for (;;) {
+                        const int g = edsc::uniform_int(sv.started) ? kcur - kbase : 0;
+                        mode = edsc::coop12_decide_head(sv, nb, s_gcost[g], work, lane);
+                        if (mode == edsc::M_RETURN) { walk = edsc::W_RETURN; break; }
+                        if (mode != edsc::M_ADVANCE) { gacc = g; break; }                 // M_LIN_ITER0 / M_LIN_ACCEPT: this one becomes the accepted point
+                        const edsc::Walk12 wk = edsc::coop12_walk(sv, s_cand, kcur + 1, 0, lane);       // unsuccessful: one notch down the radius sequence
+                        walk = wk.walk; head = wk.head;
+                        if (wk.walk != edsc::W_EVAL) { kcur = wk.k; break; }             // the solve ended, or no step is prepared for this radius
+                        edsc::coop12_take(sv, s_cand[wk.k], lane);
+                        kcur = wk.k;
+                        if (kcur - kbase >= GROUPS) break;                               // prepared, but not evaluated in this round: the next round starts there
+                    }
+                    if (lane == 0) {
+                        s_gacc = gacc; s_kacc = kcur; s_linmode = mode;
+                        s_accept = gacc >= 0 ? 1 : 0;
+                        s_walk = walk; s_k = kcur; s_head = head;
+                    }
+                }
+                __syncthreads();
+                // ---- phase 2: the full sums of the accepted group, the linearisation, the walk on from there ------------------------------
+                const int gacc = s_gacc;
+                if (gacc >= 0) {
+                    for (int e = tid; e < nval; e += nthr) { double tot; collect(gacc, e, tot); *entry(e) = tot; }
+                    __syncthreads();
+                    if (wave == 0) {
+                        const int mode = edsc::coop12_linearise(sv, sums, work, s_pb[edsc::uniform_int(s_kacc)], edsc::uniform_int(s_linmode), lane);
+                        edsc::Walk12 wk{edsc::W_RETURN, 0, 0};
+                        if (mode != edsc::M_RETURN) wk = edsc::coop12_walk(sv, s_cand, EDS_NCAND, 0, lane);      // fresh linearisation: every prepared step is stale
+                        if (lane == 0) {
+                            s_walk = wk.walk;
+                            if (mode != edsc::M_RETURN) { s_k = wk.k; s_head = wk.head; }
+                            if (mode == edsc::M_RETURN) s_accept = 0;
+                        }
+                        if (wk.walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[wk.k], lane);
+                    }
+                }
+            } else {
             for (int e = tid; e < nval; e += nthr) {
                 // all 2 K granules of the entry in flight at once (the members sit on other XCDs: every load is a fabric round trip,
                 // and 2 K of them one after the other were ~4 us per evaluation), then only the late ones are polled again
@@ -526,9 +630,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 if (tid == 0) { sv.termination = edss::TERM_FAILURE; sv.num_unsuccessful = -2; }
                 break;
             }
+            }
         }
-        EDS12_STAMP(1);
-        if (wave == 0) {                        // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
+        if (GROUPS == 1) EDS12_STAMP(1);
+        if (GROUPS == 1 && wave == 0) {         // the LM state machine (eds_solver12_coop.hpp): what this evaluation means, the
             const int mode = edsc::coop12_decide(sv, sums, work, s_pose, lane);          // linearisation if it was accepted,
             // and the bookkeeping up to the next step — a prepared one, if there is one (every lane walks; lane 0 keeps the outcome)
             edsc::Walk12 wk{edsc::W_RETURN, 0, 0};
@@ -582,6 +687,12 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #ifdef EDS_FUSED_STAMPS
         ++st_n;
 #endif
+        if (GROUPS > 1) {                       // candidate groups: the residuals of the accepted point stay in the registers of the group that evaluated it
+            if (s_accept) {
+                res_owner = s_gacc;
+                if (group == s_gacc) { racc[0] = rkeep[0]; racc[1] = rkeep[1]; }
+            }
+        } else
         if (s_accept) {                         // the candidate became the accepted point: its residuals are the ones to keep
             // each thread copies what it wrote itself; its first two points out of registers — a lone alignment on 8 CUs has nothing
             // else, and the load of the value just stored (an L2 round trip) sat at the head of the next evaluation
@@ -605,10 +716,19 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                work.st[0] / st_n, work.st[1] / st_n, work.st[2] / st_n, work.st[3] / st_n, work.st[4] / st_n, work.st[5] / st_n, work.st[6] / st_n);
     }
 #endif
+    if (GROUPS > 1) {                           // (a member's slice is at most 2 x NTHR points: the launcher forms groups only then)
+        if (group == res_owner) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int i = lo + jj * nthr + tid;
+                if (i < hi) { A.r[base + i] = racc[jj]; if (A.rmap) A.rmap[base + i] = racc[jj]; }
+            }
+        }
+    } else
     if (TEAM > 1 && A.rmap) {                   // the kept residuals into the pinned mirror (each thread: the entries it wrote itself)
         for (int i = lo + tid; i < hi; i += nthr) A.rmap[base + i] = A.r[base + i];
     }
-    if (TEAM > 1 && member != 0) return;        // every member holds the same result; member 0 reports it
+    if (TEAM > 1 && (member != 0 || group != 0)) return;        // every member holds the same result; member 0 (of group 0) reports it
     if (tid == 0) {
         EdsFused12Out& O = out[slot];
         const bool ok = sv.termination != edss::TERM_FAILURE;
@@ -671,10 +791,6 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;       // (see eds_fused_solve)
     A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     const unsigned ticket_base = fb.ticket_base;
-    if (team > 1) {
-        fb.ticket_base += (unsigned)(count * team);
-        for (int s = first; s < first + count; ++s) fb.h_out12[s].failed = 2;    // "no result yet" reads as a time-out (eds_fused_solve)
-    }
     const int drop = kn.team_drop ? 1 : 0;            // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
@@ -682,13 +798,28 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     const bool strips = pl.strips_eligible && eds_strips_for_solve(h, first, count);
     eds_ref12_plan_finish(kn, rin, strips ? 1 : 0, pl);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
-    if (!eds_fused12_instance_exists(pl.S, pl.T, pl.CAP, pl.NC, pl.K, pl.Q))
+    const int groups = pl.K > 1 ? pl.G : 1;          // candidate groups: G x K workgroups per alignment
+    if (!eds_fused12_instance_exists(pl.S, pl.T, pl.CAP, pl.NC, pl.K, pl.Q, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
-    std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q);
-    fb.last_workgroups = count * pl.K - (pl.K > 1 ? drop : 0); fb.last_team = pl.K; fb.last_layout = pl.Q == 2 ? 2 : 1;
+    if (team > 1) {
+        fb.ticket_base += (unsigned)(count * team * groups);
+        for (int s = first; s < first + count; ++s) fb.h_out12[s].failed = 2;    // "no result yet" reads as a time-out (eds_fused_solve)
+    }
+    if (groups > 1) std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q, groups);
+    else std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q);
+    fb.last_workgroups = count * pl.K * groups - (pl.K > 1 ? drop : 0); fb.last_team = pl.K * groups; fb.last_layout = pl.Q == 2 ? 2 : 1;
     bool launched = false;
+#define EDS_INST_LAUNCH12G_(S_, T_, C_, N_, K_, Q_, G_)                                                                               \
+    if (!launched && groups == G_ && pl.S == S_ && pl.T == T_ && pl.CAP == C_ && (pl.NC != 0) == N_ && pl.K == K_ && pl.Q == Q_) {   \
+        launched = true;                                                                                                              \
+        hipLaunchKernelGGL((eds_fused12_kernel<S_, T_, C_, N_, K_, Q_, G_>), dim3(count * K_ * G_ - drop), dim3(T_), 0, h->st, A, fb.d_in, \
+                           fb.d_out12, first, iters, h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance, \
+                           h->cfg.parameter_tolerance, nb, fb.d_mail12, fb.d_ticket, ticket_base, fb.epoch);                         \
+    }
+    if (groups > 1) { EDS_FUSED12_GROUP_INSTANCES(EDS_INST_LAUNCH12G_) }
+#undef EDS_INST_LAUNCH12G_
 #define EDS_INST_LAUNCH12_(S_, T_, C_, N_, K_, Q_)                                                                                    \
-    if (!launched && pl.S == S_ && pl.T == T_ && pl.CAP == C_ && (pl.NC != 0) == N_ && pl.K == K_ && pl.Q == Q_) {                   \
+    if (!launched && groups == 1 && pl.S == S_ && pl.T == T_ && pl.CAP == C_ && (pl.NC != 0) == N_ && pl.K == K_ && pl.Q == Q_) {    \
         launched = true;                                                                                                              \
         hipLaunchKernelGGL((eds_fused12_kernel<S_, T_, C_, N_, K_, Q_>), dim3(count * K_ - ((K_) > 1 ? drop : 0)), dim3(T_), 0, h->st, A, fb.d_in, \
                            fb.d_out12, first, iters, h->cfg.loss_type, h->cfg.loss_param, h->cfg.function_tolerance, h->cfg.gradient_tolerance, \

@@ -52,6 +52,7 @@ struct EdsKnobs {
     int force6_set = 0, force6[6] = {0, 0, 0, 0, 0, 0};        // EDS_FORCE_FUSED6   "S,P,T,Q,K,G": launch exactly this instantiation of eds_fused6_kernel
     int force12_set = 0, force12[6] = {0, 0, 0, 0, 0, 0};      // EDS_FORCE_FUSED12  "S,T,CAP,NC,K,Q": ... of eds_fused12_kernel.  Test hooks (tests/test_instances_gpu.py
                                                                // walks the compiled lists with them); honoured only where the instantiation exists and fits the range
+    int ref12_groups = 0;       // EDS_REF12_GROUPS    1 | 2 | 4: candidate groups of a REF12 team launch (eds_fused12.hip)   0: the rule
     int upload_streams = 0;     // EDS_UPLOAD_STREAMS  1: the batch upload keeps to the handle's stream (default: alternate frames on a second one)
     int upload_dma = 0;         // EDS_UPLOAD_DMA      1: the batch upload moves the staged frames with the copy engine (hipMemcpyAsync) instead of kernels reading pinned memory
     int lm6_groups = 0;         // EDS_LM6_GROUPS      1 | 2 | 4 | 8: candidate groups of a team launch (eds_fused.hip)   0: the rule
@@ -89,6 +90,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_FRAME_LAYOUT")) { if (unset || is("tiles")) k->frame_rowmajor = 0; else if (is("rowmajor")) k->frame_rowmajor = 1; else return -2; }
     else if (!strcmp(name, "EDS_REDUCE_PPL")) { if (unset) k->reduce_ppl = 4; else if (one_of({4, 8})) k->reduce_ppl = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_LM6_GROUPS")) { if (unset) k->lm6_groups = 0; else if (one_of({1, 2, 4, 8})) k->lm6_groups = (int)iv; else return -2; }
+    else if (!strcmp(name, "EDS_REF12_GROUPS")) { if (unset) k->ref12_groups = 0; else if (one_of({1, 2, 4})) k->ref12_groups = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_UPLOAD_THREADS")) { if (unset) k->upload_threads = 0; else if (num && iv >= 1 && iv <= 64) k->upload_threads = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_UPLOAD_DMA")) return flag(&k->upload_dma, 0);
     else if (!strcmp(name, "EDS_UPLOAD_STREAMS")) { if (unset) k->upload_streams = 0; else if (one_of({1, 2})) k->upload_streams = iv == 1 ? 1 : 0; else return -2; }
@@ -117,7 +119,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12")
+    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12") X("EDS_REF12_GROUPS")
 
 // the process environment, read once per handle (eds_trk_create)
 static inline void eds_knobs_from_env(EdsKnobs* k) {
@@ -157,7 +159,7 @@ struct EdsLm6Plan {
 };
 
 static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G);
-static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q);
+static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q, int G);
 struct EdsRef12In;
 static inline bool eds_lm6_force_feasible(const EdsKnobs& kn, const EdsLm6In& in, const EdsLm6Plan& p);
 static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In& in);
@@ -364,6 +366,7 @@ struct EdsRef12Plan {
     int wide, wants_team;               // begin
     int team, quad, strips_eligible;    // team
     int S, T, CAP, NC, K, Q;            // finish
+    int G;                              // candidate groups (seventh template argument): G x K workgroups per alignment
 };
 
 static inline void eds_ref12_plan_begin(const EdsKnobs& kn, const EdsRef12In& in, EdsRef12Plan& p) {
@@ -411,7 +414,7 @@ static inline void eds_ref12_plan_team(const EdsKnobs& kn, const EdsRef12In& in,
 static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In& in) {
     if (!kn.force12_set) return false;
     const int S = kn.force12[0], T = kn.force12[1], CAP = kn.force12[2], NC = kn.force12[3], K = kn.force12[4], Q = kn.force12[5];
-    if (K < 1 || !eds_fused12_instance_exists(S, T, CAP, NC, K, Q)) return false;
+    if (K < 1 || !eds_fused12_instance_exists(S, T, CAP, NC, K, Q, 1)) return false;
     if (S != (in.bicubic ? 0 : 1) || (NC != 0) != (in.nc != 0)) return false;
     if (K > 1 && (in.nc || in.retry || in.count > EDS_RULE_TEAM12_SLOTS || in.count * K > EDS_RULE_TEAM12_MEMBERS)) return false;
     if (Q != 0 && in.H >= 8000) return false;
@@ -420,8 +423,26 @@ static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In
 
 static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& in, int strips, EdsRef12Plan& p) {
     strips = strips && p.strips_eligible;
+    // Candidate groups (the latency regime proper: the launch leaves CUs idle): G teams evaluate G prepared steps at once — as many as
+    // give every workgroup a CU of its own (measured, tools/check_groups12.py: 8 alignments x 8 CUs x 4 groups on all 256 CUs 114.8 us,
+    // 2 groups 119.8, none 122.0; unlike the pose-only kernel, whose rounds are short enough for a full chip to cost more than it gives).
+    // Only where a member's slice is at most 512 points (its patch cache in this shape; the kept residuals stay in registers) and an
+    // instantiation exists.
+    auto groups_for = [&](EdsRef12Plan& q) {
+        q.G = 1;
+        if (q.K <= 1 || q.NC || q.T != 512 || (long long)in.maxN > 512ll * q.K) return;
+        int g = 1;
+        for (int c = 4; c >= 2; c >>= 1)
+            if (in.count * q.K * c <= EDS_RULE_CUS) { g = c; break; }
+        if (kn.ref12_groups) g = kn.ref12_groups;
+        if (g > 1 && (in.count * q.K * g > EDS_RULE_TEAM12_MEMBERS || !eds_fused12_instance_exists(q.S, q.T, 512, q.NC, q.K, q.Q, g))) g = 1;
+        q.G = g;
+        if (g > 1) q.CAP = 512;
+    };
     if (eds_ref12_force_feasible(kn, in) && (kn.force12[5] != 2 || strips) && p.team == kn.force12[4]) {
         p.S = kn.force12[0]; p.T = kn.force12[1]; p.CAP = kn.force12[2]; p.NC = kn.force12[3]; p.K = kn.force12[4]; p.Q = kn.force12[5];
+        p.G = 1;
+        if (kn.ref12_groups > 1) groups_for(p);          // (a forced instantiation forms groups only when asked to)
         return;
     }
     const bool want_strips = !in.nc && !kn.layout_tiles;
@@ -433,6 +454,7 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     if (p.team >= 8 || !in.bicubic) p.Q = 0;
     else p.Q = strips ? 2 : (quad ? 1 : 0);
     if (p.team == 1 && !(in.bicubic && strips)) p.NC = in.nc ? 1 : 0;
+    groups_for(p);
 }
 
 #define EDS_FUSED12_INSTANCES(X)                                                                                                      \
@@ -444,10 +466,19 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     X(0, 256, 320, false, 1, 2) X(0, 256, 320, false, 1, 1) X(0, 256, 320, true, 1, 1) X(0, 256, 320, false, 1, 0)                  \
     X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)
 
-static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q) {
+// ... and the candidate-group instantiations X(S, T, CAP, NC, K, Q, G), G > 1: a member's slice is at most 512 points here, so is its patch
+// cache (CAP = 512) — the LDS that leaves holds the G sets of sums of a round
+#define EDS_FUSED12_GROUP_INSTANCES(X)                                                                                                \
+    X(0, 512, 512, false, 8, 0, 2) X(0, 512, 512, false, 8, 0, 4) X(1, 512, 512, false, 8, 0, 2) X(1, 512, 512, false, 8, 0, 4)   \
+    X(0, 512, 512, false, 4, 0, 2) X(1, 512, 512, false, 4, 0, 2)
+
+static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q, int G) {
 #define EDS_INST_EQ_(s, t, c, n, k, q) if (S == s && T == t && CAP == c && (NC != 0) == n && K == k && Q == q) return true;
+#define EDS_INST_EQ7_(s, t, c, n, k, q, g) if (S == s && T == t && CAP == c && (NC != 0) == n && K == k && Q == q && G == g) return true;
+    if (G > 1) { EDS_FUSED12_GROUP_INSTANCES(EDS_INST_EQ7_) return false; }
     EDS_FUSED12_INSTANCES(EDS_INST_EQ_)
 #undef EDS_INST_EQ_
+#undef EDS_INST_EQ7_
     return false;
 }
 

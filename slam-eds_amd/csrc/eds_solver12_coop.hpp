@@ -82,9 +82,11 @@ struct Step12 {                 // LDS scratch of one proposing wavefront
 // Solver12::on_eval up to (and including) the linearisation at a newly accepted point.  Wavefront 0, all lanes.
 // Returns M_RETURN (solve ended: sv.done set), M_ADVANCE (unsuccessful step: radius already shrunk, prepared steps still valid) or
 // M_LIN_ITER0 / M_LIN_ACCEPT (fresh linearisation: prepared steps are stale).  `pb`: the pose block the sums were evaluated at.
-__device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
+// Round 5: in two halves, because the candidate groups of the team kernel (eds_fused12.hip, GROUPS > 1) take the DECISION on the block
+// costs alone — sblk[b] = ||r_b||^2 of the candidate, all a rejection ever needs — and fetch the 157 sums per block only of the
+// candidate that was accepted, for the linearisation.  coop12_decide = head + linearise is what one team per alignment runs.
+__device__ inline int coop12_decide_head(edss::Solver12& sv, const int nb, const double* sblk, Work12& W, const int lane) {
     using namespace edss;
-    const int nb = S.nb;
 #ifdef EDS_FUSED_STAMPS
     if (lane == 0) W.st_t = __builtin_readcyclecounter();
 #endif
@@ -93,7 +95,7 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
     // started? -> the 26 coordinates -> mode -> W.mode -> every lane.  Lane 0 stores what the decision changes.
     double r0 = 0.0, r1 = 1.0;
     if (lane < nb) {
-        loss_eval(sv.loss_type, sv.loss_a, S.s[lane], &r0, &r1);
+        loss_eval(sv.loss_type, sv.loss_a, sblk[lane], &r0, &r1);
         W.r1[lane] = r1;                // (the linearisation weighs the blocks' sums with it)
     }
     const int final_pass = sv.final_pass, started = sv.started;
@@ -160,8 +162,15 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
         else if (lane < 13) sv.v[lane - 7] = sv.cv[lane - 7];
         EDS_WSYNC();
     }
+    return mode;
+}
 
-    {                                   // Solver12::linearise at the (new) accepted point
+// Second half: Solver12::linearise at the (new) accepted point, from the per-block sums S of the evaluation that was accepted (W.r1, W.cost,
+// W.rel: left by the head).  `pb`: the pose block those sums were evaluated at.  mode: M_LIN_ITER0 | M_LIN_ACCEPT; returns it, or M_RETURN.
+__device__ inline int coop12_linearise(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int mode, const int lane) {
+    using namespace edss;
+    const int nb = S.nb;
+    {
         bool bad = !(fabs(W.cost) < 1e300);
         const int nbu = uniform_int(nb);        // (scalar loops over the blocks: nb comes out of LDS, i.e. in a vector register)
         for (int i = lane; i < 144; i += 64) {
@@ -257,6 +266,12 @@ __device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S
         EDS_CSTAMP(1);
     }
     return mode;
+}
+
+__device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
+    const int mode = coop12_decide_head(sv, S.nb, S.s, W, lane);
+    if (mode == M_RETURN || mode == M_ADVANCE) return mode;
+    return coop12_linearise(sv, S, W, pb, mode, lane);
 }
 
 // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system for the radius that `ahead` further shrinkages lead to, the

@@ -178,7 +178,7 @@ int hl_lm6_rule(const char* knobs, const int32_t* in7, int flags, int32_t* out) 
     std::memcpy(out, o, sizeof(o));
     return 0;
 }
-// in5 = {maxN, count, bicubic, nc, H}; flags as above.  out = {S, T, CAP, NC, K, Q, strips_eligible, wants_team, instance_exists}
+// in5 = {maxN, count, bicubic, nc, H}; flags as above.  out = {S, T, CAP, NC, K, Q, strips_eligible, wants_team, instance_exists, G}
 int hl_ref12_rule(const char* knobs, const int32_t* in5, int flags, int32_t* out) {
     EdsKnobs kn;
     if (parse_knobs(knobs, &kn)) return -1;
@@ -189,7 +189,7 @@ int hl_ref12_rule(const char* knobs, const int32_t* in5, int flags, int32_t* out
     eds_ref12_plan_team(kn, in, team_ok, (flags & 4) ? 1 : 0, p);
     const int strips = p.strips_eligible && (flags & 8);
     eds_ref12_plan_finish(kn, in, strips, p);
-    const int32_t o[9] = {p.S, p.T, p.CAP, p.NC, p.K, p.Q, p.strips_eligible, p.wants_team, eds_fused12_instance_exists(p.S, p.T, p.CAP, p.NC, p.K, p.Q) ? 1 : 0};
+    const int32_t o[10] = {p.S, p.T, p.CAP, p.NC, p.K, p.Q, p.strips_eligible, p.wants_team, eds_fused12_instance_exists(p.S, p.T, p.CAP, p.NC, p.K, p.Q, p.G) ? 1 : 0, p.G};
     std::memcpy(out, o, sizeof(o));
     return 0;
 }

@@ -21,7 +21,7 @@ import numpy as np
 sys.path.insert(0, sys.argv[1])
 capi = importlib.import_module("slam-eds_amd.capi"); synth = importlib.import_module("slam-eds_amd.synth")
 out = {}
-for name, samp, N, B, tau in (("bicubic_p4", capi.SAMPLE_BICUBIC, 2000, 70, 0.0), ("bicubic_p2_huber", capi.SAMPLE_BICUBIC, 900, 40, 0.004), ("bilinear_p4", capi.SAMPLE_BILINEAR, 1900, 48, 0.0)):
+for name, samp, N, B, tau in (("bicubic_p4", capi.SAMPLE_BICUBIC, 2000, 136, 0.0), ("bicubic_p2_huber", capi.SAMPLE_BICUBIC, 900, 40, 0.004), ("bilinear_p4", capi.SAMPLE_BILINEAR, 1900, 132, 0.0)):
     als = [synth.make_alignment(8100 + i, H=240, W=320, N=N) for i in range(5)]
     h = capi.Handle(capi.default_config(sampling=samp, solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10, huber_tau=tau), B, N, 240, 320)
     for b in range(B):

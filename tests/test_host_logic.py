@@ -219,10 +219,10 @@ def _lm6(hl, knobs="", maxN=2000, count=4096, bicubic=1, iters=10, lm6=1, huber=
 
 
 def _ref12(hl, knobs="", maxN=2000, count=4096, bicubic=1, nc=0, H=480, flags=TEAM_OK | STRIPS):
-    out = np.zeros(9, dtype=np.int32)
+    out = np.zeros(10, dtype=np.int32)
     rc = hl.hl_ref12_rule(knobs.encode(), np.array([maxN, count, bicubic, nc, H], dtype=np.int32).ctypes.data_as(_ip), int(flags), out.ctypes.data_as(_ip))
     assert rc == 0
-    return dict(zip(("S", "T", "CAP", "NC", "K", "Q", "strips_eligible", "wants_team", "exists"), (int(x) for x in out)))
+    return dict(zip(("S", "T", "CAP", "NC", "K", "Q", "strips_eligible", "wants_team", "exists", "G"), (int(x) for x in out)))
 
 
 def _k6(d):
@@ -324,17 +324,25 @@ def test_launch_rule_ref12_table(hl):
     assert K(_ref12(hl)) == (0, 256, 320, 0, 1, 2) and K(_ref12(hl, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 1)       # the batch: two alignments per CU
     assert K(_ref12(hl, count=512, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 0)                                       # tiles: the quad gather from 1 024 on
     assert K(_ref12(hl, count=256)) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, count=65, flags=TEAM_OK)) == (0, 512, 1408, 0, 1, 0)
-    assert K(_ref12(hl, count=1)) == (0, 512, 1408, 0, 8, 0) and K(_ref12(hl, count=16)) == (0, 512, 1408, 0, 8, 0)
-    assert K(_ref12(hl, count=17)) == (0, 512, 1408, 0, 4, 0) and K(_ref12(hl, count=64)) == (0, 512, 1408, 0, 4, 2)
+    # (round 5: where candidate groups are formed a member's patch cache is 512 points; EDS_REF12_GROUPS=1 is the one-team launch)
+    assert K(_ref12(hl, count=1)) == (0, 512, 512, 0, 8, 0) and K(_ref12(hl, count=16)) == (0, 512, 512, 0, 8, 0)
+    assert K(_ref12(hl, "EDS_REF12_GROUPS=1", count=1)) == (0, 512, 1408, 0, 8, 0) and K(_ref12(hl, "EDS_REF12_GROUPS=1", count=16)) == (0, 512, 1408, 0, 8, 0)
+    assert K(_ref12(hl, count=17)) == (0, 512, 512, 0, 4, 0) and K(_ref12(hl, count=33)) == (0, 512, 1408, 0, 4, 0) and K(_ref12(hl, count=64)) == (0, 512, 1408, 0, 4, 2)
     assert K(_ref12(hl, maxN=1000, count=8)) == (0, 512, 1408, 0, 2, 0) and K(_ref12(hl, maxN=500, count=8))[4] == 1
     assert K(_ref12(hl, maxN=16000, count=4)) == (0, 512, 1408, 0, 16, 0) and K(_ref12(hl, maxN=8000, count=64)) == (0, 512, 1408, 0, 8, 0)
     # teams of 8 / 16 have no strip instantiation: their frames are not converted
     assert not _ref12(hl, "EDS_REF12_TEAM=8", count=64)["strips_eligible"] and _ref12(hl, count=64)["strips_eligible"]
     # the NC residual: no teams, no strips; the bilinear sampler: the lane gather
     assert K(_ref12(hl, nc=1)) == (0, 256, 320, 1, 1, 1) and K(_ref12(hl, nc=1, count=8)) == (0, 512, 1408, 1, 1, 0)
-    assert K(_ref12(hl, bicubic=0)) == (1, 256, 320, 0, 1, 0) and K(_ref12(hl, bicubic=0, count=4)) == (1, 512, 1408, 0, 8, 0)
+    assert K(_ref12(hl, bicubic=0)) == (1, 256, 320, 0, 1, 0) and K(_ref12(hl, bicubic=0, count=4)) == (1, 512, 512, 0, 8, 0)
     assert K(_ref12(hl, "EDS_REF12_KERNEL=wide")) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, "EDS_REF12_KERNEL=paired", count=8)) == (0, 256, 320, 0, 1, 0)
     assert K(_ref12(hl, "EDS_REF12_TEAM=4", count=8, flags=COOLDOWN))[4] == 1 and K(_ref12(hl, count=8, flags=RETRY | TEAM_OK))[4] == 1
+    # candidate groups (round 5): as many teams as give every workgroup a CU of its own; teams of 8 and 4 (lane gather) only
+    assert [_ref12(hl, count=c)["G"] for c in (1, 8, 9, 16, 17, 32, 33, 64, 65)] == [4, 4, 2, 2, 2, 2, 1, 1, 1]
+    assert _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["G"] == 1 and _ref12(hl, "EDS_REF12_GROUPS=2", count=1)["G"] == 2 and _ref12(hl, "EDS_REF12_GROUPS=4", count=20)["G"] == 1
+    assert _ref12(hl, maxN=4097, count=1)["G"] == 1 and _ref12(hl, maxN=4096, count=1)["G"] == 4 and _ref12(hl, count=1, bicubic=0)["G"] == 4
+    assert _ref12(hl, count=1)["CAP"] == 512 and _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["CAP"] == 1408 and _ref12(hl, maxN=2049, count=20)["G"] == 1
+    assert _ref12(hl, count=1, nc=1)["G"] == 1 and _ref12(hl, count=4, flags=COOLDOWN | STRIPS)["G"] == 1 and _ref12(hl, maxN=1000, count=8)["G"] == 1
 
 
 def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
@@ -358,7 +366,8 @@ def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
                 assert d["P"] * d["threads"] >= maxN, (kn, maxN, count, d)       # register-resident points: every point has a lane slot
             n += 1
     for kn in ["", "EDS_FUSED_LAYOUT=tiles", "EDS_FUSED_GATHER=lane", "EDS_FUSED_GATHER=quad", "EDS_REF12_TEAM=1", "EDS_REF12_TEAM=2", "EDS_REF12_TEAM=4",
-               "EDS_REF12_TEAM=8", "EDS_REF12_TEAM=16", "EDS_REF12_KERNEL=wide", "EDS_REF12_KERNEL=paired"]:
+               "EDS_REF12_TEAM=8", "EDS_REF12_TEAM=16", "EDS_REF12_KERNEL=wide", "EDS_REF12_KERNEL=paired", "EDS_REF12_GROUPS=1", "EDS_REF12_GROUPS=2",
+               "EDS_REF12_GROUPS=4", "EDS_REF12_GROUPS=4;EDS_REF12_TEAM=8"]:
         for _ in range(300):
             d = _ref12(hl, kn, maxN=int(rng.choice([64, 512, 513, 1024, 1025, 2000, 4096, 4097, 8192, 8193, 16000])),
                        count=int(rng.choice([1, 16, 17, 32, 33, 64, 65, 256, 257, 1023, 1024, 4096])), bicubic=int(rng.integers(2)), nc=int(rng.integers(2)),
@@ -376,7 +385,7 @@ def test_knob_names_and_strip_budget(hl):
              "EDS_REF12_TEAM": ("8", "5"), "EDS_STRIPS_PHASES": ("2", "3"), "EDS_STRIPS_POLICY": ("never", "always"), "EDS_STRIPS_BUDGET_PCT": ("30", "0"),
              "EDS_NO_SPIN": ("1", "x"), "EDS_UPLOAD": ("bands", "1"), "EDS_FRAME_LAYOUT": ("rowmajor", "1"), "EDS_REDUCE_PPL": ("8", "abc"),
              "EDS_LM6_GROUPS": ("4", "3"), "EDS_UPLOAD_THREADS": ("6", "0"), "EDS_UPLOAD_DMA": ("1", "2"), "EDS_UPLOAD_STREAMS": ("1", "3"),
-             "EDS_FORCE_FUSED6": ("0,4,512,3,1,1", "0,4,512"), "EDS_FORCE_FUSED12": ("0,256,320,0,1,2", "a,b")}
+             "EDS_FORCE_FUSED6": ("0,4,512,3,1,1", "0,4,512"), "EDS_FORCE_FUSED12": ("0,256,320,0,1,2", "a,b"), "EDS_REF12_GROUPS": ("2", "3")}
     for name, (good, bad) in table.items():
         assert hl.hl_knob_set(name.encode(), good.encode()) == 0, name
         assert hl.hl_knob_set(name.encode(), bad.encode()) == -2, name
