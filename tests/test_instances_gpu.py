@@ -37,7 +37,7 @@ def test_the_library_reports_its_instantiations(gpu, capi):
     f6, f12 = capi.kernel_instances(0), capi.kernel_instances(1)
     assert len(f6) >= 90 and len(f12) >= 20 and len(set(f6)) == len(f6) and len(set(f12)) == len(f12)
     assert (0, 4, 512, 1, 1, 1) in f6 and (0, 4, 512, 3, 1, 1) in f6 and (0, 1, 512, 0, 4, 8) in f6 and (0, 256, 320, 0, 1, 1) in f12
-    assert capi.lib().eds_trk_kernel_instances(2, -1, None) == -1
+    assert capi.lib().eds_trk_kernel_instances(3, -1, None) == -1
     print(f"\n[instances] eds_fused6_kernel: {len(f6)}, eds_fused12_kernel: {len(f12)}")
 
 
@@ -91,8 +91,12 @@ def test_every_fused6_instantiation_vs_oracle(gpu, capi, synth, po):
 def test_every_fused12_instantiation_vs_oracle(gpu, capi, synth, po):
     qs = synth.quat_from_axis_angle([0.3, -0.5, 0.8], 2e-3)
     checked = 0
-    for (S, T, CAP, NC, K, Q) in capi.kernel_instances(1):
-        N = 2000 if K <= 4 else (4000 if K == 8 else 9000)
+    # family 1: the one-team instantiations; family 2 (round 5): the candidate-group ones {S, T, NC, K, Q, G}, reached by forcing the one-team
+    # instantiation they extend and asking for G groups (their patch cache is 512 points: a member's slice must fit)
+    cases = [(S, T, CAP, NC, K, Q, 1) for (S, T, CAP, NC, K, Q) in capi.kernel_instances(1)] + [(S, T, 1408, NC, K, Q, G) for (S, T, NC, K, Q, G) in capi.kernel_instances(2)]
+    assert len(capi.kernel_instances(2)) >= 6
+    for (S, T, CAP, NC, K, Q, G) in cases:
+        N = (2000 if K <= 4 else (4000 if K == 8 else 9000)) if G == 1 else 500 * K - 11
         B = 3
         cfg = capi.default_config(sampling=S, solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=8, num_blocks=2, nc=NC,
                                   loss_type=capi.LOSS_HUBER, loss_param=0.3)
@@ -104,10 +108,11 @@ def test_every_fused12_instantiation_vs_oracle(gpu, capi, synth, po):
         if Q == 2:
             h.prepare_frames(0, B)
         h.set_knob("EDS_FORCE_FUSED12", f"{S},{T},{CAP},{NC},{K},{Q}")
+        h.set_knob("EDS_REF12_GROUPS", str(G))
         h.set_states(0, np.stack([PS] * B), np.stack([qs] * B), np.stack([a.v0 for a, _ in als]))
         h.optimize_batch(0, 0, B)
         li = h.last_launch()
-        want = f"eds_fused12_kernel<{S}, {T}, {CAP}, {'true' if NC else 'false'}, {K}, {Q}>"
+        want = f"eds_fused12_kernel<{S}, {T}, {CAP if G == 1 else 512}, {'true' if NC else 'false'}, {K}, {Q}" + (f", {G}>" if G > 1 else ">")
         assert li["kernel"] == want, (li["kernel"], want)
         assert h.info(0)["flags"] == 0, "team time-out"
         tab = h.results(0, B)
@@ -131,7 +136,7 @@ def test_every_fused12_instantiation_vs_oracle(gpu, capi, synth, po):
         h.close()
         checked += 1
     print(f"\n[instances] {checked} eds_fused12_kernel instantiations launched by name and checked against the oracle")
-    assert checked == len(capi.kernel_instances(1))
+    assert checked == len(capi.kernel_instances(1)) + len(capi.kernel_instances(2))
 
 
 @pytest.mark.parametrize("script,args", [("fuzz_parity.py", ["40", "901"]), ("fuzz_batch.py", ["12", "902"]), ("fuzz_rows.py", ["40", "903"]),
