@@ -77,8 +77,11 @@ using namespace edsd;
 // records and iteration counts are those of the sequential solver bit for bit (each candidate's sums are added in the same member
 // order as a team of K adds them); the pattern above takes 5 rounds instead of 11 passes.  The residuals at the accepted pose live in
 // the registers of the group that evaluated it: that group writes them at the end.
+#ifndef EDS_TEAM_P1_WAVES_PER_EU
+#define EDS_TEAM_P1_WAVES_PER_EU 1
+#endif
 template <int SAMPLING, int PPT, int MAXT, int QUAD, int TEAM, int GROUPS = 1>
-__global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
+__global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PER_EU : 1) void eds_fused6_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                           EdsFusedOut* __restrict__ out, edss::Solver6* __restrict__ sv_all,
                                                           int first, int iters, int damped, double lambda0,
                                                           double huber_tau, int nb, unsigned long long* __restrict__ mail,
@@ -123,9 +126,11 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     // not meet in one bank group: 16-way conflicts on every read before, profiles/r04_sq_counters.txt)
     constexpr int ZSH = (QUAD >= 3 && SAMPLING == 1) ? 4 : 0;
     constexpr int ZSLOT = 256 + ZSH;                     // floats from one landing slot (64 lanes x 16 bytes) to the next
-    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NPATCH : 1][CACHE ? EDS_CACHE_CAP + 8 * ZSH : 1];
-    static_assert(QUAD < 3 || (MAXT / 64) * NREG * 4 * ZSLOT <= NPATCH * (EDS_CACHE_CAP + 8 * ZSH), "landing zone exceeds its allocation");
-    __shared__ int s_cell[CACHE ? EDS_CACHE_CAP : 1];
+    // (a team member of 512 points caches 512 patches: 32 KB instead of 128 — what lets two such workgroups share a CU)
+    constexpr int CCAP = (TEAM > 1 && PPT == 1 && QUAD < 3) ? 512 : EDS_CACHE_CAP;
+    __shared__ __attribute__((aligned(16))) float s_patch[CACHE ? NPATCH : 1][CACHE ? CCAP + 8 * ZSH : 1];
+    static_assert(QUAD < 3 || (MAXT / 64) * NREG * 4 * ZSLOT <= NPATCH * (CCAP + 8 * ZSH), "landing zone exceeds its allocation");
+    __shared__ int s_cell[CACHE ? CCAP : 1];
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const int Nall = (int)gpb[EDS_PB_N];
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
     // start of that allocation (quad gather); fslot is wave-uniform, so this is scalar arithmetic and the address lives in SGPRs
     // (the product in a 32-bit scalar multiply: 64-bit it became VALU work whose result sat in VGPRs — two v_readfirstlane per load)
     const float* __restrict__ tiles = A.frame + (size_t)((unsigned)fslot * (unsigned)(A.Hp * A.Wp / 16)) * 16;
-    static_assert(!QUAD || ((SAMPLING == 0 || QUAD >= 3) && PPT > 0 && PPT * MAXT <= EDS_CACHE_CAP), "quad gather: register-resident points, all cached; the bilinear sampler on strips only");
+    static_assert(!QUAD || ((SAMPLING == 0 || QUAD >= 3) && PPT > 0 && PPT * MAXT <= CCAP), "quad gather: register-resident points, all cached; the bilinear sampler on strips only");
 
     if (tid == 0) {
         const EdsFusedIn& I = in[slot];
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             } else if (in_range) {
                 A.mhat[o] = mh;
             }
-            if (CACHE && i < EDS_CACHE_CAP) s_cell[i] = 0x7fffffff;       // no cell cached yet
+            if (CACHE && i < CCAP) s_cell[i] = 0x7fffffff;       // no cell cached yet
         }
     }
     const float tau = (float)huber_tau;
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
             for (int j = 0; j < NREG; ++j) {
                 const int i = tid + j * nthr;
                 project_point(ps, kf[j], pg[j]);
-                const bool cached = CACHE && i < EDS_CACHE_CAP;
+                const bool cached = CACHE && i < CCAP;
                 const int key = (pg[j].r0 << 16) ^ (pg[j].c0 & 0xffff);
                 miss[j] = !(cached && s_cell[i] == key);
                 if (miss[j]) {
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
 #pragma unroll
             for (int j = 0; j < NREG; ++j) {
                 const int i = tid + j * nthr;
-                if (CACHE && miss[j] && i < EDS_CACHE_CAP) {
+                if (CACHE && miss[j] && i < CCAP) {
 #pragma unroll
                     for (int t = 0; t < NTAP; ++t) s_patch[t][i] = tap[j][t];
                 }
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(MAXT) void eds_fused6_kernel(EdsArrays A, const Eds
                 PointGeom pg;
                 project_point(ps, k, pg);
                 float tap[NTAP];
-                const bool cached = CACHE && i < EDS_CACHE_CAP;
+                const bool cached = CACHE && i < CCAP;
                 const int key = (pg.r0 << 16) ^ (pg.c0 & 0xffff);
                 if (cached && s_cell[i] == key) {
 #pragma unroll

@@ -275,7 +275,7 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
         // Candidate groups (the latency regime proper: every workgroup of the launch on a CU of its own, the other CUs idle): G teams
         // evaluate G prepared candidates at once.  Instantiated for the members of 512 points (one per lane), lane / quad gather on tiles.
         p.G = 1;
-        if (p.P == 1 && p.K == 4 && !p.wide_members) {
+        if (((p.P == 1 && p.K == 4) || (p.P == 2 && p.K == 2 && in.maxN <= 2048)) && !p.wide_members) {
             // measured (tools/check_groups.py, MI355X): a launch that takes HALF the CUs is faster than one that takes all of them
             // (8 alignments: 47.9 us with 4 groups on 128 CUs, 50.6 with 8 on 256), and two groups on all 256 still beat none
             // (32 alignments: 52.5 against 64.1 us); beyond the CU count the workgroups queue and a round waits for the queue
@@ -284,7 +284,7 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
                 if (in.count * p.K * c <= EDS_RULE_CUS / 2) { g = c; break; }
             if (g == 1 && in.count * p.K * 2 <= EDS_RULE_CUS) g = 2;
             if (kn.lm6_groups == 1 || kn.lm6_groups == 2 || kn.lm6_groups == 4 || kn.lm6_groups == 8) g = kn.lm6_groups;
-            if (in.count * p.K * g > EDS_RULE_TEAM_MEMBERS) g = 1;                    // the mailboxes' capacity
+            if (in.count * p.K * g > EDS_RULE_TEAM_MEMBERS || !eds_fused6_instance_exists(p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, g)) g = 1;     // the mailboxes' capacity; compiled?
             p.G = g;
         }
         return;
@@ -334,9 +334,11 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
 
 // ... and the candidate-group instantiations X(S, P, T, Q, K, G), G > 1 (teams of four members of 512 points)
 #define EDS_FUSED6_GROUP_INSTANCES(X)                                                                                                 \
-    X(0, 1, 512, 0, 4, 2) X(0, 1, 512, 0, 4, 4) X(0, 1, 512, 0, 4, 8) X(0, 1, 512, 1, 4, 2) X(0, 1, 512, 1, 4, 4) X(0, 1, 512, 1, 4, 8)
+    X(0, 1, 512, 0, 4, 2) X(0, 1, 512, 0, 4, 4) X(0, 1, 512, 0, 4, 8) X(0, 1, 512, 1, 4, 2) X(0, 1, 512, 1, 4, 4) X(0, 1, 512, 1, 4, 8) \
+    X(0, 2, 512, 0, 2, 2) X(0, 2, 512, 1, 2, 2) X(0, 2, 512, 3, 2, 2) X(0, 2, 512, 2, 2, 2) X(0, 2, 512, 4, 2, 2) X(1, 2, 512, 3, 2, 2) X(1, 2, 512, 4, 2, 2) \
+    X(0, 2, 512, 0, 2, 4) X(0, 2, 512, 1, 2, 4) X(0, 2, 512, 3, 2, 4)
 #define EDS_FUSED6_BILINEAR_GROUP_INSTANCES(X)                                                                                        \
-    X(1, 1, 512, 0, 4, 2) X(1, 1, 512, 0, 4, 4) X(1, 1, 512, 0, 4, 8)
+    X(1, 1, 512, 0, 4, 2) X(1, 1, 512, 0, 4, 4) X(1, 1, 512, 0, 4, 8) X(1, 2, 512, 0, 2, 2)
 
 static inline bool eds_fused6_instance_exists(int S, int P, int T, int Q, int K, int bilinear_tu, int G) {
 #define EDS_INST_EQ_(s, p, t, q, k) if (S == s && P == p && T == t && Q == q && K == k) return true;
