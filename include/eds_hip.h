@@ -393,7 +393,7 @@ int eds_trk_timer_stop(eds_trk* h, float* elapsed_ms);      /* synchronises the 
  * [first, first+count) `reps` times back-to-back at the stored states and reports the mean
  * duration per launch in ms, measured with HIP events on the handle's stream. */
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms);
-/* ABI 5.  ONE kernel of the streaming path timed COLD: before every repetition 1 GiB is streamed through the caches (the Infinity
+/* ABI 5.  ONE kernel of the streaming path timed COLD: before every repetition 1 GiB is READ through the caches (the Infinity
  * Cache holds 256 MB), then the kernel runs between its own pair of HIP events; mean over `reps`.  which: 0 the residual/Jacobian
  * kernel, 1 the reduction kernel over the planes of a residual/Jacobian pass made beforehand. */
 int eds_trk_bench_kernel_cold(eds_trk* h, int first, int count, int ncols, int which, int reps, float* mean_ms);

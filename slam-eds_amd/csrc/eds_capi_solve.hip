@@ -533,9 +533,9 @@ int eds_trk_hbm_probe(eds_trk* h, size_t bytes, int reps, float* read_GBps, floa
     return EDS_OK;
 }
 
-// One kernel of the streaming path timed COLD: before every repetition 1 GiB is streamed through the caches (the Infinity Cache holds
-// 256 MB: the planes the previous kernel wrote, or the frames an earlier repetition read, are gone), then the kernel runs between its
-// own pair of events.  which: 0 the residual/Jacobian kernel, 1 the reduction kernel (over the planes of a residual/Jacobian pass made
+// One kernel of the streaming path timed COLD: before every repetition 1 GiB is READ through the caches (the Infinity Cache holds
+// 256 MB: the planes the previous kernel wrote, or the frames an earlier repetition read, are gone — and what replaced them is clean),
+// then the kernel runs between its own pair of events.  which: 0 the residual/Jacobian kernel, 1 the reduction kernel (over the planes of a residual/Jacobian pass made
 // beforehand).  Reports the mean over the repetitions.
 int eds_trk_bench_kernel_cold(eds_trk* h, int first, int count, int ncols, int which, int reps, float* mean_ms) {
     if (!h || !mean_ms) return fail(EDS_ERR_INVALID, "null argument");
@@ -565,7 +565,9 @@ int eds_trk_bench_kernel_cold(eds_trk* h, int first, int count, int ncols, int w
     float* sink = reinterpret_cast<float*>(reinterpret_cast<char*>(h->d_probe) + 2 * evict_bytes);
     double total = 0.0;
     for (int i = 0; i < reps; ++i) {
-        hipLaunchKernelGGL(eds_probe_kernel, dim3(8192), dim3(256), 0, h->st, a, b, sink, evict_bytes / 16, 1);
+        // (a READ-only pass: lines a copy had written would sit in the Infinity Cache dirty, and their write-back — forced by the very
+        // reads under test — would be billed to the kernel: 70 instead of 45 us for the reduction's 229 MB)
+        hipLaunchKernelGGL(eds_probe_kernel, dim3(8192), dim3(256), 0, h->st, a, b, sink, evict_bytes / 16, 0);
         EDS_HIP_TRY(hipEventRecord(h->ev0, h->st));
         if (which == 0) eds_launch_resjac(A, h->cfg.sampling, ncols, first, count, nchunk, h->st);
         else eds_launch_reduce(A, ncols, first, count, nseg, nb_red, cpb, h->st, h->knobs.reduce_ppl);
