@@ -682,8 +682,7 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
                             if (!late) break;
                             if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
                             __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                            for (int i = 0; i < PER; ++i)
+                            for (int i = 0; i < PER; ++i)           // (constant trip count: unrolled without being asked; with the pragma PER = 1 draws a warning)
                                 if ((unsigned)(v[i] >> 32) != tag)
                                     v[i] = __hip_atomic_load(mb + (wave + i * NW) * EDS_TEAM_GRANULES + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
@@ -719,7 +718,6 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
                 double cur_cost = sp.cur[EDS_RED_N6 - 1];
                 int mode = edsp::MODE_SOLVE, nk = 0, acc = 0, last_ok = 1;
                 bool decided = false;
-#pragma unroll
                 for (int g = 0; g < GROUPS; ++g) {
                     if (decided) break;
                     double s = 0.0;

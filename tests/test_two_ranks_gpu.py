@@ -63,7 +63,8 @@ def test_two_ranks_share_the_gpu_and_gather_config4(gpu, capi, synth, po, tmp_pa
     res.sort(key=lambda r: r["rank"])
     assert [(r["first"], r["count"]) for r in res] == [(0, 32), (32, 32)]
     assert all(r["same_every_step"] for r in res)
-    assert all(r["kernel"].startswith("eds_fused6_kernel<0, 1, 512,") and r["cus"] == 4 for r in res), res      # 32 alignments per rank: 4 CUs each
+    # 32 alignments per rank: teams of 4 CUs, in two candidate groups (round 5: eds_launch_rule.hpp) — 8 CUs each
+    assert all(r["kernel"].startswith("eds_fused6_kernel<0, 1, 512,") and r["kernel"].endswith(", 4, 2>") and r["cus"] == 8 for r in res), res
     tables = np.load(out)
     table = tables[0]
     assert table.shape == (64, 16) and table[:, 15].min() == 1.0
