@@ -65,6 +65,37 @@ typedef double acc4d __attribute__((ext_vector_type(4)));
 // as one team alone; the sums are added in the same member order (inside a member the wavefronts' tiles meet in LDS by fp64 atomics, so
 // the last bits vary from run to run — with and without groups).  12 evaluations become 6-7 rounds.  The residuals of the accepted point stay in
 // the registers of the group that evaluated it, which writes them at the end.
+// Entry e of the sums of the TEAM members whose mailboxes start at gb, added in member order: all granules of up to four members in
+// flight at once, the late ones asked for again together until every one carries this round's tag (or the time-out strikes).
+template <int TEAM>
+__device__ __forceinline__ double team12_collect(const unsigned long long* __restrict__ gb, const int e, const unsigned tag, const unsigned long long t_start, int* timeout) {
+    double tot = 0.0;
+    constexpr int GM = TEAM < 4 ? TEAM : (TEAM == 16 ? 8 : 4);
+#pragma unroll
+    for (int m0 = 0; m0 < TEAM; m0 += GM) {
+        unsigned long long v[2 * GM];
+#pragma unroll
+        for (int k = 0; k < 2 * GM; ++k)
+            v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            bool late = false;
+#pragma unroll
+            for (int k = 0; k < 2 * GM; ++k) late |= (unsigned)(v[k] >> 32) != tag;
+            if (!late) break;
+            if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { *timeout = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int k = 0; k < 2 * GM; ++k)
+                if ((unsigned)(v[k] >> 32) != tag)
+                    v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int m = 0; m < GM; ++m)
+            tot += __longlong_as_double((long long)(((v[2 * m + 1] & 0xffffffffull) << 32) | (v[2 * m] & 0xffffffffull)));
+    }
+    return tot;
+}
+
 template <int SAMPLING, int NTHR, int CAP, bool NC, int TEAM, int QUAD, int GROUPS = 1>
 __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const EdsFusedIn* __restrict__ in,
                                                               EdsFused12Out* __restrict__ out, int first, int iters, int loss_type,
@@ -513,31 +544,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             // sums entry e of the K members of group `grp`, added in member order (polls until every granule carries this round's tag)
             auto collect = [&](int grp, int e, double& tot) {
-                const unsigned long long* gb = mb + (size_t)grp * TEAM * EDS_TEAM12_GRANULES;
-                tot = 0.0;
-                constexpr int GM = TEAM < 4 ? TEAM : (TEAM == 16 ? 8 : 4);
-#pragma unroll
-                for (int m0 = 0; m0 < TEAM; m0 += GM) {
-                    unsigned long long v[2 * GM];
-#pragma unroll
-                    for (int k = 0; k < 2 * GM; ++k)
-                        v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    for (;;) {
-                        bool late = false;
-#pragma unroll
-                        for (int k = 0; k < 2 * GM; ++k) late |= (unsigned)(v[k] >> 32) != tag;
-                        if (!late) break;
-                        if (__builtin_amdgcn_s_memrealtime() - t_start > EDS_TEAM_TIMEOUT_TICKS) { s_timeout = 1; break; }
-                        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                        for (int k = 0; k < 2 * GM; ++k)
-                            if ((unsigned)(v[k] >> 32) != tag)
-                                v[k] = __hip_atomic_load(gb + (size_t)(m0 + (k >> 1)) * EDS_TEAM12_GRANULES + 2 * e + (k & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int m = 0; m < GM; ++m)
-                        tot += __longlong_as_double((long long)(((v[2 * m + 1] & 0xffffffffull) << 32) | (v[2 * m] & 0xffffffffull)));
-                }
+                tot = team12_collect<TEAM>(mb + (size_t)grp * TEAM * EDS_TEAM12_GRANULES, e, tag, t_start, &s_timeout);
             };
             if constexpr (GROUPS > 1) {
                 // ---- phase 1: the block costs of every group -----------------------------------------------------------------------------
