@@ -116,8 +116,12 @@ def pmc_traffic(kernel_prefix, a):
         if (c.get("alignments_per_gpu"), c.get("points"), c.get("iterations"), c.get("solver"), c.get("sampling"), c.get("exec")) != \
                 (a.batch, a.points, a.iters, a.solver, a.sampling, a.exec_) or c.get("frame") != [a.height, a.width]:
             continue
+        # (the profiler prints every template argument — "eds_fused6_kernel<0, 4, 512, 1, 1, 1>" with the defaulted GROUPS —, the library's
+        # eds_trk_last_launch only those that differ from the default: match the name, or the name continued by further arguments)
+        stem = kernel_prefix[:-1] if kernel_prefix.endswith(">") else kernel_prefix
         for k, v in t.get("kernels", {}).items():
-            if k.startswith(kernel_prefix) and v.get("fetch_kb") is not None and v.get("write_kb") is not None:
+            if (k == kernel_prefix or k.startswith(stem + ",") or (not kernel_prefix.endswith(">") and k.startswith(stem))) \
+                    and v.get("fetch_kb") is not None and v.get("write_kb") is not None:
                 best = {"bytes": (2.0 * v["fetch_kb"] + v["write_kb"]) * 1024.0, "raw_bytes": (v["fetch_kb"] + v["write_kb"]) * 1024.0,
                         "read_requests": (v.get("l2") or {}).get("TCC_EA0_RDREQ_sum"), "profiled_avg_us": v.get("avg_us"),
                         "source": os.path.relpath(f, ROOT)}
