@@ -472,7 +472,7 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
 // cache (CAP = 512) — the LDS that leaves holds the G sets of sums of a round
 #define EDS_FUSED12_GROUP_INSTANCES(X)                                                                                                \
     X(0, 512, 512, false, 8, 0, 2) X(0, 512, 512, false, 8, 0, 4) X(1, 512, 512, false, 8, 0, 2) X(1, 512, 512, false, 8, 0, 4)   \
-    X(0, 512, 512, false, 4, 0, 2) X(1, 512, 512, false, 4, 0, 2)
+    X(0, 512, 512, false, 4, 0, 2) X(1, 512, 512, false, 4, 0, 2) X(0, 512, 512, false, 4, 0, 4) X(1, 512, 512, false, 4, 0, 4)
 
 static inline bool eds_fused12_instance_exists(int S, int T, int CAP, int NC, int K, int Q, int G) {
 #define EDS_INST_EQ_(s, t, c, n, k, q) if (S == s && T == t && CAP == c && (NC != 0) == n && K == k && Q == q) return true;
