@@ -386,7 +386,9 @@ static inline void eds_ref12_plan_team(const EdsKnobs& kn, const EdsRef12In& in,
     int team = 1;
     if (team_ok) {
         team = (in.count <= 64 && in.maxN > 1024) ? 4 : 2;
-        if (in.count <= 16 && in.maxN > 1024) team = 8;                                           // a handful of alignments: 8 CUs each
+        // a handful of alignments: 8 CUs each — up to 8 of them; 9 .. 16 of at most 2 048 points run faster on 4 CUs x 4 candidate groups than
+        // on 8 x 2 (round 5, tools/bench_ref12_b16.py: 110.5 / 117.6 against 117.8 / 122.9 us at 9 / 16 alignments)
+        if (in.count <= (in.maxN <= 2048 && !kn.ref12_groups ? 8 : 16) && in.maxN > 1024) team = 8;
         if (in.maxN > 8192 && in.count * 16 <= EDS_RULE_TEAM12_MEMBERS) team = 16;                // the finer pyramid levels: ~1 000 points per CU
         else if (in.maxN > 4096 && in.count * 8 <= EDS_RULE_TEAM12_MEMBERS) team = 8;
     }

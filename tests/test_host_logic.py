@@ -325,8 +325,9 @@ def test_launch_rule_ref12_table(hl):
     assert K(_ref12(hl, count=512, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 0)                                       # tiles: the quad gather from 1 024 on
     assert K(_ref12(hl, count=256)) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, count=65, flags=TEAM_OK)) == (0, 512, 1408, 0, 1, 0)
     # (round 5: where candidate groups are formed a member's patch cache is 512 points; EDS_REF12_GROUPS=1 is the one-team launch)
-    assert K(_ref12(hl, count=1)) == (0, 512, 512, 0, 8, 0) and K(_ref12(hl, count=16)) == (0, 512, 512, 0, 8, 0)
+    assert K(_ref12(hl, count=1)) == (0, 512, 512, 0, 8, 0) and K(_ref12(hl, count=8)) == (0, 512, 512, 0, 8, 0) and K(_ref12(hl, count=16)) == (0, 512, 512, 0, 4, 0)
     assert K(_ref12(hl, "EDS_REF12_GROUPS=1", count=1)) == (0, 512, 1408, 0, 8, 0) and K(_ref12(hl, "EDS_REF12_GROUPS=1", count=16)) == (0, 512, 1408, 0, 8, 0)
+    assert K(_ref12(hl, maxN=3000, count=16)) == (0, 512, 512, 0, 8, 0) and _ref12(hl, maxN=3000, count=16)["G"] == 2       # members of 375 points: teams of 8 stay
     assert K(_ref12(hl, count=17)) == (0, 512, 512, 0, 4, 0) and K(_ref12(hl, count=33)) == (0, 512, 1408, 0, 4, 0) and K(_ref12(hl, count=64)) == (0, 512, 1408, 0, 4, 2)
     assert K(_ref12(hl, maxN=1000, count=8)) == (0, 512, 1408, 0, 2, 0) and K(_ref12(hl, maxN=500, count=8))[4] == 1
     assert K(_ref12(hl, maxN=16000, count=4)) == (0, 512, 1408, 0, 16, 0) and K(_ref12(hl, maxN=8000, count=64)) == (0, 512, 1408, 0, 8, 0)
@@ -338,7 +339,8 @@ def test_launch_rule_ref12_table(hl):
     assert K(_ref12(hl, "EDS_REF12_KERNEL=wide")) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, "EDS_REF12_KERNEL=paired", count=8)) == (0, 256, 320, 0, 1, 0)
     assert K(_ref12(hl, "EDS_REF12_TEAM=4", count=8, flags=COOLDOWN))[4] == 1 and K(_ref12(hl, count=8, flags=RETRY | TEAM_OK))[4] == 1
     # candidate groups (round 5): as many teams as give every workgroup a CU of its own; teams of 8 and 4 (lane gather) only
-    assert [_ref12(hl, count=c)["G"] for c in (1, 8, 9, 16, 17, 32, 33, 64, 65)] == [4, 4, 2, 2, 2, 2, 1, 1, 1]
+    assert [_ref12(hl, count=c)["G"] for c in (1, 8, 9, 16, 17, 32, 33, 64, 65)] == [4, 4, 4, 4, 2, 2, 1, 1, 1]
+    assert [_ref12(hl, count=c)["K"] for c in (1, 8, 9, 16, 17, 32, 33)] == [8, 8, 4, 4, 4, 4, 4]
     assert _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["G"] == 1 and _ref12(hl, "EDS_REF12_GROUPS=2", count=1)["G"] == 2 and _ref12(hl, "EDS_REF12_GROUPS=4", count=20)["G"] == 1
     assert _ref12(hl, maxN=4097, count=1)["G"] == 1 and _ref12(hl, maxN=4096, count=1)["G"] == 4 and _ref12(hl, count=1, bicubic=0)["G"] == 4
     assert _ref12(hl, count=1)["CAP"] == 512 and _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["CAP"] == 1408 and _ref12(hl, maxN=2049, count=20)["G"] == 1
