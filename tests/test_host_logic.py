@@ -341,7 +341,7 @@ def test_launch_rule_ref12_table(hl):
     # candidate groups (round 5): as many teams as give every workgroup a CU of its own; teams of 8 and 4 (lane gather) only
     assert [_ref12(hl, count=c)["G"] for c in (1, 8, 9, 16, 17, 32, 33, 64, 65)] == [4, 4, 4, 4, 2, 2, 1, 1, 1]
     assert [_ref12(hl, count=c)["K"] for c in (1, 8, 9, 16, 17, 32, 33)] == [8, 8, 4, 4, 4, 4, 4]
-    assert _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["G"] == 1 and _ref12(hl, "EDS_REF12_GROUPS=2", count=1)["G"] == 2 and _ref12(hl, "EDS_REF12_GROUPS=4", count=20)["G"] == 1
+    assert _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["G"] == 1 and _ref12(hl, "EDS_REF12_GROUPS=2", count=1)["G"] == 2 and _ref12(hl, "EDS_REF12_GROUPS=4", count=40)["G"] == 1
     assert _ref12(hl, maxN=4097, count=1)["G"] == 1 and _ref12(hl, maxN=4096, count=1)["G"] == 4 and _ref12(hl, count=1, bicubic=0)["G"] == 4
     assert _ref12(hl, count=1)["CAP"] == 512 and _ref12(hl, "EDS_REF12_GROUPS=1", count=1)["CAP"] == 1408 and _ref12(hl, maxN=2049, count=20)["G"] == 1
     assert _ref12(hl, count=1, nc=1)["G"] == 1 and _ref12(hl, count=4, flags=COOLDOWN | STRIPS)["G"] == 1 and _ref12(hl, maxN=1000, count=8)["G"] == 1
