@@ -163,10 +163,19 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
         }
     };
     std::vector<std::thread> pool;
-    for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
+    try {                                           // (no exception may cross the C ABI: threads the system refuses are simply not used)
+        pool.reserve(nthr);
+        for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
+    } catch (...) { }
+    const bool inline_work = pool.empty();          // not even one: this thread narrows every frame itself, just in front of its kernel
     int completed = 0;
     hipError_t err = hipSuccess;
     for (int i = 0; i < count && err == hipSuccess; ++i) {
+        if (inline_work) {
+            if (i >= S) { err = hipEventSynchronize(h->ev_bstage[i % S]); if (err != hipSuccess) break; }
+            narrow_band(frames[i], stage + (size_t)(i % S) * fe, fe);
+            ready[i].store(1, std::memory_order_release);
+        }
         for (int spin = 0; !ready[i].load(std::memory_order_acquire); ++spin) if (spin > 256) std::this_thread::yield();
         if (dma) {          // copy engine: pinned staging slot -> row-major scratch in HBM, then the store kernel reads HBM
             err = hipMemcpyAsync(h->d_bdev + (size_t)(i % 2) * fe, stage + (size_t)(i % S) * fe, fe * sizeof(float), hipMemcpyHostToDevice, h->st);
