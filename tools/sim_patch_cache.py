@@ -140,6 +140,18 @@ def main():
             m4 = (np.abs(w2r - r0) > 2) | (np.abs(w2c - c0) > 2)
             g4 += m4.sum(); l4 += np.array([lines_of_window(int(r), int(c), 2) for r, c in zip(r0[m4], c0[m4])]).sum()
             w2r[m4], w2c[m4] = r0[m4], c0[m4]
+            # round 5 (VERDICT r4 Next #2): what the LATENCY regime asks of a window — not gathers per point but whether a WAVEFRONT's pass
+            # (64 consecutive points of a team member) issues no gather at all; one missing point keeps the dependent gather on the chain
+            if k > 0:
+                for nm_, mm_ in (("slot", m), ("w1", m3), ("w2", m4)):
+                    w_ = mm_[: (N // 64) * 64].reshape(-1, 64).any(1)
+                    add(f"waves_with_a_gather {nm_}", w_.sum()); add(f"waves {nm_}", w_.size)
+                    if k >= npass - 3:
+                        add(f"late waves_with_a_gather {nm_}", w_.sum()); add(f"late waves {nm_}", w_.size)
+                    t_ = mm_[: (N // 512) * 512].reshape(-1, 512).any(1)          # ... and a team member of 512 points (its pass ends at its slowest wavefront)
+                    add(f"members_with_a_gather {nm_}", t_.sum()); add(f"members {nm_}", t_.size)
+                    if k >= npass - 3:
+                        add(f"late members_with_a_gather {nm_}", t_.sum()); add(f"late members {nm_}", t_.size)
             # P6
             for n in np.nonzero((ir != r0) | (ic != c0))[0]:
                 new_t = {(int(r0[n]) - 1 + i, int(c0[n]) - 1 + j) for i in range(4) for j in range(4)}
@@ -176,6 +188,10 @@ def main():
     for k in range(int(tot["passes"] / a.n + 0.5)):
         print(f"  pass {k:2d}: {per_pass[0, k] / (a.n * 2000):.2f} | {per_pass[1, k] / (a.n * 2000):.2f} | {per_pass[2, k] / (a.n * 2000):.2f}")
 
+    print("\nwavefront passes (64 consecutive points, passes 2..) that still issue a gather — the latency regime's question:")
+    for nm_, label in (("slot", "one slot"), ("w1", "+-1 px window (6x6)"), ("w2", "+-2 px window (8x8)")):
+        print(f"  {label:22s}: {tot['waves_with_a_gather ' + nm_] / tot['waves ' + nm_]:.3f} of all, {tot['late waves_with_a_gather ' + nm_] / tot['late waves ' + nm_]:.3f} of the last three passes; "
+              f"team members of 512 points: {tot['members_with_a_gather ' + nm_] / tot['members ' + nm_]:.3f} / {tot['late members_with_a_gather ' + nm_] / tot['late members ' + nm_]:.3f}")
 
 if __name__ == "__main__":
     main()
