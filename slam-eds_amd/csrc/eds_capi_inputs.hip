@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -40,8 +41,21 @@ static int unshare_frames(eds_trk* h, int first, int count) {
 // (Zen 4 / 5) have AVX-512, older ones AVX2: pick at run time (function multiversioning by hand, __builtin_cpu_supports).
 #if defined(__x86_64__)
 #include <immintrin.h>
+// (EDS_NARROW_NT: non-temporal stores into the staging buffer — the destination lines are written whole and read next by the GPU over
+// PCIe, never by this core: without the read-for-ownership of every line the band is ~25 % less memory traffic.  Weakly ordered: an
+// sfence closes every band before its progress is published.)
+#ifndef EDS_NARROW_NT
+#define EDS_NARROW_NT 1
+#endif
 __attribute__((target("avx512f"))) static void narrow_avx512(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
     size_t i = 0;
+    if (EDS_NARROW_NT && (reinterpret_cast<uintptr_t>(dst) & 31) == 0) {
+        for (; i + 16 <= n; i += 16) {
+            _mm256_stream_ps(dst + i, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i)));
+            _mm256_stream_ps(dst + i + 8, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i + 8)));
+        }
+        _mm_sfence();
+    } else
     for (; i + 16 <= n; i += 16) {
         _mm256_storeu_ps(dst + i, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i)));
         _mm256_storeu_ps(dst + i + 8, _mm512_cvtpd_ps(_mm512_loadu_pd(src + i + 8)));
@@ -50,6 +64,13 @@ __attribute__((target("avx512f"))) static void narrow_avx512(const double* __res
 }
 __attribute__((target("avx2"))) static void narrow_avx2(const double* __restrict__ src, float* __restrict__ dst, size_t n) {
     size_t i = 0;
+    if (EDS_NARROW_NT && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        for (; i + 8 <= n; i += 8) {
+            _mm_stream_ps(dst + i, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)));
+            _mm_stream_ps(dst + i + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4)));
+        }
+        _mm_sfence();
+    } else
     for (; i + 8 <= n; i += 8) {
         _mm_storeu_ps(dst + i, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i)));
         _mm_storeu_ps(dst + i + 4, _mm256_cvtpd_ps(_mm256_loadu_pd(src + i + 4)));
