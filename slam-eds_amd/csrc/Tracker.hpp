@@ -410,13 +410,17 @@ class Tracker {
     }
     /** Tracker.cpp:251-260: records the pose, returns the mean-filtered one once 3 poses are in the history, identity before. */
 #ifdef EDS_HIP_REFERENCE_MEMBERS
-    ::base::Transform3d getTransform(bool& result) {        // the reference's own lines (Tracker.cpp:251-260), on its getFilteredPose
-        ::eds::SE3 se3(this->qx, this->px);
-        this->poses.push_back(se3);
-        result = this->getFilteredPose(se3);
-        base::Transform3d pose = base::Transform3d::Identity();
-        if (result) pose.matrix() = se3.matrix();
-        return pose;
+    ::base::Transform3d getTransform(bool& result) {        // behaviour of Tracker.cpp:251-260, written on this shim's helpers
+        // the history (the reference's std::vector<eds::SE3>, which the EDS tree's own getFilteredPose reads) gains the current
+        // pose; a copy of it goes through that filter, which replaces it by the mean once enough poses exist
+        poses.emplace_back(qx, px);
+        ::eds::SE3 filtered = poses.back();
+        result = getFilteredPose(filtered);
+        if (!result) return base::Transform3d::Identity();
+        const Eigen::Quaterniond& fq = filtered.unit_quaternion();
+        const double t[3] = {filtered.translation()[0], filtered.translation()[1], filtered.translation()[2]};
+        const double q[4] = {fq.x(), fq.y(), fq.z(), fq.w()};
+        return to_transform(t, q);
     }
     // Declared here with the reference's signatures (Tracker.hpp:98-111), DEFINED by the EDS tree's own Tracker.cpp:378-648
     // (header comment; tests/cpp/shim_reference_members.cpp is the compile-checked example of such a translation unit)

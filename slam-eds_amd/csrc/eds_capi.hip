@@ -163,12 +163,14 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EDS_ERR_NO_DEVICE, "no HIP device visible; libeds_hip has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(EDS_ERR_INVALID, "device ordinal out of range");
+    int device_cus = EDS_RULE_CUS;
     {   // the code object holds gfx950 kernels only (include/eds_hip.h: EDS_ERR_NO_DEVICE = "no gfx950 device visible")
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return fail(EDS_ERR_HIP, "hipGetDeviceProperties failed");
         if (!std::strstr(prop.gcnArchName, "gfx950"))
             return fail(EDS_ERR_NO_DEVICE, std::string("device ") + std::to_string(cfg->device) + " is " + prop.gcnArchName +
                                                ", not gfx950 (MI355X); libeds_hip has no other code path and no CPU fallback");
+        if (prop.multiProcessorCount > 0) device_cus = prop.multiProcessorCount;      // (a partitioned or smaller gfx950 part: the candidate-group rule counts ITS CUs)
     }
     eds_trk* h = new (std::nothrow) eds_trk();
     if (!h) return fail(EDS_ERR_INVALID, "out of memory");
@@ -176,7 +178,13 @@ int eds_trk_create(const eds_trk_cfg* cfg, int batch, int max_points_, int H, in
     h->B = batch; h->Nmax = max_points_; h->H = H; h->W = W; h->dev = cfg->device;
     h->Hp = eds_frame_extent(H); h->Wp = eds_frame_extent(W);
     h->tiled = 1;
-    eds_knobs_from_env(&h->knobs);       // the ONLY place the library reads tuning variables from the environment (eds_launch_rule.hpp)
+    if (const char* bad = eds_knobs_from_env(&h->knobs)) {      // the ONLY place the library reads tuning variables from the environment (eds_launch_rule.hpp)
+        const char* v = getenv(bad);
+        std::string msg = std::string("environment variable ") + bad + "=" + (v ? v : "") + " is not a value that knob takes (include/eds_hip.h: eds_trk_set_knob)";
+        delete h;
+        return fail(EDS_ERR_INVALID, msg);
+    }
+    h->knobs.cus = device_cus;
     h->tiled = h->knobs.frame_rowmajor ? 0 : 1;
     h->Np = ((max_points_ + EDS_POINT_ALIGN - 1) / EDS_POINT_ALIGN) * EDS_POINT_ALIGN;
     h->max_seg = h->Np / EDS_TPB + 2 * EDS_MAX_BLOCKS + 2;

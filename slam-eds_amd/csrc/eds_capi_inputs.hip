@@ -189,7 +189,7 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
         for (int t = 0; t < nthr; ++t) pool.emplace_back(work);
     } catch (...) { }
     const bool inline_work = pool.empty();          // not even one: this thread narrows every frame itself, just in front of its kernel
-    int completed = 0;
+    int completed = 0, launched = 0;
     hipError_t err = hipSuccess;
     for (int i = 0; i < count && err == hipSuccess; ++i) {
         if (inline_work) {
@@ -202,11 +202,14 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
             err = hipMemcpyAsync(h->d_bdev + (size_t)(i % 2) * fe, stage + (size_t)(i % S) * fe, fe * sizeof(float), hipMemcpyHostToDevice, h->st);
             if (err == hipSuccess) err = hipEventRecord(h->ev_bstage[i % S], h->st);      // the staging slot is free once the copy is through
             eds_frame_store_whole(h, first + i, h->d_bdev + (size_t)(i % 2) * fe, h->st);
+            if (err == hipSuccess) err = hipGetLastError();                               // the launch's own error, asked for BEFORE any event is polled
         } else {            // the store kernel reads the staging slot over PCIe; consecutive frames alternate between two streams, so that one
             hipStream_t sx = two_streams && (i & 1) ? h->st_up : h->st;                  // kernel's tail overlaps the next one's ramp-up
             eds_frame_store_whole(h, first + i, h->d_bstage + (size_t)(i % S) * fe, sx);
-            err = hipEventRecord(h->ev_bstage[i % S], sx);
+            err = hipGetLastError();                // the launch's own error: checked here, not behind the polls below (hipEventQuery's hipErrorNotReady
+            if (err == hipSuccess) err = hipEventRecord(h->ev_bstage[i % S], sx);        // becomes the thread's last error on ROCm < 7: ADVICE r5)
         }
+        launched = i + 1;
         // staging slots whose kernel has finished go back to the workers; when none is free and frames are still to be staged: wait for the oldest
         while (completed <= i && hipEventQuery(h->ev_bstage[completed % S]) == hipSuccess) ++completed;
         if (completed + S <= i + 1 && i + 1 < count && err == hipSuccess) { err = hipEventSynchronize(h->ev_bstage[completed % S]); ++completed; }
@@ -218,8 +221,16 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
         err = hipEventRecord(h->ev_up, h->st_up);
         if (err == hipSuccess) err = hipStreamWaitEvent(h->st, h->ev_up, 0);
     }
-    if (err != hipSuccess) { hipStreamSynchronize(h->st); return fail(EDS_ERR_HIP, hipGetErrorString(err)); }
-    EDS_HIP_TRY(hipGetLastError());
+    if (err != hipSuccess) {
+        // Both streams are drained (kernels on st_up may still read the ring or write slots), and every slot whose store kernel was
+        // launched may hold a partial frame: it no longer counts as holding one, and its strip copy is out of date.
+        hipStreamSynchronize(h->st);
+        if (h->st_up) hipStreamSynchronize(h->st_up);
+        (void)hipGetLastError();
+        h->bstage_busy = false;
+        for (int s = first; s < first + launched; ++s) { h->slots[s].has_frame = false; ++h->slots[s].frame_version; }
+        return fail(EDS_ERR_HIP, hipGetErrorString(err));
+    }
     h->bstage_busy = true;
     for (int s = first; s < first + count; ++s) { h->slots[s].has_frame = true; ++h->slots[s].frame_version; }
     return EDS_OK;

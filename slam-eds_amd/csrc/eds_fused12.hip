@@ -589,6 +589,10 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                 if (gacc >= 0) {
                     for (int e = tid; e < nval; e += nthr) { double tot; collect(gacc, e, tot); *entry(e) = tot; }
                     __syncthreads();
+                    if (s_timeout) {            // the accepted group's 157 sums per block can time out as well: never linearise on a partial total
+                        if (tid == 0) { sv.termination = edss::TERM_FAILURE; sv.num_unsuccessful = -2; }       // (the host re-runs the range without teams)
+                        break;
+                    }
                     if (wave == 0) {
                         const int mode = edsc::coop12_linearise(sv, sums, work, s_pb[edsc::uniform_int(s_kacc)], edsc::uniform_int(s_linmode), lane);
                         edsc::Walk12 wk{edsc::W_RETURN, 0, 0};

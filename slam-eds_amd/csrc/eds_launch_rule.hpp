@@ -23,9 +23,10 @@
 #define EDS_RULE_TEAM12_MEMBERS 512    // = EDS_TEAM12_MEMBERS
 #define EDS_RULE_TEAM_MEMBERS 4096     // = EDS_TEAM_MEMBERS
 #define EDS_RULE_CACHE_CAP 2048        // = EDS_CACHE_CAP (eds_fused.hip)
-#define EDS_RULE_CUS 256               // compute units of the part (MI355X): candidate groups are formed only while every workgroup of the launch gets a CU of its own
+#define EDS_RULE_CUS 256               // compute units of an MI355X: the default of EdsKnobs::cus (the handle takes its device's real count at eds_trk_create)
 
 struct EdsKnobs {
+    int cus = EDS_RULE_CUS;     // (not a knob) compute units of the handle's device: candidate groups are formed only while every workgroup of the launch gets a CU of its own
     int ref12_exec = -1;        // EDS_REF12_EXEC      device | host            -1: the rule (device wherever the kernel covers the problem)
     int fused_threads = 0;      // EDS_FUSED_THREADS   64 .. 1024, multiple of 64   0: the rule
     int fused_ppt_set = 0;      // EDS_FUSED_PPT       points per lane; set but infeasible -> 0 (constants re-read per pass)
@@ -122,10 +123,14 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12") X("EDS_REF12_GROUPS")
 
 // the process environment, read once per handle (eds_trk_create)
-static inline void eds_knobs_from_env(EdsKnobs* k) {
-#define EDS_KNOB_ENV_(N) if (const char* v_ = getenv(N)) eds_knobs_set(k, N, v_);
+// Returns the name of the first variable whose value its knob does not take (nullptr: none) — eds_trk_create refuses to make a handle
+// whose environment it would otherwise silently ignore (EDS_NO_SPIN=yes used to "work").
+static inline const char* eds_knobs_from_env(EdsKnobs* k) {
+    const char* rejected = nullptr;
+#define EDS_KNOB_ENV_(N) if (const char* v_ = getenv(N)) { if (eds_knobs_set(k, N, v_) != 0 && !rejected) rejected = N; }
     EDS_KNOB_NAMES(EDS_KNOB_ENV_)
 #undef EDS_KNOB_ENV_
+    return rejected;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -281,8 +286,8 @@ static inline void eds_lm6_plan_finish(const EdsKnobs& kn, const EdsLm6In& in, i
             // (32 alignments: 52.5 against 64.1 us); beyond the CU count the workgroups queue and a round waits for the queue
             int g = 1;
             for (int c = 8; c >= 2; c >>= 1)
-                if (in.count * p.K * c <= EDS_RULE_CUS / 2) { g = c; break; }
-            if (g == 1 && in.count * p.K * 2 <= EDS_RULE_CUS) g = 2;
+                if (in.count * p.K * c <= kn.cus / 2) { g = c; break; }
+            if (g == 1 && in.count * p.K * 2 <= kn.cus) g = 2;
             if (kn.lm6_groups == 1 || kn.lm6_groups == 2 || kn.lm6_groups == 4 || kn.lm6_groups == 8) g = kn.lm6_groups;
             if (in.count * p.K * g > EDS_RULE_TEAM_MEMBERS || !eds_fused6_instance_exists(p.S, p.P, p.T, p.Q, p.K, p.bilinear_tu, g)) g = 1;     // the mailboxes' capacity; compiled?
             p.G = g;
@@ -437,7 +442,7 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
         if (q.K <= 1 || q.NC || q.T != 512 || (long long)in.maxN > 512ll * q.K) return;
         int g = 1;
         for (int c = 4; c >= 2; c >>= 1)
-            if (in.count * q.K * c <= EDS_RULE_CUS) { g = c; break; }
+            if (in.count * q.K * c <= kn.cus) { g = c; break; }
         if (kn.ref12_groups) g = kn.ref12_groups;
         if (g > 1 && (in.count * q.K * g > EDS_RULE_TEAM12_MEMBERS || !eds_fused12_instance_exists(q.S, q.T, 512, q.NC, q.K, q.Q, g))) g = 1;
         q.G = g;

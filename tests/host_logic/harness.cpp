@@ -158,6 +158,7 @@ static int parse_knobs(const char* spec, EdsKnobs* kn) {
         size_t b = s.find(';', a); if (b == std::string::npos) b = s.size();
         const std::string item = s.substr(a, b - a);
         const size_t eq = item.find('=');
+        if (eq != std::string::npos && item.substr(0, eq) == "cus") { kn->cus = std::atoi(item.substr(eq + 1).c_str()); a = b + 1; continue; }     // (not a knob: the device's CU count)
         if (eq != std::string::npos && eds_knobs_set(kn, item.substr(0, eq).c_str(), item.substr(eq + 1).c_str()) != 0) return -1;
         a = b + 1;
     }
@@ -193,6 +194,8 @@ int hl_ref12_rule(const char* knobs, const int32_t* in5, int flags, int32_t* out
     std::memcpy(out, o, sizeof(o));
     return 0;
 }
+// the environment as eds_trk_create reads it: the first variable whose value its knob refuses (nullptr: none)
+const char* hl_knobs_from_env(void) { EdsKnobs kn; return eds_knobs_from_env(&kn); }
 int hl_knob_set(const char* name, const char* value) { EdsKnobs kn; return eds_knobs_set(&kn, name, value); }
 int hl_strips_phases_for_budget(int wanted, long long slots, long long two_copies_bytes, long long free_bytes, int pct) {
     return eds_strips_phases_for_budget(wanted, (unsigned long long)slots, (unsigned long long)two_copies_bytes, (unsigned long long)free_bytes, pct);

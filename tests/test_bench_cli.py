@@ -40,11 +40,10 @@ def _load_bench():
     return m
 
 
-def test_physical_roofline_never_exceeds_one_and_matches_profiler_names(tmp_path, monkeypatch):
-    """bench.py's roofline block: `frac` is physical — corrected bytes of the committed PMC passes / kernel time / 8 TB/s —,
-    found under the profiler's full template names (which print defaulted arguments the library's own name omits), and falls back to the
-    must-move bytes when no pass of the workload is committed."""
-    import json
+def test_roofline_block_follows_the_contract_and_matches_profiler_names():
+    """bench.py's roofline block: `achieved` / `frac` = SURVEY 8d's ALGORITHMIC bytes per launch / kernel time / 8 TB/s (the contract's
+    recipe); `traffic` / `frac_physical` = corrected bytes of the committed PMC passes (never above 1), found under the profiler's full
+    template names (which print defaulted arguments the library's own name omits); null when no pass of the workload is committed."""
     import types
     b = _load_bench()
     a = types.SimpleNamespace(batch=4096, points=2000, iters=10, solver="lm6", sampling="bicubic", exec_="device", height=480, width=640)
@@ -52,13 +51,44 @@ def test_physical_roofline_never_exceeds_one_and_matches_profiler_names(tmp_path
     assert t and t["source"].startswith("profiles/traffic_r") and 1.5e10 < t["bytes"] < 2.1e10 and abs(t["read_requests"] * 128 / t["bytes"] - 1.0) < 0.05
     assert b.pmc_traffic("eds_fused6_kernel<0, 4, 512, 1, 1>", a)["bytes"] != b.pmc_traffic("eds_fused6_kernel<0, 4, 512, 3, 1>", a)["bytes"]
     assert b.pmc_traffic("eds_fused6_kernel<9, 9, 9, 9, 9>", a) is None
-    r = b.physical_roofline("eds_fused6_kernel<0, 4, 512, 1, 1>", 2.6, 4096 * 2000 * 11, 140, 84, a)
-    assert r["basis"].startswith("physical") and 0.7 < r["frac"] <= 1.0 and abs(r["achieved"] - r["traffic"] / 2.6e-3 / 1e9) < 1e-6
-    assert abs(r["frac_must_move"] - 4096 * 2000 * 11 * 84 / 2.6e-3 / 1e9 / 8000) < 1e-9 and r["frac_credit_8d"] > r["frac_must_move"]
-    r2 = b.physical_roofline("eds_no_such_kernel", 1.0, 1000, 140, 84, a)
-    assert r2["traffic"] is None and r2["frac"] == r2["frac_must_move"] and "must-move" in r2["basis"]
+    units = 4096 * 2000 * 11
+    r = b.roofline_block("eds_fused6_kernel<0, 4, 512, 1, 1>", 2.6, units, 140, 84, a)
+    assert r["algorithmic_bytes_per_launch"] == units * 140 and abs(r["achieved"] - units * 140 / 2.6e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert 0.7 < r["frac_physical"] <= 1.0 and abs(r["achieved_physical"] - r["traffic"] / 2.6e-3 / 1e9) < 1e-6
+    assert abs(r["frac_must_move"] - units * 84 / 2.6e-3 / 1e9 / 8000) < 1e-9 and r["frac"] > r["frac_must_move"]
+    assert r["traffic_over_algorithmic"] > 1.0                                          # wasted re-reads are visible at a glance
+    r2 = b.roofline_block("eds_no_such_kernel", 1.0, 1000, 140, 84, a)
+    assert r2["traffic"] is None and r2["frac_physical"] is None and r2["frac"] == 1000 * 140 / 1e-3 / 1e9 / 8000.0
     other = types.SimpleNamespace(**{**a.__dict__, "points": 1999})
     assert b.pmc_traffic("eds_fused6_kernel<0, 4, 512, 1, 1>", other) is None         # counters of another workload are never used
+
+
+def test_compact_record_fits_the_drivers_tail():
+    """BENCH_r05.json.parsed was null because the one JSON line had grown to 20 KB and the driver keeps an 8 KB tail.
+    The last stdout line is now `compact_record(full)`: built here from a canned full record (a real run's, tests/golden/), it must
+    stay under 4 KB, parse, and carry the contract's keys with `roofline` and `cpu_baseline`; a record bloated by an unforeseen long
+    string sheds its digests rather than outgrow the limit."""
+    import json
+    b = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_full_record.json")))
+    assert len(json.dumps(full)) > 15000
+    rec, line = b.compact_record(full)
+    assert len(line) < b.COMPACT_LIMIT <= 4096 and "\n" not in line
+    back = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity_max_se3", "reference_problem", "latency", "configs"):
+        assert k in back, k
+    assert back["config"]["workload"] and "model" not in back["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "frac_physical", "frac_must_move"):
+        assert k in back["roofline"], k
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-4
+    assert abs(back["roofline"]["achieved"] - back["roofline"]["algorithmic_bytes_per_launch"] / (back["roofline"]["kernel_ms"] * 1e-3) / 1e9) < 1.0
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert abs(back["value"] - full["value"]) / full["value"] < 1e-4 and abs(back["ms_per_step"] - full["ms_per_step"]) / full["ms_per_step"] < 1e-4
+    bloated = dict(full, latency=dict(full["latency"], slice_ms=1.0), configs={f"config{i}": full["configs"]["config2"] for i in range(40)})
+    _, line2 = b.compact_record(bloated)
+    assert len(line2) < b.COMPACT_LIMIT and json.loads(line2)["roofline"]["kernel"] == back["roofline"]["kernel"]
 
 
 def test_usable_cpus_honours_the_cgroup_quota(monkeypatch):

@@ -347,6 +347,20 @@ def test_launch_rule_ref12_table(hl):
     assert _ref12(hl, count=1, nc=1)["G"] == 1 and _ref12(hl, count=4, flags=COOLDOWN | STRIPS)["G"] == 1 and _ref12(hl, maxN=1000, count=8)["G"] == 1
 
 
+def test_launch_rule_counts_the_devices_own_cus(hl):
+    """the candidate-group rule formed groups for a 256-CU part whatever the device; the handle now carries its device's CU
+    count (hipDeviceProp_t.multiProcessorCount at eds_trk_create) and the rule never asks for more workgroups than that."""
+    assert _ref12(hl, count=8)["G"] == 4 and _ref12(hl, "cus=256", count=8)["G"] == 4
+    assert _ref12(hl, "cus=128", count=8)["G"] == 2 and _ref12(hl, "cus=64", count=8)["G"] == 1
+    for cus in (64, 128, 256):
+        for c in (1, 2, 8, 16, 32):
+            d = _ref12(hl, f"cus={cus}", count=c)
+            assert d["G"] == 1 or c * d["K"] * d["G"] <= cus, (cus, c, d)
+            e = _lm6(hl, f"cus={cus}", count=c)
+            assert e["G"] == 1 or c * e["K"] * e["G"] <= cus, (cus, c, e)
+    assert _lm6(hl, count=1)["G"] == 8 and _lm6(hl, "cus=32", count=1)["G"] == 4
+
+
 def test_launch_rule_never_leaves_the_instantiations_the_library_holds(hl):
     """Closure: over a sweep of shapes, samplers, policies and knob settings the rule always names a kernel that was compiled."""
     rng = np.random.default_rng(7)
@@ -395,6 +409,22 @@ def test_knob_names_and_strip_budget(hl):
     names = open(os.path.join(HERE, "..", "slam-eds_amd", "csrc", "eds_launch_rule.hpp")).read().split("#define EDS_KNOB_NAMES(X)")[1].split("\n\n")[0]
     assert sorted(table) == sorted(set(__import__("re").findall(r'X\("(EDS_[A-Z0-9_]+)"\)', names)))      # the table above covers every knob the library has
     assert hl.hl_knob_set(b"EDS_NO_SUCH_KNOB", b"1") == -1
+    # the environment at eds_trk_create: a value a knob refuses is REPORTED (the create fails with EDS_ERR_INVALID), not skipped
+    hl.hl_knobs_from_env.restype = C.c_char_p
+    saved = {k: os.environ.pop(k, None) for k in table}
+    try:
+        assert hl.hl_knobs_from_env() is None
+        os.environ["EDS_LM6_TEAM"] = "4"; os.environ["EDS_FUSED_REPORT"] = "1"
+        assert hl.hl_knobs_from_env() is None
+        os.environ["EDS_NO_SPIN"] = "yes"
+        assert hl.hl_knobs_from_env() == b"EDS_NO_SPIN"
+        os.environ["EDS_NO_SPIN"] = "1"; os.environ["EDS_LM6_TEAM"] = "0"
+        assert hl.hl_knobs_from_env() == b"EDS_LM6_TEAM"
+    finally:
+        for k in table:
+            os.environ.pop(k, None)
+            if saved[k] is not None:
+                os.environ[k] = saved[k]
     f = hl.hl_strips_phases_for_budget
     f.argtypes = [C.c_int, C.c_longlong, C.c_longlong, C.c_longlong, C.c_int]
     two = 2 * 1264128                                       # two column copies of one 640x480 frame (488 x 648 floats)

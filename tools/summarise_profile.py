@@ -101,5 +101,13 @@ lines += ["",
           "evaluation) plus the accepted copies: that is its WRITE_SIZE; `eds_fused6_kernel` (the headline) keeps them in registers and writes",
           "the residuals once."]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
-json.dump(out, open(os.path.join(dst, f"traffic_{tag}.json"), "w"), indent=1)
+tpath = os.path.join(dst, f"traffic_{tag}.json")
+if os.path.exists(tpath):                       # (the legs' section, written by tools/summarise_legs.py, survives a re-run of the headline's profile)
+    try:
+        prev = json.load(open(tpath))
+        if prev.get("workloads"):
+            out["workloads"] = prev["workloads"]
+    except Exception:
+        pass
+json.dump(out, open(tpath, "w"), indent=1)
 print("\n".join(lines))
