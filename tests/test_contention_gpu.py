@@ -1,0 +1,130 @@
+"""The CONTENDED path of the team / candidate-group launches, for real: a team needs its K x G workgroups co-resident
+and spinning on each other; the guard against members that never become resident is a time-out (eds_fused.hpp: EDS_TEAM_TIMEOUT_TICKS),
+after which the range is solved again with one CU per alignment and teams pause on the handle.  tools/stress_oversubscribe.py never
+produced that contention (0 pauses at 16-48 threads: small launches drain faster than they collide).  Here ONE thread keeps every CU
+busy — back-to-back launches of a 1 024-alignment batch on its own handle, 4 workgroups queued per CU — while several other threads
+launch the latency-regime shapes (B = 1..4, LM6 and REF12: teams x candidate groups, up to 32 workgroups per alignment) on theirs.
+A team's members then become resident one by one as batch workgroups retire, i.e. they really wait for each other.
+
+Checked: every result equals the same sequence run alone (LM6 bit for bit, REF12 to 1e-9 — its fp64 LDS atomics are not
+order-deterministic); the run reports how many calls saw a time-out / pause and the slowest call, and bounds it: a tracker must not take
+a stall of hundreds of solves for a 0.1 ms solve."""
+import importlib
+import threading
+import time
+
+import numpy as np
+import pytest
+
+capi = importlib.import_module("slam-eds_amd.capi")
+synth = importlib.import_module("slam-eds_amd.synth")
+
+pytestmark = pytest.mark.gpu
+
+H, W, N = 480, 640, 2000
+WORST_CALL_MS = 25.0            # bound on one contended call: the team time-out (5 ms) + the one-CU re-run behind a full chip
+
+
+def _small(tid):
+    """The latency-regime sequence of thread `tid`: (solver, B, alignments)."""
+    solver = capi.SOLVER_LM6 if tid % 2 == 0 else capi.SOLVER_REF12
+    B = 1 + (tid // 2) % 4
+    als = [synth.make_alignment(8800 + 8 * tid + b, H=H, W=W, N=N) for b in range(B)]
+    return solver, B, als
+
+
+def _run_small(tid, reps, gate=None, stop=None):
+    solver, B, als = _small(tid)
+    h = capi.Handle(capi.default_config(solver=solver, exec=capi.EXEC_DEVICE, num_blocks=1, max_num_iterations=10), B, N, H, W)
+    for b, a in enumerate(als):
+        h.set_alignment(b, a)
+    h.set_knob("EDS_FUSED_LAYOUT", "tiles")        # a new frame per call is the reference's pattern: the first-solve kernels
+    p0 = np.stack([a.p0 for a in als]); q0 = np.stack([a.q0 for a in als]); v0 = np.stack([a.v0 for a in als])
+    if gate is not None:
+        gate.wait()
+    out = {"solver": solver, "B": B, "tables": [], "residuals": [], "ms": [], "flags": [], "kernels": set()}
+    for _ in range(reps):
+        h.set_states(0, p0, q0, v0)
+        t = time.perf_counter()
+        h.optimize_batch(0, 0, B)
+        out["ms"].append(1e3 * (time.perf_counter() - t))
+        out["tables"].append(np.array(h.results(0, B)))
+        out["residuals"].append(h.residuals(0).copy())
+        out["flags"].append(max(h.info(b)["flags"] for b in range(B)))
+        out["kernels"].add(h.last_launch()["kernel"])
+    h.close()
+    return out
+
+
+def test_small_team_launches_behind_a_full_chip():
+    T, REPS = 6, 40
+    alone = [_run_small(t, 2) for t in range(T)]
+    for a in alone:                                  # alone, every one of them forms teams (that is what is being contended)
+        assert any("eds_fused" in k for k in a["kernels"]) and max(a["flags"]) == 0, (a["kernels"], a["flags"])
+    # the thread that keeps the chip full: 1 024 alignments (8 distinct, every slot its own frame), LM6, frames new for the solve
+    Bb = 1024
+    big_als = [synth.make_alignment(8700 + i, H=H, W=W, N=N) for i in range(8)]
+    hb = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=10), Bb, N, H, W)
+    f32 = [np.ascontiguousarray(a.frame, dtype=np.float32) for a in big_als]
+    for b in range(Bb):
+        a = big_als[b % 8]
+        hb.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy); hb.set_event_frame(b, f32[b % 8])
+    hb.set_knob("EDS_FUSED_LAYOUT", "tiles")
+    P0 = np.stack([big_als[b % 8].p0 for b in range(Bb)]); Q0 = np.stack([big_als[b % 8].q0 for b in range(Bb)]); V0 = np.stack([big_als[b % 8].v0 for b in range(Bb)])
+    hb.set_states(0, P0, Q0, V0); hb.optimize_batch(0, 0, Bb)
+    big_ref = np.array(hb.results(0, Bb))
+    stop = threading.Event()
+    big = {"launches": 0, "same": True, "error": None}
+
+    def keep_full():
+        try:
+            while not stop.is_set():
+                hb.set_states(0, P0, Q0, V0); hb.optimize_batch(0, 0, Bb)
+                big["launches"] += 1
+                big["same"] = big["same"] and bool(np.array_equal(np.array(hb.results(0, Bb)), big_ref))
+        except BaseException as e:          # noqa: BLE001 (reported by the main thread)
+            big["error"] = e
+
+    res = [None] * T
+    gate = threading.Barrier(T + 1)
+
+    def worker(t):
+        try:
+            res[t] = _run_small(t, REPS, gate)
+        except BaseException as e:          # noqa: BLE001
+            res[t] = e
+
+    tb = threading.Thread(target=keep_full); tb.start()
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for x in ths:
+        x.start()
+    time.sleep(0.05)                        # the batch is running before the small launches start
+    gate.wait()
+    for x in ths:
+        x.join(timeout=300)
+        assert not x.is_alive(), "a contended launch did not return"
+    stop.set(); tb.join(timeout=60)
+    hb.close()
+    assert big["error"] is None, big["error"]
+    assert big["launches"] >= 5 and big["same"], big                       # the chip really was kept busy, and the batch is undisturbed
+    flagged = timeouts = calls = 0
+    worst = 0.0
+    for t in range(T):
+        assert not isinstance(res[t], BaseException), res[t]
+        r, ref_tab, ref_r = res[t], alone[t]["tables"][0], alone[t]["residuals"][0]
+        for tab, rr, fl, ms in zip(r["tables"], r["residuals"], r["flags"], r["ms"]):
+            calls += 1
+            flagged += 1 if fl else 0
+            timeouts += 1 if fl & capi.INFO_TEAM_TIMEOUT else 0
+            worst = max(worst, ms)
+            if r["solver"] == capi.SOLVER_LM6:
+                assert np.array_equal(tab, ref_tab) and np.array_equal(rr, ref_r), (t, fl)
+            else:
+                np.testing.assert_allclose(tab[:, :13], ref_tab[:, :13], rtol=0, atol=1e-9)
+                assert np.array_equal(tab[:, 14:], ref_tab[:, 14:]), (t, fl)
+                np.testing.assert_allclose(rr, ref_r, rtol=0, atol=1e-9)
+    med = float(np.median([ms for t in range(T) for ms in res[t]["ms"]]))
+    print(f"\n[contention] {T} threads x {REPS} calls behind {big['launches']} launches of {Bb} alignments: {flagged} calls flagged (time-out or teams paused), "
+          f"{timeouts} team time-outs, median call {med:.3f} ms, slowest call {worst:.3f} ms; alone: "
+          f"{float(np.median([ms for a in alone for ms in a['ms']])):.3f} ms")
+    assert worst < WORST_CALL_MS, f"a contended call took {worst:.1f} ms"
