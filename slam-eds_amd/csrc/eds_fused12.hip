@@ -106,8 +106,17 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     static_assert(TEAM == 1 || !NC, "the NC residual needs a second exchange (block norm of the sampled brightness): no teams");
     static_assert(GROUPS == 1 || (TEAM > 1 && GROUPS <= EDS_NCAND), "candidate groups: teams only, at most one per prepared step");
     constexpr int VTEAM = TEAM * GROUPS;              // workgroups per alignment
+    // FULL (round 6): ONE alignment per CU with a patch-cache slot for EVERY point — 512 threads, CAP = 2 000 patches
+    // (128 000 B of rows + 8 000 B of keys of the CU's 163 840).  What is left has to hold the solver: ONE residual block (the
+    // reference problem of the bench; launches with more blocks take the other shapes), and the rows [J | r] of a wavefront go
+    // through the matrix core's staging area 16 at a time instead of 64 (four rounds of: 16 lanes store their rows, the wavefront
+    // reads them back as four operand pairs).
+    constexpr bool FULL = NTHR == 512 && CAP == 2000;
+    static_assert(!FULL || (TEAM == 1 && !NC && GROUPS == 1), "the full-cache shape: one CU per alignment, plain residual");
+    constexpr int MAXB = FULL ? 1 : EDS_DEV_MAX_BLOCKS;      // residual blocks this instantiation can hold
+    constexpr int SROWS = FULL ? 16 : 64;                   // rows of a wavefront staged at a time
     __shared__ int s_ticket, s_timeout;
-    __shared__ double s_gcost[GROUPS][EDS_DEV_MAX_BLOCKS];      // GROUPS > 1: ||r_b||^2 of every group's candidate (summed over its members)
+    __shared__ double s_gcost[GROUPS][MAXB];      // GROUPS > 1: ||r_b||^2 of every group's candidate (summed over its members)
     __shared__ int s_gacc, s_kacc, s_linmode;                   // ... the group / prepared step that was accepted this round (-1: none), how
     int team_slot = blockIdx.x, member = 0, group = 0, res_owner = 0;
     if (TEAM > 1) {
@@ -118,17 +127,21 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     }
     const int slot = first + team_slot;
     if (tid == 0 && member == 0 && group == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
+    if (nb > MAXB) {                    // (the launcher never asks for it: eds_ref12_force_feasible / the rule; a failed solve, not a wrong one)
+        if (tid == 0) { out[slot].failed = 1; out[slot].termination = edss::TERM_FAILURE; out[slot].t_end = __builtin_amdgcn_s_memrealtime(); }
+        return;
+    }
     unsigned pass_no = 0;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NTAP = (SAMPLING == 0) ? 16 : 4;
     __shared__ edss::Solver12 sv;
-    __shared__ edss::Sums12Dev sums;
+    __shared__ edss::Sums12T<MAXB> sums;
     __shared__ edsc::Work12 work;
     __shared__ double s_pb[EDS_NCAND][EDS_POSE_STRIDE];      // pose blocks of the prepared steps (eds_solver12_coop.hpp); s_pb[s_k] is being evaluated
     __shared__ edsc::Cand12 s_cand[EDS_NCAND];
     __shared__ edsc::Step12 s_step[EDS_NCAND];
     __shared__ int s_k, s_head, s_walk;
-    __shared__ float s_stage[(NTHR / 64)][64 * 17];
+    __shared__ float s_stage[(NTHR / 64)][SROWS * 17];
     __shared__ int s_state, s_accept;
     __shared__ __attribute__((aligned(16))) float s_patch[NTAP][CAP];
     static_assert(!QUAD || (SAMPLING == 0 && CAP % 4 == 0), "quad gather: bicubic, whole quads cached");
@@ -144,8 +157,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     // 512-thread shapes (whose LDS is full), keep the plane.
     constexpr int RC_CAP = (NTHR == 256) ? 2048 : 0;
     __shared__ float s_rc[RC_CAP > 0 ? RC_CAP : 1];
-    __shared__ double s_G[EDS_DEV_MAX_BLOCKS * 36];
-    __shared__ double s_nc[EDS_DEV_MAX_BLOCKS][8];    // NC residual: per block 1/||E||, then sum_j E_j J'_j / ||E||^3
+    __shared__ double s_G[MAXB * 36];
+    __shared__ double s_nc[NC ? MAXB : 1][8];    // NC residual: per block 1/||E||, then sum_j E_j J'_j / ||E||^3
 
     const double* __restrict__ gpb = A.pose + (size_t)slot * EDS_POSE_STRIDE;
     const double* __restrict__ Gg = A.G + (size_t)slot * EDS_MAX_BLOCKS * 36;
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     }
     static_assert(NTHR / 64 >= EDS_NCAND, "one wavefront per prepared step");
     for (int i = tid; i < CAP; i += nthr) s_cell[i] = 0x7fffffff;
-    for (int k = tid; k < (NTHR / 64) * 64 * 17; k += nthr) (&s_stage[0][0])[k] = 0.0f;    // columns 13..15 stay zero for good
+    for (int k = tid; k < (NTHR / 64) * SROWS * 17; k += nthr) (&s_stage[0][0])[k] = 0.0f;    // columns 13..15 stay zero for good
     for (int k = tid; k < (int)(sizeof(sums) / sizeof(double)); k += nthr)
         if (k > 0) reinterpret_cast<double*>(&sums)[k] = 0.0;                               // word 0 holds nb
     __syncthreads();
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #define EDS12_STAMP(k) do { } while (0)
 #define EDS12_PSTAMP(k) do { } while (0)
 #endif
-    float rkeep[2] = {0.0f, 0.0f};                           // candidate residuals of this lane's first two points (all sweeps write them)
+    float rkeep[FULL ? 4 : 2] = {};                          // candidate residuals of this lane's first two points (all sweeps write them; FULL: of all four)
     float racc[2] = {0.0f, 0.0f};                            // GROUPS > 1: ... of the accepted point, in the group that evaluated it
     for (;;) {
         EDS12_PSTAMP(5);                                     // residual copy of an accepted evaluation, loop back
@@ -255,7 +268,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
         };
         if (PREF) fetch_consts(lo, pc);
-        for (int j0 = lo; j0 < hi; j0 += 2 * nthr) {
+        // one step of the sweep: 2 x nthr points from j0 on (FULL: its 2 000 points are exactly two steps, and the candidate residuals of
+        // all four points of a lane stay in registers — picked by the wave-uniform step index, two selects per point)
+        auto sweep_step = [&](const int j0) {
             // phase A: two points per lane: constants from HBM/L2, projection, cache probe, gathers in flight
             float cc[2][9];
             if (PREF) {
@@ -470,10 +485,15 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         for (int k = 0; k < 6; ++k) x[k] = w * (st7[k * jplane] * inv_e - E * (float)nk[1 + k]);
                         x[12] = w * (m * inv_n - E * inv_e);
                     }
-                    if (valid && GROUPS == 1) {                       // candidate residual (candidate groups: registers only — the groups share the plane)
+                    if (valid && GROUPS == 1 && !FULL) {              // candidate residual (candidate groups: registers only — the groups share the plane)
                         if (RC_CAP > 0 && i - lo < RC_CAP) s_rc[i - lo] = x[12]; else A.mhat[base + i] = x[12];
                     }
-                    if (j0 == lo) rkeep[jj] = x[12];                  // (the first two of a lane also stay in registers: see the accept copy)
+                    if (FULL) {                                       // (all four of a lane: no plane, no LDS)
+                        const bool second = j0 != lo;
+                        rkeep[jj] = second ? rkeep[jj] : x[12];
+                        rkeep[2 + jj] = second ? x[12] : rkeep[2 + jj];
+                    }
+                    else if (j0 == lo) rkeep[jj] = x[12];             // (the first two of a lane also stay in registers: see the accept copy)
                 }
                 EDS12_PSTAMP(2);                                        // row formed, candidate residual stored
                 if (i_first < hi) {
@@ -486,21 +506,43 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
                         // (one block, plain residual: a lane without a point carries w = 0 and the constants of the slot's first point, so its row is
                         // all zeros already — no select in front of the 13 staging stores)
                         const bool on = (MODE == 0 && one_block) ? true : (valid && myb == b);
+                        if constexpr (SROWS == 64) {
 #pragma unroll
-                        for (int c = 0; c < 13; ++c) stage[lane * 17 + c] = on ? x[c] : 0.0f;
-                        EDS_WSYNC();
+                            for (int c = 0; c < 13; ++c) stage[lane * 17 + c] = on ? x[c] : 0.0f;
+                            EDS_WSYNC();
 #pragma unroll
-                        for (int mm = 0; mm < 16; mm += 2) {
-                            const float a0 = stage[(4 * mm + (lane >> 4)) * 17 + (lane & 15)];
-                            const float a1 = stage[(4 * mm + 4 + (lane >> 4)) * 17 + (lane & 15)];
-                            C = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0, (double)a0, C, 0, 0, 0);
-                            C2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1, (double)a1, C2, 0, 0, 0);
+                            for (int mm = 0; mm < 16; mm += 2) {
+                                const float a0 = stage[(4 * mm + (lane >> 4)) * 17 + (lane & 15)];
+                                const float a1 = stage[(4 * mm + 4 + (lane >> 4)) * 17 + (lane & 15)];
+                                C = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0, (double)a0, C, 0, 0, 0);
+                                C2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1, (double)a1, C2, 0, 0, 0);
+                            }
+                            EDS_WSYNC();
+                        } else {
+                            // SROWS rows at a time (the full-cache shape: its staging area is a quarter of a wavefront's rows): the lanes of
+                            // round q store, every lane reads the round's SROWS / 4 operand quadruples; same products, same order of the sums
+#pragma unroll
+                            for (int q = 0; q < 64 / SROWS; ++q) {
+                                if ((lane / SROWS) == q) {
+#pragma unroll
+                                    for (int c = 0; c < 13; ++c) stage[(lane % SROWS) * 17 + c] = on ? x[c] : 0.0f;
+                                }
+                                EDS_WSYNC();
+#pragma unroll
+                                for (int mm = 0; mm < SROWS / 4; mm += 2) {
+                                    const float a0 = stage[(4 * mm + (lane >> 4)) * 17 + (lane & 15)];
+                                    const float a1 = stage[(4 * mm + 4 + (lane >> 4)) * 17 + (lane & 15)];
+                                    C = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a0, (double)a0, C, 0, 0, 0);
+                                    C2 = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a1, (double)a1, C2, 0, 0, 0);
+                                }
+                                EDS_WSYNC();
+                            }
                         }
-                        EDS_WSYNC();
                     }
                 }
             }
-        }
+        };
+        for (int j0 = lo; j0 < hi; j0 += 2 * nthr) sweep_step(j0);
         EDS12_PSTAMP(3);                                                // staging + matrix core
         if (cb >= 0) flush(C + C2, cb);
         C = acc4d{0, 0, 0, 0}; C2 = acc4d{0, 0, 0, 0}; cb = -1;
@@ -708,8 +750,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             // each thread copies what it wrote itself; its first two points out of registers — a lone alignment on 8 CUs has nothing
             // else, and the load of the value just stored (an L2 round trip) sat at the head of the next evaluation
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) { const int i = lo + jj * nthr + tid; if (i < hi) A.r[base + i] = rkeep[jj]; }
-            for (int i = lo + 2 * nthr + tid; i < hi; i += nthr) A.r[base + i] = (RC_CAP > 0 && i - lo < RC_CAP) ? s_rc[i - lo] : A.mhat[base + i];
+            for (int jj = 0; jj < (FULL ? 4 : 2); ++jj) { const int i = lo + jj * nthr + tid; if (i < hi) A.r[base + i] = rkeep[jj]; }
+            if (!FULL)
+                for (int i = lo + 2 * nthr + tid; i < hi; i += nthr) A.r[base + i] = (RC_CAP > 0 && i - lo < RC_CAP) ? s_rc[i - lo] : A.mhat[base + i];
         }
         if (s_state == 2) break;
     }
@@ -777,7 +820,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     const EdsKnobs& kn = h->knobs;
     int maxN = 0;
     for (int s = first; s < first + count; ++s) maxN = std::max(maxN, h->slots[s].N);
-    const EdsRef12In rin{maxN, count, h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 1 : 0, h->cfg.nc ? 1 : 0, h->H, fb.pending_retry ? 1 : 0};
+    const EdsRef12In rin{maxN, count, h->cfg.sampling == EDS_SAMPLE_BICUBIC ? 1 : 0, h->cfg.nc ? 1 : 0, h->H, fb.pending_retry ? 1 : 0, nb};
     EdsRef12Plan pl;
     eds_ref12_plan_begin(kn, rin, pl);
     const bool team_ok = pl.wants_team && eds_team_allowed(&fb);         // the time-out policy of eds_fused.hpp

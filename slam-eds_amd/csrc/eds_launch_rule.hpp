@@ -81,7 +81,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_TEAM_WIDE")) return flag(&k->team_wide, -1);
     else if (!strcmp(name, "EDS_FUSED_GATHER")) { if (unset) k->gather = 0; else if (is("lane")) k->gather = 2; else if (is("quad")) k->gather = 1; else return -2; }
     else if (!strcmp(name, "EDS_FUSED_REPORT")) return flag(&k->report, 0);
-    else if (!strcmp(name, "EDS_REF12_KERNEL")) { if (unset) k->ref12_kernel = 0; else if (is("wide")) k->ref12_kernel = 1; else if (is("paired")) k->ref12_kernel = 2; else return -2; }
+    else if (!strcmp(name, "EDS_REF12_KERNEL")) { if (unset) k->ref12_kernel = 0; else if (is("wide")) k->ref12_kernel = 1; else if (is("paired")) k->ref12_kernel = 2; else if (is("full")) k->ref12_kernel = 3; else return -2; }
     else if (!strcmp(name, "EDS_REF12_TEAM")) { if (unset) k->ref12_team = 0; else if (one_of({1, 2, 4, 8, 16})) k->ref12_team = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_STRIPS_PHASES")) { if (unset) k->strips_phases = 0; else if (one_of({1, 2, 4})) k->strips_phases = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_STRIPS_POLICY")) { if (unset || is("reuse")) k->strips_policy = 0; else if (is("eager")) k->strips_policy = 1; else if (is("never")) k->strips_policy = 2; else return -2; }
@@ -368,7 +368,10 @@ struct EdsRef12In {
     int bicubic, nc;        // cfg.sampling == bicubic; cfg.nc (the PhotometricErrorNC residual)
     int H;
     int retry;
+    int nb;                 // residual blocks (cfg.num_blocks; 0 reads as 1): the full-cache shape holds the sums of one
 };
+#define EDS_RULE_FULL_CAP 2000         // = the CAP of the full-cache instantiations of eds_fused12_kernel (512 threads, one alignment per CU)
+static inline bool eds_ref12_full_fits(const EdsRef12In& in) { return in.bicubic && !in.nc && in.nb <= 1 && in.maxN <= EDS_RULE_FULL_CAP && in.H < 8000; }
 struct EdsRef12Plan {
     int wide, wants_team;               // begin
     int team, quad, strips_eligible;    // team
@@ -382,7 +385,7 @@ static inline void eds_ref12_plan_begin(const EdsKnobs& kn, const EdsRef12In& in
     // patch cache; beyond, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase overlaps
     // the other's point phase
     bool wide = in.count <= 256;
-    if (kn.ref12_kernel == 1) wide = true; else if (kn.ref12_kernel == 2) wide = false;
+    if (kn.ref12_kernel == 1 || kn.ref12_kernel == 3) wide = true; else if (kn.ref12_kernel == 2) wide = false;
     p.wide = wide;
     p.wants_team = wide && !in.nc && in.maxN > 512 && in.count <= EDS_RULE_TEAM12_SLOTS && !in.retry;
 }
@@ -427,6 +430,7 @@ static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In
     if (S != (in.bicubic ? 0 : 1) || (NC != 0) != (in.nc != 0)) return false;
     if (K > 1 && (in.nc || in.retry || in.count > EDS_RULE_TEAM12_SLOTS || in.count * K > EDS_RULE_TEAM12_MEMBERS)) return false;
     if (Q != 0 && in.H >= 8000) return false;
+    if (CAP == EDS_RULE_FULL_CAP && !eds_ref12_full_fits(in)) return false;          // one residual block, every point cached
     return true;
 }
 
@@ -463,6 +467,8 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     if (p.team >= 8 || !in.bicubic) p.Q = 0;
     else p.Q = strips ? 2 : (quad ? 1 : 0);
     if (p.team == 1 && !(in.bicubic && strips)) p.NC = in.nc ? 1 : 0;
+    // EDS_REF12_KERNEL=full (round 6, A/B knob): one alignment per CU with a cache slot for every point (quad gather, tiles or strips)
+    if (kn.ref12_kernel == 3 && p.team == 1 && eds_ref12_full_fits(in)) { p.T = 512; p.CAP = EDS_RULE_FULL_CAP; p.Q = strips ? 2 : 1; p.NC = 0; }
     groups_for(p);
 }
 
@@ -473,7 +479,8 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     X(0, 512, 1408, false, 1, 2) X(0, 512, 1408, false, 1, 1) X(0, 512, 1408, true, 1, 1) X(0, 512, 1408, false, 1, 0)              \
     X(0, 512, 1408, true, 1, 0) X(1, 512, 1408, false, 1, 0) X(1, 512, 1408, true, 1, 0)                                            \
     X(0, 256, 320, false, 1, 2) X(0, 256, 320, false, 1, 1) X(0, 256, 320, true, 1, 1) X(0, 256, 320, false, 1, 0)                  \
-    X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)
+    X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)                                               \
+    X(0, 512, 2000, false, 1, 1) X(0, 512, 2000, false, 1, 2)
 
 // ... and the candidate-group instantiations X(S, T, CAP, NC, K, Q, G), G > 1: a member's slice is at most 512 points here, so is its patch
 // cache (CAP = 512) — the LDS that leaves holds the G sets of sums of a round

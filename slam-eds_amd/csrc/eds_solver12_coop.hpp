@@ -167,7 +167,8 @@ __device__ inline int coop12_decide_head(edss::Solver12& sv, const int nb, const
 
 // Second half: Solver12::linearise at the (new) accepted point, from the per-block sums S of the evaluation that was accepted (W.r1, W.cost,
 // W.rel: left by the head).  `pb`: the pose block those sums were evaluated at.  mode: M_LIN_ITER0 | M_LIN_ACCEPT; returns it, or M_RETURN.
-__device__ inline int coop12_linearise(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int mode, const int lane) {
+template <class SUMS>              // edss::Sums12T<MAXB>: the sums of up to MAXB residual blocks (the full-cache shape of eds_fused12_kernel holds one)
+__device__ inline int coop12_linearise(edss::Solver12& sv, const SUMS& S, Work12& W, const double* pb, const int mode, const int lane) {
     using namespace edss;
     const int nb = S.nb;
     {
@@ -268,7 +269,8 @@ __device__ inline int coop12_linearise(edss::Solver12& sv, const edss::Sums12Dev
     return mode;
 }
 
-__device__ inline int coop12_decide(edss::Solver12& sv, const edss::Sums12Dev& S, Work12& W, const double* pb, const int lane) {
+template <class SUMS>
+__device__ inline int coop12_decide(edss::Solver12& sv, const SUMS& S, Work12& W, const double* pb, const int lane) {
     const int mode = coop12_decide_head(sv, S.nb, S.s, W, lane);
     if (mode == M_RETURN || mode == M_ADVANCE) return mode;
     return coop12_linearise(sv, S, W, pb, mode, lane);

@@ -183,7 +183,7 @@ int hl_lm6_rule(const char* knobs, const int32_t* in7, int flags, int32_t* out) 
 int hl_ref12_rule(const char* knobs, const int32_t* in5, int flags, int32_t* out) {
     EdsKnobs kn;
     if (parse_knobs(knobs, &kn)) return -1;
-    const EdsRef12In in{in5[0], in5[1], in5[2], in5[3], in5[4], (flags & 1) ? 1 : 0};
+    const EdsRef12In in{in5[0], in5[1], in5[2], in5[3], in5[4], (flags & 1) ? 1 : 0, (flags >> 8) & 0xff};       // flags bits 8..15: residual blocks (0 reads as 1)
     EdsRef12Plan p;
     eds_ref12_plan_begin(kn, in, p);
     const int team_ok = p.wants_team && (flags & 2);
