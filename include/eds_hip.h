@@ -44,7 +44,7 @@ extern "C" {
  * 5 (round 5): new entry points eds_trk_bench_kernel_cold, eds_trk_hbm_probe (measurement), eds_trk_set_event_frames (many host frames,
  * narrowed on a thread pool), eds_trk_kernel_instances (the compiled instantiation lists); new knob EDS_LM6_GROUPS (candidate groups
  * of the team kernel).  Nothing was removed or re-ordered. */
-#define EDS_HIP_ABI_VERSION 5
+#define EDS_HIP_ABI_VERSION 6
 #define EDS_MAX_LEVELS 8
 
 typedef enum eds_status {
@@ -127,9 +127,9 @@ typedef struct eds_trk_info {
                                      * eds_trk_last_launch().timing_source says which one a call used) */
 } eds_trk_info;
 
-#define EDS_INFO_TEAM_TIMEOUT 1      /* this solve was launched on several CUs per alignment, a team did not assemble within 50 ms (something
+#define EDS_INFO_TEAM_TIMEOUT 1      /* this solve was launched on several CUs per alignment, a team did not assemble within 5 ms (something
                                      * else held the GPU), and the range was solved again with one CU per alignment: the result is valid, the
-                                     * call took >= 50 ms, and the handle forms no teams for its next launches (it re-arms by itself) */
+                                     * call took >= 5 ms, and the handle forms no teams for its next launches (it re-arms by itself) */
 #define EDS_INFO_TEAMS_PAUSED 2     /* solved with one CU per alignment because an earlier time-out's cool-down is still running */
 
 typedef struct eds_trk eds_trk;     /* opaque */
@@ -268,6 +268,10 @@ int eds_trk_optimize(eds_trk* h, int slot, int level, double p[3], double q_xyzw
  * handle's stream; eds_trk_sync waits.  Results via eds_trk_get_state / eds_trk_get_info. */
 int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count);
 int eds_trk_sync(eds_trk* h);
+/* ABI 6: eds_trk_optimize_batch + eds_trk_sync in ONE call (what Tracker::optimize does for its single alignment, Tracker.cpp:201-203,
+ * for a range of slots): launch, wait, collect.  A caller with several threads in a managed runtime (the Python binding under its
+ * interpreter lock) then has no gap of its own between launch and wait. */
+int eds_trk_optimize_batch_wait(eds_trk* h, int level, int first, int count);
 int eds_trk_get_info(eds_trk* h, int slot, eds_trk_info* info);
 /* Per-iteration trace of the last 6-DoF solve of a slot: increments (iters x 6), cost at the
  * candidate (iters), accepted flags (iters).  Returns the number of iterations (<= max_iters) or <0. */

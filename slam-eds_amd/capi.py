@@ -36,7 +36,7 @@ EXPORTS = (
     "eds_trk_set_undistort_map", "eds_trk_set_undistort_map_sized", "eds_trk_build_event_frame", "eds_trk_build_event_frames", "eds_trk_build_event_frame_batch", "eds_trk_build_event_frames_aos", "eds_trk_build_event_frames_aos_timed", "eds_event_times_aos",
     "eds_trk_get_event_frame", "eds_trk_share_event_frame",
     "eds_trk_set_state", "eds_trk_get_state", "eds_trk_set_states", "eds_trk_get_states", "eds_trk_get_results",
-    "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch",
+    "eds_trk_eval", "eds_trk_optimize", "eds_trk_optimize_batch", "eds_trk_optimize_batch_wait",
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param", "eds_trk_residuals_and_loss",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
@@ -185,6 +185,7 @@ def lib():
         L.eds_trk_eval.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
         L.eds_trk_optimize.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, C.POINTER(Info)]
         L.eds_trk_optimize_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.eds_trk_optimize_batch_wait.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.eds_trk_sync.argtypes = [C.c_void_p]
         L.eds_trk_get_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(Info)]
         L.eds_trk_get_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _ip]
@@ -481,9 +482,10 @@ class Handle:
 
     def optimize_batch(self, level=0, first=0, count=None, sync=True):
         count = self.batch - first if count is None else count
-        _check(lib().eds_trk_optimize_batch(self._h, level, first, count))
-        if sync:
-            self.sync()
+        if sync:            # ABI 6: launch + wait + collect in one call (no interpreter between them)
+            _check(lib().eds_trk_optimize_batch_wait(self._h, level, first, count))
+        else:
+            _check(lib().eds_trk_optimize_batch(self._h, level, first, count))
 
     def sync(self):
         _check(lib().eds_trk_sync(self._h))

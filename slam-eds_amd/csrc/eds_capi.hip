@@ -121,6 +121,14 @@ void free_all(eds_trk* h) {
 int eds_internal_fail(int code, const char* msg) { return fail(code, msg ? msg : ""); }
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count) { return solve_host(h, level, first, count); }
 
+// (C++ linkage: called from the other translation units of the library — eds_fused.hpp)
+int eds_stream_idle(eds_trk* h) {
+    if (!h->stream_dirty) return EDS_OK;
+    h->stream_dirty = false;
+    EDS_HIP_TRY(hipStreamSynchronize(h->st));
+    return EDS_OK;
+}
+
 extern "C" {
 
 int eds_abi_version(void) { return EDS_HIP_ABI_VERSION; }
@@ -357,9 +365,31 @@ int eds_trk_get_results(eds_trk* h, int first, int count, double* t) {
 // Waits for the handle's stream.  A launch of a few alignments is over in 0.1-0.3 ms, and a blocking wait adds the wake-up of the
 // calling thread to every such call; the latency regime therefore polls the stream (hipStreamQuery) for up to EDS_SPIN_US before
 // it blocks.  Batches block right away: nobody should burn a core for milliseconds.
+// Round 6: every workgroup of a small solve ends by storing the launch's tag into its own word of pinned host memory, behind a
+// system-scope fence over everything it wrote (result record, residual mirror) — so the host can see the solve finish WITHOUT the runtime:
+// no end-of-kernel cache release, no completion signal, no hipStreamQuery per poll (B = 1: -6 .. -8 us per call).  The stream is then not
+// known to be idle (the trace copy behind the record may be microseconds behind; it is only ever read through the stream):
+// h->stream_dirty says so, eds_stream_idle() waits.  A word that never arrives (a workgroup that never ran) ends the poll after EDS_SPIN_US.
 #define EDS_SPIN_US 500.0
 static hipError_t wait_stream(eds_trk* h) {
-    const bool spin = h->cfg.exec == EDS_EXEC_DEVICE && h->fused.pending_count > 0 && h->fused.pending_count <= 64 && !h->knobs.no_spin;
+    const EdsFusedBuffers& fb = h->fused;
+    const bool spin = h->cfg.exec == EDS_EXEC_DEVICE && fb.pending_count > 0 && fb.pending_count <= 64 && !h->knobs.no_spin;
+    if (spin && fb.pending_vteam > 0 && fb.h_done) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const unsigned tag = fb.done_seq;
+        const unsigned* w = fb.h_done + (size_t)fb.pending_first * EDS_DONE_WORDS;
+        int s = 0, m = 0;                                   // next word to see: alignment s of the range, workgroup m
+        for (unsigned it = 0;; ++it) {
+            while (s < fb.pending_count && __atomic_load_n(w + (size_t)s * EDS_DONE_WORDS + m, __ATOMIC_ACQUIRE) == tag)
+                if (++m >= fb.pending_vteam) { m = 0; ++s; }
+            if (s >= fb.pending_count) { h->stream_dirty = true; return hipSuccess; }
+            if ((it & 63u) == 63u && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > EDS_SPIN_US) break;
+            __builtin_ia32_pause();
+        }
+        h->stream_dirty = false;
+        return hipStreamSynchronize(h->st);
+    }
+    h->stream_dirty = false;
     if (spin) {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {

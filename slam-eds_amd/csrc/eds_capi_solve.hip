@@ -247,8 +247,8 @@ int solve_host(eds_trk* h, int level, int first, int count) {
 int materialise_residuals(eds_trk* h, int slot) {
     Slot& s = h->slots[slot];
     if (!s.res_on_device) return EDS_OK;
-    if (s.res_in_hostmap) {             // the kernel left a copy in pinned host memory: no HIP call at all
-        const float* r = h->h_rmap + (size_t)slot * h->Np;
+    if (s.res_in_hostmap) {             // the kernel left a copy in pinned host memory: no HIP call at all (a solve seen complete through its
+        const float* r = h->h_rmap + (size_t)slot * h->Np;      // workgroups' done words has the mirror behind those words: eds_capi.hip wait_stream)
         s.residuals.resize(s.N);
         for (int i = 0; i < s.N; ++i) s.residuals[i] = r[i];
         s.res_on_device = false; s.res_in_hostmap = false;
@@ -353,6 +353,10 @@ int eds_trk_optimize(eds_trk* h, int slot, int level, double p[3], double q[4], 
 }
 
 int eds_trk_optimize_batch(eds_trk* h, int level, int first, int count) { return solve_range(h, level, first, count); }
+int eds_trk_optimize_batch_wait(eds_trk* h, int level, int first, int count) {
+    const int rc = solve_range(h, level, first, count);
+    return rc != EDS_OK ? rc : eds_trk_sync(h);
+}
 
 int eds_trk_get_residuals(eds_trk* h, int slot, double* r) {
     int rc = check_slot(h, slot);

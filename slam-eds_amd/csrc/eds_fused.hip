@@ -932,7 +932,7 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
         for (int j = 0; j < NREG; ++j) {
             const int i = tid + j * nthr;
             if (i < N && group == res_owner) A.r[base + i] = racc[j];
-            if (TEAM > 1 && A.rmap && i < N && group == res_owner) A.rmap[base + i] = racc[j];      // the caller reads them next (Tracker.cpp:223-233)
+            if (A.rmap && i < N && group == res_owner) A.rmap[base + i] = racc[j];      // the caller reads them next (Tracker.cpp:223-233)
         }
     }
 #ifdef EDS_FUSED_STAMPS
@@ -947,8 +947,17 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
 #endif
 #endif
 
+    // small solves: this workgroup's completion word (EdsArrays::done) — every thread's writes are out at system scope first
+    unsigned* const done_word = A.done ? A.done + (size_t)slot * EDS_DONE_WORDS + (TEAM > 1 ? group * TEAM + member : 0) : nullptr;
+    // (every wavefront waits for ITS stores to be acknowledged — the mirror is uncached host memory, nothing sits in the L2 — and the
+    // barrier hands that to thread 0, whose release store at system scope follows; a __threadfence_system() per thread instead wrote the
+    // L2 back and invalidated it on every wavefront of up to 32 workgroups: +2.7 us per solve, measured)
+    if (done_word) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
     __syncthreads();                    // the solver state as its last writer left it
-    if (TEAM > 1 && (member != 0 || group != 0)) return;    // every member holds the same result; member 0 (of group 0) reports it
+    if (TEAM > 1 && (member != 0 || group != 0)) {          // every member holds the same result; member 0 (of group 0) reports it
+        if (tid == 0 && done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (tid == 0) {
         EdsFusedOut& O = out[slot];
         for (int i = 0; i < 3; ++i) O.p[i] = sv.p[i];
@@ -958,7 +967,9 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
         int na = 0;
         for (int k = 0; k < sv.ntrace; ++k) na += sv.tr_acc[k];
         O.naccepted = na;
-        O.t_end = __builtin_amdgcn_s_memrealtime();
+        // the LAST word of the record, released at system scope: a host that sees it non-zero sees the whole record (wait_stream polls it)
+        __hip_atomic_store(&O.t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // full solver state (trace) to HBM, cooperatively
     {
@@ -1021,6 +1032,9 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     if (hipHostGetDevicePointer((void**)&fb->d_in, fb->h_in, 0) != hipSuccess) return -1;
     if (hipHostGetDevicePointer((void**)&fb->d_out, fb->h_out, 0) != hipSuccess) return -1;
     if (hipHostGetDevicePointer((void**)&fb->d_out12, fb->h_out12, 0) != hipSuccess) return -1;
+    if (hipHostMalloc((void**)&fb->h_done, sizeof(unsigned) * EDS_DONE_WORDS * (size_t)B, hipHostMallocMapped) != hipSuccess) return -1;
+    if (hipHostGetDevicePointer((void**)&fb->d_done, fb->h_done, 0) != hipSuccess) return -1;
+    std::memset(fb->h_done, 0, sizeof(unsigned) * EDS_DONE_WORDS * (size_t)B);
     // team launches (eds_fused6_kernel TEAM > 1): granule mailboxes of EDS_TEAM_SLOTS alignments + the ticket counter
     if (hipMalloc((void**)&fb->d_mail, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
     if (hipMemset(fb->d_mail, 0, EDS_TEAM_MAIL_BYTES) != hipSuccess) return -1;
@@ -1061,6 +1075,7 @@ void eds_fused_free(EdsFusedBuffers* fb) {
     if (fb->d_mail12) hipFree(fb->d_mail12);
     if (fb->d_ticket) hipFree(fb->d_ticket);
     if (fb->h_out12) hipHostFree(fb->h_out12);
+    if (fb->h_done) hipHostFree(fb->h_done);
     *fb = EdsFusedBuffers();
 }
 
@@ -1115,8 +1130,12 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     // after EDS_TEAM_TIMEOUT_TICKS and eds_fused_collect re-runs the range without teams (tests/test_team_timeout_gpu.py)
     const int drop = kn.team_drop ? 1 : 0;
     // team launches (the latency regime) write the kept residuals into the pinned mirror themselves: one launch less behind the solve
-    const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
+    // (round 6: so do the one-CU kernels that keep their points in registers, when the launch reports through done words)
+    const bool done_words = fb.pending_ticks && kn.poll_results && !drop && pl.kind != EDS_K6_STREAM && team * groups <= EDS_DONE_WORDS;
+    const bool rmap_in_kernel = (team > 1 || (done_words && pl.kind == EDS_K6_FUSED && pl.P > 0)) && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
     A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
+    fb.pending_vteam = 0;
+    if (done_words) { if (++fb.done_seq == 0u) fb.done_seq = 1u; A.done = fb.d_done; A.done_tag = fb.done_seq; fb.pending_vteam = team * groups; }
     fb.pending_team = team; fb.pending_level = level;
     if (pl.kind != EDS_K6_STREAM && !eds_fused6_instance_exists(pl.S, pl.P, pl.T, pl.Q, pl.K, pl.bilinear_tu, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
@@ -1168,7 +1187,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
             }
             const unsigned ticket_base = fb.ticket_base;
             fb.ticket_base += (unsigned)(cnt * team * groups);
-            for (int s = f0; s < f0 + cnt; ++s) fb.h_out[s].failed = 2;      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
+            for (int s = f0; s < f0 + cnt; ++s) { fb.h_out[s].failed = 2; fb.h_out[s].t_end = 0; }      // "no result yet": what a workgroup that never ran leaves behind reads as a time-out
             launch(f0, cnt, ticket_base);
         }
     } else if (pl.kind == EDS_K6_STREAM) {
@@ -1176,10 +1195,12 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
         fb.last_workgroups = count; fb.last_team = 1; fb.last_layout = 1;
         eds_stream6_launch(A, h->cfg.sampling, pl.wide ? 1 : 0, fb.d_in, fb.d_out, fb.d_sv, first, count, iters, damped, h->cfg.lambda0, tau, nb, h->st);
     } else {
+        if (fb.pending_ticks) for (int s = first; s < first + count; ++s) fb.h_out[s].t_end = 0;      // (the completion word wait_stream polls)
         launch(first, count, 0u);
     }
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
+    if (fb.pending_host_r && !rmap_in_kernel) fb.pending_vteam = 0;      // a mirror launch follows the solve: only the stream says when IT is through
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

@@ -32,7 +32,7 @@ struct EdsFused12Out {         // compact result of a REF12 solve
 
 // ---- teams: several workgroups (CUs) per alignment, partial sums exchanged as tagged 8-byte granules (eds_fused.hip) -----------
 #define EDS_TEAM_GRANULES 64                      // LM6, per member and parity: 56 used (28 doubles as two halves), padded to one 512-byte block
-#define EDS_TEAM_TIMEOUT_TICKS 5000000ull         // 50 ms of s_memrealtime
+#define EDS_TEAM_TIMEOUT_TICKS 500000ull          // 5 ms of s_memrealtime (round 6: 50 before — a tracker cannot take a 50 ms stall on a 0.1 ms solve; tests/test_contention_gpu.py)
 #define EDS_TEAM_COOLDOWN 16                      // solves without teams after a time-out (doubling up to EDS_TEAM_COOLDOWN_MAX while they recur)
 #define EDS_TEAM_COOLDOWN_MAX 1024
 #define EDS_TEAM_REARM_CLEAN 64                   // clean team launches after which a new time-out counts as a first one again
@@ -70,6 +70,9 @@ struct EdsFusedBuffers {
     bool pending_paused = false;            // the launch in flight would have used teams but for the cool-down
     int pending_team = 1, pending_level = 0;
     bool pending_ticks = false;    // device time from the kernels' own time stamps (no event records around the launch)
+    unsigned *h_done = nullptr, *d_done = nullptr;   // pinned, device-mapped [B][EDS_DONE_WORDS]: one completion word per workgroup of a small solve
+    unsigned done_seq = 0;         // the tag of the launch in flight (never 0)
+    int pending_vteam = 0;         // > 0: the launch in flight reports through the done words, this many workgroups per alignment
     bool pending_host_r = false;   // the launch in flight mirrors its residuals into the handle's h_rmap (eds_mirror_residuals)
     char last_kernel[96] = {0};    // what the last solve launched (eds_trk_last_launch)
     int last_workgroups = 0, last_team = 1, last_first = 0, last_count = 0, last_layout = 1, last_kind = 0;
@@ -198,4 +201,5 @@ int  eds_keyframe_get_points(eds_trk* h, int slot, double* coord_xy, double* nor
 // defined in eds_capi.hip
 int eds_internal_refresh_gram(eds_trk* h, int slot);
 int eds_internal_fail(int code, const char* msg);
+int eds_stream_idle(eds_trk* h);        // eds_capi.hip: waits for the handle's stream if the last solve was only seen complete through its result records
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count);

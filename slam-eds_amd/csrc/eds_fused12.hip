@@ -112,9 +112,13 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     // through the matrix core's staging area 16 at a time instead of 64 (four rounds of: 16 lanes store their rows, the wavefront
     // reads them back as four operand pairs).
     constexpr bool FULL = NTHR == 512 && CAP == 2000;
-    static_assert(!FULL || (TEAM == 1 && !NC && GROUPS == 1), "the full-cache shape: one CU per alignment, plain residual");
-    constexpr int MAXB = FULL ? 1 : EDS_DEV_MAX_BLOCKS;      // residual blocks this instantiation can hold
-    constexpr int SROWS = FULL ? 16 : 64;                   // rows of a wavefront staged at a time
+    // HALF (round 6, second attempt): the paired shape — two 256-thread alignments per CU, one's solver phase under the other's point
+    // phase — with the same slimming, which leaves each of the two a cache of 736 patches (37 % of 2 000 points: what two workgroups per CU leave of its 160 KB).
+    constexpr bool HALF = NTHR == 256 && CAP == 736;
+    constexpr bool SLIM = FULL || HALF;
+    static_assert(!SLIM || (TEAM == 1 && !NC && GROUPS == 1), "the slim shapes: one workgroup per alignment, plain residual");
+    constexpr int MAXB = SLIM ? 1 : EDS_DEV_MAX_BLOCKS;      // residual blocks this instantiation can hold
+    constexpr int SROWS = SLIM ? 16 : 64;                   // rows of a wavefront staged at a time
     __shared__ int s_ticket, s_timeout;
     __shared__ double s_gcost[GROUPS][MAXB];      // GROUPS > 1: ||r_b||^2 of every group's candidate (summed over its members)
     __shared__ int s_gacc, s_kacc, s_linmode;                   // ... the group / prepared step that was accepted this round (-1: none), how
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int slot = first + team_slot;
     if (tid == 0 && member == 0 && group == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
     if (nb > MAXB) {                    // (the launcher never asks for it: eds_ref12_force_feasible / the rule; a failed solve, not a wrong one)
-        if (tid == 0) { out[slot].failed = 1; out[slot].termination = edss::TERM_FAILURE; out[slot].t_end = __builtin_amdgcn_s_memrealtime(); }
+        if (tid == 0) { out[slot].failed = 1; out[slot].termination = edss::TERM_FAILURE; __hip_atomic_store(&out[slot].t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         return;
     }
     unsigned pass_no = 0;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     // (3 % of the line fills at the pose-only kernel's 21 % hit rate), and probing, selecting and writing back for all points cost more
     // vector instructions than that returns (profiles/r04_sq_counters.txt: 523 per point-evaluation, a quarter of the wavefront-cycles wait
     // for an issue slot).  The quad gather of that shape therefore skips the cache (round 4); the lane gather and the 512-thread shapes keep it.
-    constexpr bool QCACHE = !(QUAD != 0 && NTHR == 256);
+    constexpr bool QCACHE = !(QUAD != 0 && NTHR == 256) || HALF;
     // Candidate residuals of an evaluation: in LDS for the batch shape (two 256-thread workgroups per CU: 8 KB fit its 80 KB), copied to the
     // residual plane when the candidate is accepted — round 3 wrote every evaluation's candidates to the mhat plane and read them back on
     // acceptance (0.5 GB of writes per 4 096-alignment launch: profiles/r03_summary.md WRITE_SIZE).  Points beyond the buffer, and the
@@ -779,10 +783,16 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
             }
         }
     } else
-    if (TEAM > 1 && A.rmap) {                   // the kept residuals into the pinned mirror (each thread: the entries it wrote itself)
+    if (A.rmap) {                               // the kept residuals into the pinned mirror (each thread: the entries it wrote itself)
         for (int i = lo + tid; i < hi; i += nthr) A.rmap[base + i] = A.r[base + i];
     }
-    if (TEAM > 1 && (member != 0 || group != 0)) return;        // every member holds the same result; member 0 (of group 0) reports it
+    // small solves: this workgroup's completion word (EdsArrays::done) — every thread's writes are out at system scope first
+    unsigned* const done_word = A.done ? A.done + (size_t)slot * EDS_DONE_WORDS + (TEAM > 1 ? group * TEAM + member : 0) : nullptr;
+    if (done_word) { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); __syncthreads(); }      // (vmcnt(0): this wavefront's stores are acknowledged — see eds_fused6_kernel)
+    if (TEAM > 1 && (member != 0 || group != 0)) {              // every member holds the same result; member 0 (of group 0) reports it
+        if (tid == 0 && done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (tid == 0) {
         EdsFused12Out& O = out[slot];
         const bool ok = sv.termination != edss::TERM_FAILURE;
@@ -792,7 +802,9 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         O.initial_cost = sv.initial_cost; O.final_cost = sv.minimum_cost;
         O.termination = sv.termination; O.num_successful = sv.num_successful; O.num_unsuccessful = sv.num_unsuccessful;
         O.failed = ok ? 0 : (TEAM > 1 && sv.num_unsuccessful == -2 ? 2 : 1);     // 2: team timeout
-        O.t_end = __builtin_amdgcn_s_memrealtime();
+        // the LAST word of the record, released at system scope: a host that sees it non-zero sees the whole record (wait_stream polls it)
+        __hip_atomic_store(&O.t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -842,23 +854,30 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
         }
     }
     fb.pending_team = team; fb.pending_level = level;
-    const bool rmap_in_kernel = team > 1 && h->d_rmap && first + count <= EDS_RHOST_SLOTS;       // (see eds_fused_solve)
-    A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
-    const unsigned ticket_base = fb.ticket_base;
     const int drop = kn.team_drop ? 1 : 0;            // test hook for the time-out path (see eds_fused_solve)
     fb.pending_ticks = count <= 64;                  // as eds_fused_solve
+    const bool done_words = fb.pending_ticks && kn.poll_results && !drop;                     // (see eds_fused_solve; the group count is only known below)
+    const bool rmap_in_kernel = (team > 1 || done_words) && h->d_rmap && first + count <= EDS_RHOST_SLOTS;       // (see eds_fused_solve)
+    A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
+    const unsigned ticket_base = fb.ticket_base;
     if (!fb.pending_ticks) hipEventRecord(h->ev0, h->st);
     // the strip copies of the frames: asked for only where an instantiation reads them (teams of up to 4, both one-CU shapes)
     const bool strips = pl.strips_eligible && eds_strips_for_solve(h, first, count);
     eds_ref12_plan_finish(kn, rin, strips ? 1 : 0, pl);
     A.strips = h->dstrips; A.strip_phases = h->strip_phases;
     const int groups = pl.K > 1 ? pl.G : 1;          // candidate groups: G x K workgroups per alignment
+    fb.pending_vteam = 0;
+    if (done_words && pl.K * groups <= EDS_DONE_WORDS) {
+        if (++fb.done_seq == 0u) fb.done_seq = 1u;
+        A.done = fb.d_done; A.done_tag = fb.done_seq; fb.pending_vteam = pl.K * groups;
+    }
     if (!eds_fused12_instance_exists(pl.S, pl.T, pl.CAP, pl.NC, pl.K, pl.Q, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
     if (team > 1) {
         fb.ticket_base += (unsigned)(count * team * groups);
         for (int s = first; s < first + count; ++s) fb.h_out12[s].failed = 2;    // "no result yet" reads as a time-out (eds_fused_solve)
     }
+    if (fb.pending_ticks) for (int s = first; s < first + count; ++s) fb.h_out12[s].t_end = 0;      // (the completion word wait_stream polls)
     if (groups > 1) std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q, groups);
     else std::snprintf(fb.last_kernel, sizeof(fb.last_kernel), "eds_fused12_kernel<%d, %d, %d, %s, %d, %d>", pl.S, pl.T, pl.CAP, pl.NC ? "true" : "false", pl.K, pl.Q);
     fb.last_workgroups = count * pl.K * groups - (pl.K > 1 ? drop : 0); fb.last_team = pl.K * groups; fb.last_layout = pl.Q == 2 ? 2 : 1;
@@ -883,6 +902,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
 #undef EDS_INST_LAUNCH12_
     if (!fb.pending_ticks) hipEventRecord(h->ev1, h->st);
     fb.pending_host_r = rmap_in_kernel ? true : eds_mirror_residuals(h, first, count);
+    if (fb.pending_host_r && !rmap_in_kernel) fb.pending_vteam = 0;      // (a mirror launch follows: see eds_fused_solve)
     e = hipGetLastError();
     if (e != hipSuccess) return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e));
     fb.pending_first = first;

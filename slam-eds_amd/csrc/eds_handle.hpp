@@ -74,6 +74,9 @@ struct eds_trk {
     bool idp_busy = false;
     bool gram_pending = false;          // h_G's refresh is still in flight on the stream (set_idepth does not wait for it)
     bool stage_busy = false;            // ev_stage has to be waited for before h_fstage is written again
+    bool stream_dirty = false;          // the last small solve was seen complete through its workgroups' done words in pinned memory
+                                        // (eds_capi.hip: wait_stream) — the stream itself has not been waited for.  Records and residual mirror
+                                        // are covered by the words; anything else a host reader wants of that launch: eds_stream_idle() first
     size_t h_f32_elems = 0;
     float *h_bstage = nullptr, *d_bstage = nullptr;   // pinned, device-mapped ring of staging slots of eds_trk_set_event_frames (allocated at its first call)
     hipStream_t st_up = nullptr;        // second stream of the batch upload (alternate frames), created at its first call
@@ -91,7 +94,7 @@ struct eds_trk {
         A.x = dx; A.y = dy; A.rho = drho; A.gx = dgx; A.gy = dgy; A.w = dw;
         A.f0x = df0x; A.f0y = df0y; A.cell0 = dcell0;
         A.kf = dkf; A.kf_plane = (size_t)B * Np;
-        A.mhat = dmhat; A.frame = dframe; A.rmap = nullptr; A.strips = nullptr /* set by the launch sites that made sure the copies are current */; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
+        A.mhat = dmhat; A.frame = dframe; A.rmap = nullptr; A.done = nullptr; A.done_tag = 0; A.strips = nullptr /* set by the launch sites that made sure the copies are current */; A.strip_phases = strip_phases; A.pose = dpose; A.G = dG; A.r = dr; A.J = dJ; A.part = dpart; A.ncstat = dncstat;
         A.B = B; A.Np = Np; A.H = H; A.W = W; A.max_seg = max_seg;
         A.Hp = Hp; A.Wp = Wp; A.tiled = tiled;
         return A;

@@ -24,6 +24,10 @@ struct EdsArrays {
     float* r;            // [B][Np]
     float* rmap;         // pinned host mirror of the first EDS_RHOST_SLOTS rows of `r` (device view) or null: team launches store the kept
                          // residuals there themselves (no mirror launch behind a lone solve)
+    // Small solves (round 6): EVERY workgroup of the launch, once everything it writes is out (system-scope fence), stores `done_tag` into
+    // its word done[slot * EDS_DONE_WORDS + workgroup-of-the-alignment] in pinned host memory — the host sees the solve finish, records AND
+    // residual mirror, without the runtime (eds_capi.hip: wait_stream).  null: a batch; the stream is waited for.
+    unsigned* done; unsigned done_tag;
     float* J;            // [12][B][Np]
     double* part;        // [B][max_seg][EDS_RED_K]
     double* ncstat;      // [B][EDS_MAX_BLOCKS][8]  PhotometricErrorNC block statistics (eds_layout.hpp)
@@ -32,6 +36,7 @@ struct EdsArrays {
 };
 
 #define EDS_RHOST_SLOTS 8
+#define EDS_DONE_WORDS 32          // workgroups per alignment at most: teams x candidate groups (4 x 8, 8 x 4, 16 x 1)
 
 void eds_launch_gram(const EdsArrays& A, int slot, int nb, hipStream_t st, const float* new_rho = nullptr);
 void eds_launch_model(const EdsArrays& A, int first, int count, int nchunk, hipStream_t st);

@@ -46,6 +46,7 @@ struct EdsKnobs {
     int strips_budget_pct = 50; // EDS_STRIPS_BUDGET_PCT  the strip copies may take at most this share of the device memory that is FREE when
                                 //                     they are first allocated (1 .. 95); fewer row phases, or none, beyond it
     int no_spin = 0;            // EDS_NO_SPIN         block in the stream wait from the start
+    int poll_results = 1;       // EDS_POLL_RESULTS    0: small solves are waited for through the stream (hipStreamQuery) instead of their result records
     int upload_bands = 0;       // EDS_UPLOAD=bands    one launch per band of a host frame (round 2's upload)
     int frame_rowmajor = 0;     // EDS_FRAME_LAYOUT=rowmajor   (read at create only: it decides the allocation)
     int reduce_ppl = 4;         // EDS_REDUCE_PPL      4 | 8: points a lane of eds_reduce_kernel<6> folds (16-byte loads)
@@ -81,12 +82,13 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     else if (!strcmp(name, "EDS_TEAM_WIDE")) return flag(&k->team_wide, -1);
     else if (!strcmp(name, "EDS_FUSED_GATHER")) { if (unset) k->gather = 0; else if (is("lane")) k->gather = 2; else if (is("quad")) k->gather = 1; else return -2; }
     else if (!strcmp(name, "EDS_FUSED_REPORT")) return flag(&k->report, 0);
-    else if (!strcmp(name, "EDS_REF12_KERNEL")) { if (unset) k->ref12_kernel = 0; else if (is("wide")) k->ref12_kernel = 1; else if (is("paired")) k->ref12_kernel = 2; else if (is("full")) k->ref12_kernel = 3; else return -2; }
+    else if (!strcmp(name, "EDS_REF12_KERNEL")) { if (unset) k->ref12_kernel = 0; else if (is("wide")) k->ref12_kernel = 1; else if (is("paired")) k->ref12_kernel = 2; else if (is("full")) k->ref12_kernel = 3; else if (is("half")) k->ref12_kernel = 4; else return -2; }
     else if (!strcmp(name, "EDS_REF12_TEAM")) { if (unset) k->ref12_team = 0; else if (one_of({1, 2, 4, 8, 16})) k->ref12_team = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_STRIPS_PHASES")) { if (unset) k->strips_phases = 0; else if (one_of({1, 2, 4})) k->strips_phases = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_STRIPS_POLICY")) { if (unset || is("reuse")) k->strips_policy = 0; else if (is("eager")) k->strips_policy = 1; else if (is("never")) k->strips_policy = 2; else return -2; }
     else if (!strcmp(name, "EDS_STRIPS_BUDGET_PCT")) { if (unset) k->strips_budget_pct = d.strips_budget_pct; else if (num && iv >= 1 && iv <= 95) k->strips_budget_pct = (int)iv; else return -2; }
     else if (!strcmp(name, "EDS_NO_SPIN")) return flag(&k->no_spin, 0);
+    else if (!strcmp(name, "EDS_POLL_RESULTS")) return flag(&k->poll_results, 1);
     else if (!strcmp(name, "EDS_UPLOAD")) { if (unset) k->upload_bands = 0; else if (is("bands")) k->upload_bands = 1; else return -2; }
     else if (!strcmp(name, "EDS_FRAME_LAYOUT")) { if (unset || is("tiles")) k->frame_rowmajor = 0; else if (is("rowmajor")) k->frame_rowmajor = 1; else return -2; }
     else if (!strcmp(name, "EDS_REDUCE_PPL")) { if (unset) k->reduce_ppl = 4; else if (one_of({4, 8})) k->reduce_ppl = (int)iv; else return -2; }
@@ -120,7 +122,7 @@ static inline int eds_knobs_set(EdsKnobs* k, const char* name, const char* value
     X("EDS_REF12_EXEC") X("EDS_FUSED_THREADS") X("EDS_FUSED_PPT") X("EDS_LM6_SPEC") X("EDS_LM6_KERNEL") X("EDS_FUSED_LAYOUT")        \
     X("EDS_TEAM_TEST_DROP_MEMBER") X("EDS_LM6_TEAM") X("EDS_TEAM_WIDE") X("EDS_FUSED_GATHER") X("EDS_FUSED_REPORT")                   \
     X("EDS_REF12_KERNEL") X("EDS_REF12_TEAM") X("EDS_STRIPS_PHASES") X("EDS_STRIPS_POLICY") X("EDS_STRIPS_BUDGET_PCT")               \
-    X("EDS_NO_SPIN") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12") X("EDS_REF12_GROUPS")
+    X("EDS_NO_SPIN") X("EDS_POLL_RESULTS") X("EDS_UPLOAD") X("EDS_FRAME_LAYOUT") X("EDS_REDUCE_PPL") X("EDS_LM6_GROUPS") X("EDS_UPLOAD_THREADS") X("EDS_UPLOAD_DMA") X("EDS_UPLOAD_STREAMS") X("EDS_FORCE_FUSED6") X("EDS_FORCE_FUSED12") X("EDS_REF12_GROUPS")
 
 // the process environment, read once per handle (eds_trk_create)
 // Returns the name of the first variable whose value its knob does not take (nullptr: none) — eds_trk_create refuses to make a handle
@@ -370,6 +372,7 @@ struct EdsRef12In {
     int retry;
     int nb;                 // residual blocks (cfg.num_blocks; 0 reads as 1): the full-cache shape holds the sums of one
 };
+#define EDS_RULE_HALF_CAP 736          // ... and of the paired slim shape (256 threads, two alignments per CU, 736 of the points cached)
 #define EDS_RULE_FULL_CAP 2000         // = the CAP of the full-cache instantiations of eds_fused12_kernel (512 threads, one alignment per CU)
 static inline bool eds_ref12_full_fits(const EdsRef12In& in) { return in.bicubic && !in.nc && in.nb <= 1 && in.maxN <= EDS_RULE_FULL_CAP && in.H < 8000; }
 struct EdsRef12Plan {
@@ -385,7 +388,7 @@ static inline void eds_ref12_plan_begin(const EdsKnobs& kn, const EdsRef12In& in
     // patch cache; beyond, 256-thread workgroups with a small cache so that TWO alignments share a CU and one's solver phase overlaps
     // the other's point phase
     bool wide = in.count <= 256;
-    if (kn.ref12_kernel == 1 || kn.ref12_kernel == 3) wide = true; else if (kn.ref12_kernel == 2) wide = false;
+    if (kn.ref12_kernel == 1 || kn.ref12_kernel == 3) wide = true; else if (kn.ref12_kernel == 2 || kn.ref12_kernel == 4) wide = false;
     p.wide = wide;
     p.wants_team = wide && !in.nc && in.maxN > 512 && in.count <= EDS_RULE_TEAM12_SLOTS && !in.retry;
 }
@@ -430,7 +433,7 @@ static inline bool eds_ref12_force_feasible(const EdsKnobs& kn, const EdsRef12In
     if (S != (in.bicubic ? 0 : 1) || (NC != 0) != (in.nc != 0)) return false;
     if (K > 1 && (in.nc || in.retry || in.count > EDS_RULE_TEAM12_SLOTS || in.count * K > EDS_RULE_TEAM12_MEMBERS)) return false;
     if (Q != 0 && in.H >= 8000) return false;
-    if (CAP == EDS_RULE_FULL_CAP && !eds_ref12_full_fits(in)) return false;          // one residual block, every point cached
+    if ((CAP == EDS_RULE_FULL_CAP || CAP == EDS_RULE_HALF_CAP) && !eds_ref12_full_fits(in)) return false;          // the slim shapes: one residual block
     return true;
 }
 
@@ -469,6 +472,13 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     if (p.team == 1 && !(in.bicubic && strips)) p.NC = in.nc ? 1 : 0;
     // EDS_REF12_KERNEL=full (round 6, A/B knob): one alignment per CU with a cache slot for every point (quad gather, tiles or strips)
     if (kn.ref12_kernel == 3 && p.team == 1 && eds_ref12_full_fits(in)) { p.T = 512; p.CAP = EDS_RULE_FULL_CAP; p.Q = strips ? 2 : 1; p.NC = 0; }
+    // The paired shape with 736 cache slots per alignment (round 6): what the batch launches for the reference problem (one residual block,
+    // up to 2 000 points) on frames that are NEW for the solve — the tile gather runs at the fabric's line-fill rate, and the cache takes
+    // 13 % of its requests away (4 096 alignments: 194 M -> 169 M, 3.64 -> 3.48 ms, profiles/r06_ref12_shapes.txt).  On the strip copies the
+    // same cache LOSES (2.68 -> 3.07 ms: that gather is bound by its instruction stream, and probing costs instructions): EDS_REF12_KERNEL=half
+    // forces it there too, =paired keeps the cache-less shape everywhere.
+    if (p.team == 1 && !p.wide && eds_ref12_full_fits(in) && p.T == 256 && ((p.Q == 1 && kn.ref12_kernel != 2) || (kn.ref12_kernel == 4 && p.Q != 0)))
+        { p.CAP = EDS_RULE_HALF_CAP; p.NC = 0; }
     groups_for(p);
 }
 
@@ -480,7 +490,7 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     X(0, 512, 1408, true, 1, 0) X(1, 512, 1408, false, 1, 0) X(1, 512, 1408, true, 1, 0)                                            \
     X(0, 256, 320, false, 1, 2) X(0, 256, 320, false, 1, 1) X(0, 256, 320, true, 1, 1) X(0, 256, 320, false, 1, 0)                  \
     X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)                                               \
-    X(0, 512, 2000, false, 1, 1) X(0, 512, 2000, false, 1, 2)
+    X(0, 512, 2000, false, 1, 1) X(0, 512, 2000, false, 1, 2) X(0, 256, 736, false, 1, 1) X(0, 256, 736, false, 1, 2)
 
 // ... and the candidate-group instantiations X(S, T, CAP, NC, K, Q, G), G > 1: a member's slice is at most 512 points here, so is its patch
 // cache (CAP = 512) — the LDS that leaves holds the G sets of sums of a round

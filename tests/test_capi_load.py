@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = capi.lib()
     for name in _declared_functions():
         assert hasattr(L, name), f"libeds_hip.so does not export {name}"
-    assert L.eds_abi_version() == 5
+    assert L.eds_abi_version() == 6
 
 
 def test_library_contains_gfx950_code_object(capi):

@@ -10,6 +10,7 @@ Checked: every result equals the same sequence run alone (LM6 bit for bit, REF12
 order-deterministic); the run reports how many calls saw a time-out / pause and the slowest call, and bounds it: a tracker must not take
 a stall of hundreds of solves for a 0.1 ms solve."""
 import importlib
+import sys
 import threading
 import time
 
@@ -22,19 +23,20 @@ synth = importlib.import_module("slam-eds_amd.synth")
 pytestmark = pytest.mark.gpu
 
 H, W, N = 480, 640, 2000
-WORST_CALL_MS = 25.0            # bound on one contended call: the team time-out (5 ms) + the one-CU re-run behind a full chip
+WORST_CALL_MS = 25.0            # bound on one contended call, measured INSIDE the library (launch -> results collected): the team
+                                # time-out (5 ms) + the one-CU re-run behind a full chip, with room for a shared box
 
 
-def _small(tid):
+def _small(tid, bmax):
     """The latency-regime sequence of thread `tid`: (solver, B, alignments)."""
     solver = capi.SOLVER_LM6 if tid % 2 == 0 else capi.SOLVER_REF12
-    B = 1 + (tid // 2) % 4
-    als = [synth.make_alignment(8800 + 8 * tid + b, H=H, W=W, N=N) for b in range(B)]
+    B = 1 + (tid // 2) % bmax if bmax > 1 else 1
+    als = [synth.make_alignment(8800 + 8 * (tid % 6) + b, H=H, W=W, N=N) for b in range(B)]
     return solver, B, als
 
 
-def _run_small(tid, reps, gate=None, stop=None):
-    solver, B, als = _small(tid)
+def _run_small(tid, reps, bmax, gate=None):
+    solver, B, als = _small(tid, bmax)
     h = capi.Handle(capi.default_config(solver=solver, exec=capi.EXEC_DEVICE, num_blocks=1, max_num_iterations=10), B, N, H, W)
     for b, a in enumerate(als):
         h.set_alignment(b, a)
@@ -42,23 +44,24 @@ def _run_small(tid, reps, gate=None, stop=None):
     p0 = np.stack([a.p0 for a in als]); q0 = np.stack([a.q0 for a in als]); v0 = np.stack([a.v0 for a in als])
     if gate is not None:
         gate.wait()
-    out = {"solver": solver, "B": B, "tables": [], "residuals": [], "ms": [], "flags": [], "kernels": set()}
+    out = {"solver": solver, "B": B, "tables": [], "residuals": [], "ms": [], "lib_ms": [], "flags": [], "kernels": set()}
     for _ in range(reps):
         h.set_states(0, p0, q0, v0)
         t = time.perf_counter()
         h.optimize_batch(0, 0, B)
-        out["ms"].append(1e3 * (time.perf_counter() - t))
+        out["ms"].append(1e3 * (time.perf_counter() - t))             # (with several Python threads this includes waiting for the interpreter lock)
+        infos = [h.info(b) for b in range(B)]
+        out["lib_ms"].append(1e-3 * max(i["meas_time_us"] for i in infos))      # launch -> collected, by the library's own clock
         out["tables"].append(np.array(h.results(0, B)))
         out["residuals"].append(h.residuals(0).copy())
-        out["flags"].append(max(h.info(b)["flags"] for b in range(B)))
+        out["flags"].append(max(i["flags"] for i in infos))
         out["kernels"].add(h.last_launch()["kernel"])
     h.close()
     return out
 
 
-def test_small_team_launches_behind_a_full_chip():
-    T, REPS = 6, 40
-    alone = [_run_small(t, 2) for t in range(T)]
+def _contend(T, REPS, bmax):
+    alone = [_run_small(t, 2, bmax) for t in range(T)]
     for a in alone:                                  # alone, every one of them forms teams (that is what is being contended)
         assert any("eds_fused" in k for k in a["kernels"]) and max(a["flags"]) == 0, (a["kernels"], a["flags"])
     # the thread that keeps the chip full: 1 024 alignments (8 distinct, every slot its own frame), LM6, frames new for the solve
@@ -81,7 +84,8 @@ def test_small_team_launches_behind_a_full_chip():
             while not stop.is_set():
                 hb.set_states(0, P0, Q0, V0); hb.optimize_batch(0, 0, Bb)
                 big["launches"] += 1
-                big["same"] = big["same"] and bool(np.array_equal(np.array(hb.results(0, Bb)), big_ref))
+                if big["launches"] % 8 == 0:
+                    big["same"] = big["same"] and bool(np.array_equal(np.array(hb.results(0, Bb)), big_ref))
         except BaseException as e:          # noqa: BLE001 (reported by the main thread)
             big["error"] = e
 
@@ -90,41 +94,63 @@ def test_small_team_launches_behind_a_full_chip():
 
     def worker(t):
         try:
-            res[t] = _run_small(t, REPS, gate)
+            res[t] = _run_small(t, REPS, bmax, gate)
         except BaseException as e:          # noqa: BLE001
             res[t] = e
 
-    tb = threading.Thread(target=keep_full); tb.start()
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-    for x in ths:
-        x.start()
-    time.sleep(0.05)                        # the batch is running before the small launches start
-    gate.wait()
-    for x in ths:
-        x.join(timeout=300)
-        assert not x.is_alive(), "a contended launch did not return"
-    stop.set(); tb.join(timeout=60)
+    old_switch = sys.getswitchinterval()
+    sys.setswitchinterval(1e-4)             # (the default hands the interpreter lock over every 5 ms: with 7-13 threads that alone is tens of ms per call)
+    try:
+        tb = threading.Thread(target=keep_full); tb.start()
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in ths:
+            x.start()
+        time.sleep(0.05)                    # the batch is running before the small launches start
+        gate.wait()
+        for x in ths:
+            x.join(timeout=300)
+            assert not x.is_alive(), "a contended launch did not return"
+        stop.set(); tb.join(timeout=60)
+    finally:
+        sys.setswitchinterval(old_switch)
     hb.close()
     assert big["error"] is None, big["error"]
     assert big["launches"] >= 5 and big["same"], big                       # the chip really was kept busy, and the batch is undisturbed
     flagged = timeouts = calls = 0
-    worst = 0.0
+    worst = worst_py = 0.0
     for t in range(T):
         assert not isinstance(res[t], BaseException), res[t]
         r, ref_tab, ref_r = res[t], alone[t]["tables"][0], alone[t]["residuals"][0]
-        for tab, rr, fl, ms in zip(r["tables"], r["residuals"], r["flags"], r["ms"]):
+        for tab, rr, fl, ms, lms in zip(r["tables"], r["residuals"], r["flags"], r["ms"], r["lib_ms"]):
             calls += 1
             flagged += 1 if fl else 0
             timeouts += 1 if fl & capi.INFO_TEAM_TIMEOUT else 0
-            worst = max(worst, ms)
-            if r["solver"] == capi.SOLVER_LM6:
+            worst = max(worst, lms); worst_py = max(worst_py, ms)
+            if fl:          # solved (again) with one CU per alignment: another order of the fp64 sums — equal to the last digits (as tests/test_team_timeout_gpu.py)
+                np.testing.assert_allclose(tab[:, :13], ref_tab[:, :13], rtol=1e-6, atol=1e-6)
+                assert np.array_equal(tab[:, 14:], ref_tab[:, 14:]), (t, fl)
+            elif r["solver"] == capi.SOLVER_LM6:
                 assert np.array_equal(tab, ref_tab) and np.array_equal(rr, ref_r), (t, fl)
             else:
                 np.testing.assert_allclose(tab[:, :13], ref_tab[:, :13], rtol=0, atol=1e-9)
                 assert np.array_equal(tab[:, 14:], ref_tab[:, 14:]), (t, fl)
                 np.testing.assert_allclose(rr, ref_r, rtol=0, atol=1e-9)
-    med = float(np.median([ms for t in range(T) for ms in res[t]["ms"]]))
-    print(f"\n[contention] {T} threads x {REPS} calls behind {big['launches']} launches of {Bb} alignments: {flagged} calls flagged (time-out or teams paused), "
-          f"{timeouts} team time-outs, median call {med:.3f} ms, slowest call {worst:.3f} ms; alone: "
-          f"{float(np.median([ms for a in alone for ms in a['ms']])):.3f} ms")
-    assert worst < WORST_CALL_MS, f"a contended call took {worst:.1f} ms"
+    med = float(np.median([ms for t in range(T) for ms in res[t]["lib_ms"]]))
+    wg = sum(32 * res[t]["B"] for t in range(T))
+    print(f"\n[contention] {T} threads x {REPS} calls (up to {wg} team workgroups wanted at once) behind {big['launches']} launches of {Bb} alignments: "
+          f"{flagged} of {calls} calls flagged (time-out or teams paused), {timeouts} team time-outs; inside the library: median call {med:.3f} ms, slowest {worst:.3f} ms "
+          f"(through Python, interpreter lock included: slowest {worst_py:.3f} ms); alone: {float(np.median([ms for a in alone for ms in a['lib_ms']])):.3f} ms")
+    assert worst < WORST_CALL_MS, f"a contended call took {worst:.1f} ms inside the library"
+    return flagged, timeouts
+
+
+def test_small_team_launches_behind_a_full_chip():
+    """Six threads, B = 1..3: their teams fit the chip together (at most 6 x 96 workgroups, mostly fewer) but every CU is busy with the batch."""
+    _contend(6, 40, 3)
+
+
+def test_team_launches_oversubscribing_each_other_behind_a_full_chip():
+    """Twelve threads, B = 1..4 (up to 128 workgroups per launch, ~900 wanted at once on 256 busy CUs): teams of different handles hold
+    CUs while they wait for their own last members — the situation the time-out exists for.  Results must still equal the solo runs;
+    whatever time-outs / pauses occur are counted and every call stays bounded."""
+    _contend(12, 25, 4)

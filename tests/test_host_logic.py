@@ -321,7 +321,16 @@ def test_launch_rule_force_knobs(hl):
 
 def test_launch_rule_ref12_table(hl):
     K = lambda d: (d["S"], d["T"], d["CAP"], d["NC"], d["K"], d["Q"])
-    assert K(_ref12(hl)) == (0, 256, 320, 0, 1, 2) and K(_ref12(hl, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 1)       # the batch: two alignments per CU
+    NB2 = 2 << 8                                                                                                    # (flags bits 8..15: residual blocks)
+    assert K(_ref12(hl)) == (0, 256, 320, 0, 1, 2) and K(_ref12(hl, flags=TEAM_OK | NB2)) == (0, 256, 320, 0, 1, 1)       # the batch: two alignments per CU
+    # round 6: ONE residual block of at most 2 000 points on NEW frames (tiles) — the paired shape with 736 cache slots per alignment; on
+    # the strip copies only by knob; the full-cache one-per-CU shape only by knob (it loses: profiles/r06_ref12_shapes.txt)
+    assert K(_ref12(hl, flags=TEAM_OK)) == (0, 256, 736, 0, 1, 1) and K(_ref12(hl, flags=TEAM_OK, maxN=2001)) == (0, 256, 320, 0, 1, 1)
+    assert K(_ref12(hl, "EDS_REF12_KERNEL=paired", flags=TEAM_OK)) == (0, 256, 320, 0, 1, 1) and K(_ref12(hl, "EDS_REF12_KERNEL=half")) == (0, 256, 736, 0, 1, 2)
+    assert K(_ref12(hl, "EDS_REF12_KERNEL=full", flags=TEAM_OK)) == (0, 512, 2000, 0, 1, 1) and K(_ref12(hl, "EDS_REF12_KERNEL=full")) == (0, 512, 2000, 0, 1, 2)
+    assert K(_ref12(hl, "EDS_REF12_KERNEL=full", flags=TEAM_OK | NB2)) == (0, 512, 1408, 0, 1, 1) and K(_ref12(hl, "EDS_REF12_KERNEL=full", nc=1))[2] == 1408
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,2000,0,1,1", count=300, flags=TEAM_OK)) == (0, 512, 2000, 0, 1, 1)
+    assert K(_ref12(hl, "EDS_FORCE_FUSED12=0,512,2000,0,1,1", count=300, flags=TEAM_OK | NB2)) != (0, 512, 2000, 0, 1, 1)       # two blocks: refused
     assert K(_ref12(hl, count=512, flags=TEAM_OK)) == (0, 256, 320, 0, 1, 0)                                       # tiles: the quad gather from 1 024 on
     assert K(_ref12(hl, count=256)) == (0, 512, 1408, 0, 1, 2) and K(_ref12(hl, count=65, flags=TEAM_OK)) == (0, 512, 1408, 0, 1, 0)
     # (round 5: where candidate groups are formed a member's patch cache is 512 points; EDS_REF12_GROUPS=1 is the one-team launch)
@@ -399,7 +408,7 @@ def test_knob_names_and_strip_budget(hl):
              "EDS_LM6_KERNEL": ("paired", "fast"), "EDS_FUSED_LAYOUT": ("tiles", "rows"), "EDS_TEAM_TEST_DROP_MEMBER": ("1", "2"), "EDS_LM6_TEAM": ("4", "3"),
              "EDS_TEAM_WIDE": ("0", "wide"), "EDS_FUSED_GATHER": ("lane", "1"), "EDS_FUSED_REPORT": ("1", "on"), "EDS_REF12_KERNEL": ("wide", "1"),
              "EDS_REF12_TEAM": ("8", "5"), "EDS_STRIPS_PHASES": ("2", "3"), "EDS_STRIPS_POLICY": ("never", "always"), "EDS_STRIPS_BUDGET_PCT": ("30", "0"),
-             "EDS_NO_SPIN": ("1", "x"), "EDS_UPLOAD": ("bands", "1"), "EDS_FRAME_LAYOUT": ("rowmajor", "1"), "EDS_REDUCE_PPL": ("8", "abc"),
+             "EDS_NO_SPIN": ("1", "x"), "EDS_POLL_RESULTS": ("0", "2"), "EDS_UPLOAD": ("bands", "1"), "EDS_FRAME_LAYOUT": ("rowmajor", "1"), "EDS_REDUCE_PPL": ("8", "abc"),
              "EDS_LM6_GROUPS": ("4", "3"), "EDS_UPLOAD_THREADS": ("6", "0"), "EDS_UPLOAD_DMA": ("1", "2"), "EDS_UPLOAD_STREAMS": ("1", "3"),
              "EDS_FORCE_FUSED6": ("0,4,512,3,1,1", "0,4,512"), "EDS_FORCE_FUSED12": ("0,256,320,0,1,2", "a,b"), "EDS_REF12_GROUPS": ("2", "3")}
     for name, (good, bad) in table.items():

@@ -1,5 +1,5 @@
 """The failure path of the team launches (eds_fused.hip / eds_fused12.hip): a team whose members do not all arrive reports a time-out
-after EDS_TEAM_TIMEOUT_TICKS (50 ms) instead of hanging, the collect step re-runs the range with one CU per alignment, teams pause on
+after EDS_TEAM_TIMEOUT_TICKS (5 ms) instead of hanging, the collect step re-runs the range with one CU per alignment, teams pause on
 that handle for EDS_TEAM_COOLDOWN solves (eds_trk_info.flags says so) and then come back by themselves.  EDS_TEAM_TEST_DROP_MEMBER launches the team grid one workgroup short — exactly the situation the
 bound exists for — without touching the kernels."""
 import importlib
@@ -45,7 +45,7 @@ def test_incomplete_team_times_out_and_falls_back(solver):
     walls_ok, tab_ok, _ = _solve(solver, 3, False, seeds)
     walls, tab, infos = _solve(solver, 3, True, seeds)
     # the short launch waited for the bound, then the range was solved again: well above a normal call, far below a hang
-    assert 0.045 < walls[0] < 2.0, walls
+    assert 0.0045 < walls[0] < 2.0, walls
     assert walls_ok[0] < 0.02
     # every alignment has a usable result, the one whose team was incomplete included
     assert all(i["success"] for i in infos)
@@ -90,7 +90,7 @@ def test_teams_pause_then_come_back(solver):
     assert info_team["flags"] == 0 and w_team < 0.02
     for round_ in range(2):                                    # a time-out, the pause, the come-back — twice
         w, tab, info = call(drop=True)
-        assert w > 0.045 and info["flags"] & capi.INFO_TEAM_TIMEOUT and info["success"]
+        assert w > 0.0045 and info["flags"] & capi.INFO_TEAM_TIMEOUT and info["success"]
         np.testing.assert_allclose(tab, tab_team, rtol=1e-6, atol=1e-6)
         pause = capi.TEAM_COOLDOWN * (2 ** round_)             # a time-out right after a re-arm doubles the pause
         dev_paused, w_paused = [], []
@@ -99,7 +99,7 @@ def test_teams_pause_then_come_back(solver):
             assert info["flags"] == capi.INFO_TEAMS_PAUSED, (round_, k, info["flags"])
             assert info["success"]
             dev_paused.append(info["device_time_us"]); w_paused.append(w)
-        # normal speed during the pause (the median: a shared box may stall any single call), and no 50 ms wait inside the kernels
+        # normal speed during the pause (the median: a shared box may stall any single call), and no time-out wait inside the kernels
         assert np.median(w_paused) < 0.005 and max(dev_paused) < 5000.0, (round_, sorted(w_paused)[-3:], max(dev_paused))
         w, tab, info = call()                                  # re-armed
         assert info["flags"] == 0 and info["success"], (round_, info["flags"])

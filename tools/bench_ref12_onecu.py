@@ -24,7 +24,7 @@ for layout in ("tiles", "strips"):
     h.set_knob("EDS_FUSED_LAYOUT", "tiles" if layout == "tiles" else None)
     if layout == "strips":
         h.prepare_frames(0, B)
-    for shape in ("paired", "wide", "full"):
+    for shape in ("paired", "half", "wide", "full"):
         h.set_knob("EDS_REF12_KERNEL", shape)
         ts, ds = [], []
         for _ in range(REPS):

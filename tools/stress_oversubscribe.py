@@ -1,6 +1,6 @@
 """Over-subscription stress of the team / candidate-group launches: T host threads, each with its own handle and stream, launch small
 batches (team x group shapes: up to 128 workgroups per launch) at the same time, so the chip's 256 CUs are asked for up to T x 128
-co-resident workgroups.  A team whose members cannot all become resident must time out (50 ms bound), fall back to one CU per
+co-resident workgroups.  A team whose members cannot all become resident must time out (5 ms bound), fall back to one CU per
 alignment and still return the result the same sequence gives when it runs alone: LM6 bit for bit, REF12 within 1e-9 (its fp64 LDS
 atomics are not order-deterministic).  Prints the time-out count (allowed) and the disagreement count (must be 0).
 
