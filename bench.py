@@ -168,6 +168,10 @@ def compact_record(full):
             rec["configs"][name] = dict(_pick(c, ("iterations_per_s", "ms_per_step")), kernel_ms=r.get("kernel_ms"), frac=r.get("frac"),
                                         frac_physical=r.get("frac_physical"), frac_must_move=r.get("frac_must_move"),
                                         parity_max_se3=(c.get("parity") or {}).get("parity_max_se3"))
+    pd = full.get("point_distribution")
+    if pd:
+        rec["point_distribution"] = {k: dict(_pick(pd[k], ("iterations_per_s",)), kernel_ms=pd[k]["roofline"].get("kernel_ms"), frac=pd[k]["roofline"].get("frac"),
+                                             frac_physical=pd[k]["roofline"].get("frac_physical")) for k in ("uniform", "edges") if k in pd}
     if full.get("strong_scaling_config4"):
         rec["strong_scaling_config4"] = _pick(full["strong_scaling_config4"], ("ms_per_step", "iterations_per_s", "alignments_per_gpu", "kernel_ms_rank0"))
     if full.get("hbm_probe"):
@@ -176,7 +180,7 @@ def compact_record(full):
     rec = _sig(rec)
     line = json.dumps(rec, separators=(",", ":"))
     # never let an unforeseen string push the record past what the driver keeps: drop digests, least important first
-    for k in ("hbm_probe_GBps", "strong_scaling_config4", "cpu_baseline_ref12", "cpu_baseline_fast", "configs", "latency", "roofline_reduce", "roofline_resjac"):
+    for k in ("hbm_probe_GBps", "strong_scaling_config4", "point_distribution", "cpu_baseline_ref12", "cpu_baseline_fast", "configs", "latency", "roofline_reduce", "roofline_resjac"):
         if len(line) <= COMPACT_LIMIT:
             break
         rec.pop(k, None)

@@ -394,7 +394,61 @@ def setup_b1(capi, synth, a, solver, al=None, num_blocks=1):
     return Leg("b1_" + solver, lambda: h.optimize(0, p=al.p0, q=al.q0, v=al.v0), h.close, h=h, al=al)
 
 
-LEGS = {"config2": lambda c, s, a: setup_config2(c, s, a), "config2_resident": lambda c, s, a: setup_config2(c, s, a, resident=True),
+def setup_distribution(capi, synth, a, layout):
+    """The headline's kernel on another POINT DISTRIBUTION (every figure was for uniformly random points): 1 024
+    alignments of 640x480 / 2 000 points, 8 distinct, every slot its own frame, LM6 on new frames.  layout = "uniform"  or
+    "edges" (synth.make_alignment: points strung along contours, as a gradient-selected keyframe of a real scene has them)."""
+    from concurrent.futures import ThreadPoolExecutor
+    Bd, Dd = 1024, 8
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as pool:
+        als = list(pool.map(lambda i: synth.make_alignment(6200 + i, H=a.height, W=a.width, N=a.points, layout=layout), range(Dd)))
+    h = capi.Handle(capi.default_config(solver=capi.SOLVER_LM6, exec=capi.EXEC_DEVICE, max_num_iterations=a.iters, lambda0=a.lambda0), Bd, a.points, a.height, a.width)
+    fr = [np.ascontiguousarray(x.frame, dtype=np.float32) for x in als]
+    for b in range(Bd):
+        x = als[b % Dd]
+        h.set_keyframe(b, x.norm_coord, x.grad, x.idp, x.weights, x.fx, x.fy, x.cx, x.cy); h.set_event_frame(b, fr[b % Dd])
+    h.set_knob("EDS_FUSED_LAYOUT", "tiles")
+    P0 = np.stack([als[b % Dd].p0 for b in range(Bd)]); Q0 = np.stack([als[b % Dd].q0 for b in range(Bd)]); V0 = np.stack([als[b % Dd].v0 for b in range(Bd)])
+
+    def step():
+        h.set_states(0, P0, Q0, V0); h.optimize_batch(0, 0, Bd, sync=True)
+    return Leg("dist_" + layout, step, h.close, h=h, als=als, B=Bd, D=Dd, frames32=fr)
+
+
+def distribution_block(capi, synth, a):
+    """Uniform against edge-like point positions, same box, same batch shape: rate, kernel time, credited / must-move / physical fractions,
+    8 rows of each against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    per_pt, mm = BYTES_RESJAC[a.sampling] + BYTES_REDUCE, BYTES_MUST_MOVE[a.sampling]
+    out = {}
+    for layout in ("uniform", "edges"):
+        L = setup_distribution(capi, synth, a, layout)
+        L.step(); L.step()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter(); L.step(); ts.append(time.perf_counter() - t0)
+        tab = L.h.results(0, L.B); launch = L.h.last_launch(); k_ms = L.h.info(0)["device_time_us"] * 1e-3
+        worst, mism = 0.0, 0
+        for d in range(L.D):
+            x = L.als[d]
+            x32 = synth.Alignment(**{**x.__dict__, "frame": L.frames32[d].astype(np.float64)})
+            ref = po.Oracle(x32).pose6_lm(x.p0, x.q0, x.v0, iters=a.iters, lambda0=a.lambda0)
+            worst = max(worst, po.se3_distance(tab[d, 0:3], tab[d, 3:7], ref["p"], ref["q"])); mism += int(tab[d, 14] != ref["iterations"])
+        wall = float(np.median(ts))
+        out[layout] = {"iterations_per_s": L.B * float(np.mean(tab[:, 14])) / wall, "ms_per_step": 1e3 * wall, "kernel": launch["kernel"],
+                       "roofline": roofline_block(launch["kernel"], k_ms, L.B * a.points * (a.iters + 1), per_pt, mm, a, workload="dist_" + layout),
+                       "success_fraction": float(np.mean(tab[:, 15])),
+                       "parity": {"rows_checked": L.D, "parity_max_se3": worst, "iteration_count_mismatches": mism, "tolerance": PARITY_TOL}}
+        L.finish()
+    out["edges_over_uniform"] = out["edges"]["iterations_per_s"] / out["uniform"]["iterations_per_s"]
+    out["note"] = ("1 024 alignments x 2 000 points, LM6 on new frames, the headline's kernel: 'uniform' = SURVEY 8d's point positions, 'edges' = the same number of "
+                   "points strung along contours (what a gradient-selected keyframe looks like): neighbouring patches share 128-byte lines, so the gather moves less")
+    return out
+
+
+LEGS = {"dist_uniform": lambda c, s, a: setup_distribution(c, s, a, "uniform"), "dist_edges": lambda c, s, a: setup_distribution(c, s, a, "edges"),
+        "config2": lambda c, s, a: setup_config2(c, s, a), "config2_resident": lambda c, s, a: setup_config2(c, s, a, resident=True),
         "config3": setup_config3, "config4_one_gpu": setup_config4,
         "b1_lm6": lambda c, s, a: setup_b1(c, s, a, "lm6"), "b1_ref12": lambda c, s, a: setup_b1(c, s, a, "ref12")}
 
@@ -690,6 +744,7 @@ def detail_legs(capi, synth, c, out):
         out["latency"] = latency_block(capi, synth, als[0], a)
     if device and a.sampling == "bicubic" and a.solver == "lm6" and not a.no_configs:
         out["configs"] = configs_block(capi, synth, a)
+        out["point_distribution"] = distribution_block(capi, synth, a)
     if device and not a.no_shared:
         # Informational: TWO batches in flight — a second handle (own stream, own copy of every frame) takes step k + 1 while step k
         # runs.  The host's work per step and, more, the TAIL of a launch (its last workgroups end up to one alignment's duration

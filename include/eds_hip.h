@@ -431,9 +431,9 @@ int eds_trk_prepare_frames(eds_trk* h, int first, int count, int force, float* e
  * different knobs coexist, and no solve touches getenv().  value NULL or "" restores the default.  Names and values (csrc/eds_launch_rule.hpp
  * holds the rule they steer): EDS_REF12_EXEC=device|host, EDS_FUSED_THREADS=64..1024, EDS_FUSED_PPT=0|1|2|4, EDS_LM6_SPEC=0|1,
  * EDS_LM6_KERNEL=resident|paired|wide, EDS_FUSED_LAYOUT=tiles|strips, EDS_FUSED_GATHER=quad|lane, EDS_LM6_TEAM / EDS_REF12_TEAM=1|2|4|8|16,
- * EDS_TEAM_WIDE=0|1, EDS_REF12_KERNEL=wide|paired, EDS_STRIPS_PHASES=1|2|4, EDS_STRIPS_POLICY=reuse|eager|never,
+ * EDS_TEAM_WIDE=0|1, EDS_REF12_KERNEL=wide|paired|half|full (ABI 6: half = the paired shape with 736 cache slots per alignment, full = one alignment per CU with a slot for every point; one residual block, <= 2 000 points), EDS_STRIPS_PHASES=1|2|4, EDS_STRIPS_POLICY=reuse|eager|never,
  * EDS_STRIPS_BUDGET_PCT=1..95 (share of the FREE device memory the strip copies may take when they are first allocated; default 50),
- * EDS_REDUCE_PPL=4|8 (points a lane of the 6-column reduction folds: measured equal), EDS_NO_SPIN, EDS_UPLOAD=bands, EDS_FUSED_REPORT,
+ * EDS_REDUCE_PPL=4|8 (points a lane of the 6-column reduction folds: measured equal), EDS_NO_SPIN, EDS_POLL_RESULTS=0|1 (ABI 6: 0 waits for small solves through the stream instead of their workgroups' completion words in pinned memory), EDS_UPLOAD=bands, EDS_FUSED_REPORT,
  * EDS_TEAM_TEST_DROP_MEMBER (test hook); round 5: EDS_LM6_GROUPS=1|2|4|8 (candidate groups of the team kernel), EDS_UPLOAD_THREADS=1..64,
  * EDS_REF12_GROUPS=1|2|4 (the same for the REF12 team kernel), EDS_UPLOAD_DMA=0|1, EDS_UPLOAD_STREAMS=1|2 (eds_trk_set_event_frames), EDS_FORCE_FUSED6 / EDS_FORCE_FUSED12 (below).
  * EDS_FRAME_LAYOUT=rowmajor decides the allocation and is honoured at create only (EDS_ERR_STATE here).  Unknown name, or a value the

@@ -128,7 +128,8 @@ def render_frame(H, W, K, norm_coord, grad, idp, p, q, v, *, blur_ksize: int = 7
 def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, *,
                    rot_deg: float = 0.2, trans_norm: float = 0.004,
                    blur_ksize: int = 7, blur_sigma: float = 1.5, noise: float = 0.05,
-                   unit_weights: bool = False, start: str = "truth_velocity", margin: int = 16) -> Alignment:
+                   unit_weights: bool = False, start: str = "truth_velocity", margin: int = 16,
+                   layout: str = "uniform") -> Alignment:
     """Build one deterministic alignment (numpy PCG64, ``default_rng(seed)``).
 
     ``rot_deg`` / ``trans_norm`` set the ground-truth offset of the event frame
@@ -137,12 +138,37 @@ def make_alignment(seed: int = 1234, H: int = 480, W: int = 640, N: int = 2000, 
     the defaults widen the basin so Gauss-Newton converges from identity).
     ``start``: "truth_velocity" (pose-only mode, v = v*) or "ctor"
     (v = normalize(0.001 * ones), Tracker.cpp:45-46).
+    ``layout``: "uniform" (distinct pixels uniform over the frame) or
+    "edges" — the points strung along ~40 random contours, 0-2 pixels off them, the
+    way a gradient-selected keyframe of a real scene looks (KeyFrame.cpp:740-823 keeps
+    the strongest gradients of every cell, i.e. edge pixels).  Same raster order of the
+    20x20 cells, same everything else: only where the points sit differs.
     """
     rng = np.random.default_rng(seed)
     fx, fy, cx, cy = intrinsics(H, W)
     # distinct integer pixels in [margin, W-1-margin] x [margin, H-1-margin]
     w_in, h_in = W - 2 * margin, H - 2 * margin
-    flat = rng.choice(w_in * h_in, size=N, replace=False)
+    if layout == "uniform":
+        flat = rng.choice(w_in * h_in, size=N, replace=False)
+    elif layout == "edges":
+        seen, chosen = set(), []
+        while len(chosen) < N:
+            # one contour: a quadratic Bezier arc between two random points, sampled every ~0.7 pixel, each sample jittered by 0-2 pixels
+            a, b, c = (rng.uniform([0, 0], [w_in - 1, h_in - 1]) for _ in range(3))
+            n_s = int(1.5 * (np.linalg.norm(b - a) + np.linalg.norm(c - b))) + 2
+            t = np.linspace(0.0, 1.0, n_s)[:, None]
+            xy = (1 - t) ** 2 * a + 2 * (1 - t) * t * b + t ** 2 * c + rng.integers(-2, 3, size=(n_s, 2))
+            xy = np.clip(np.rint(xy).astype(np.int64), [0, 0], [w_in - 1, h_in - 1])
+            take = max(1, N // 40)
+            for x_, y_ in xy[rng.permutation(n_s)]:
+                f_ = int(y_) * w_in + int(x_)
+                if f_ not in seen:
+                    seen.add(f_); chosen.append(f_); take -= 1
+                    if take == 0 or len(chosen) == N:
+                        break
+        flat = np.asarray(chosen[:N], dtype=np.int64)
+    else:
+        raise ValueError(f"layout must be 'uniform' or 'edges', not {layout!r}")
     px = (flat % w_in + margin).astype(np.float64)
     py = (flat // w_in + margin).astype(np.float64)
     # the reference selects points patch by patch over a grid scanned row-major (KeyFrame.cpp:752-787,

@@ -7,7 +7,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-$PWD}"
 export TMPDIR=/tmp
 TAG=${1:-r06}
-LEGS=${LEGS:-config2 config2_resident config3 config4_one_gpu b1_lm6 b1_ref12}
+LEGS=${LEGS:-config2 config2_resident config3 config4_one_gpu b1_lm6 b1_ref12 dist_uniform dist_edges}
 OUT=gpurun_out/prof_legs_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 for leg in $LEGS; do
