@@ -482,6 +482,12 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     groups_for(p);
 }
 
+// (the full-cache shape fills the CU's LDS to 40 bytes: the diagnostic builds, whose scratch structures carry stamps, leave it out)
+#ifdef EDS_FUSED_STAMPS
+#define EDS_FUSED12_FULL_INSTANCES(X)
+#else
+#define EDS_FUSED12_FULL_INSTANCES(X) X(0, 512, 2000, false, 1, 1) X(0, 512, 2000, false, 1, 2)
+#endif
 #define EDS_FUSED12_INSTANCES(X)                                                                                                      \
     X(0, 512, 1408, false, 16, 0) X(1, 512, 1408, false, 16, 0) X(0, 512, 1408, false, 8, 0) X(1, 512, 1408, false, 8, 0)           \
     X(0, 512, 1408, false, 4, 2) X(0, 512, 1408, false, 4, 1) X(0, 512, 1408, false, 4, 0) X(1, 512, 1408, false, 4, 0)             \
@@ -490,7 +496,7 @@ static inline void eds_ref12_plan_finish(const EdsKnobs& kn, const EdsRef12In& i
     X(0, 512, 1408, true, 1, 0) X(1, 512, 1408, false, 1, 0) X(1, 512, 1408, true, 1, 0)                                            \
     X(0, 256, 320, false, 1, 2) X(0, 256, 320, false, 1, 1) X(0, 256, 320, true, 1, 1) X(0, 256, 320, false, 1, 0)                  \
     X(0, 256, 320, true, 1, 0) X(1, 256, 320, false, 1, 0) X(1, 256, 320, true, 1, 0)                                               \
-    X(0, 512, 2000, false, 1, 1) X(0, 512, 2000, false, 1, 2) X(0, 256, 736, false, 1, 1) X(0, 256, 736, false, 1, 2)
+    EDS_FUSED12_FULL_INSTANCES(X) X(0, 256, 736, false, 1, 1) X(0, 256, 736, false, 1, 2)
 
 // ... and the candidate-group instantiations X(S, T, CAP, NC, K, Q, G), G > 1: a member's slice is at most 512 points here, so is its patch
 // cache (CAP = 512) — the LDS that leaves holds the G sets of sums of a round
