@@ -717,16 +717,23 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
 #ifdef EDS_FUSED_STAMPS
             if (tid == 0) ++st_prop;
 #endif
+            // Round 6: the walk over the prepared steps needs their validity flags and the solver state, not their pose blocks — where the
+            // workgroup has a wavefront to spare (512 threads) it runs on wavefront EDS_NCAND WHILE wavefronts 0 .. 3 fill the pose blocks
+            // (one barrier moved); the 256-thread shape has none and keeps the order.
+            constexpr bool SPARE = NTHR / 64 > EDS_NCAND;
             if (wave < EDS_NCAND) {
                 edsc::coop12_propose(sv, wave, s_cand[wave], s_step[wave], lane);
                 EDS12_SOLVE_STAMP(3);           // factorisation, substitutions, model cost change, candidate point
+            }
+            if (SPARE) __syncthreads();         // every candidate's validity is out
+            if (wave < EDS_NCAND) {
                 if (edsc::uniform_int(s_cand[wave].valid))
                     edsc::coop_fill_pose_block(s_cand[wave].cp, s_cand[wave].cq, s_cand[wave].cv, s_G, nb, s_pb[wave], lane);
                 EDS12_SOLVE_STAMP(4);           // pose block
             }
-            __syncthreads();
+            if (!SPARE) __syncthreads();
             EDS12_SOLVE_STAMP(5);               // waiting for the slowest of the proposing wavefronts
-            if (wave == 0) {
+            if (wave == (SPARE ? EDS_NCAND : 0)) {
                 const edsc::Walk12 wk = edsc::coop12_walk(sv, s_cand, 0, edsc::uniform_int(s_head), lane);
                 if (lane == 0) { s_walk = wk.walk; s_k = wk.k; s_head = wk.head; }
                 if (wk.walk == edsc::W_EVAL) edsc::coop12_take(sv, s_cand[wk.k], lane);
