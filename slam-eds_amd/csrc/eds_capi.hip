@@ -368,8 +368,8 @@ int eds_trk_get_results(eds_trk* h, int first, int count, double* t) {
 // Round 6: every workgroup of a small solve ends by storing the launch's tag into its own word of pinned host memory, behind a
 // system-scope fence over everything it wrote (result record, residual mirror) — so the host can see the solve finish WITHOUT the runtime:
 // no end-of-kernel cache release, no completion signal, no hipStreamQuery per poll (B = 1: -6 .. -8 us per call).  The stream is then not
-// known to be idle (the trace copy behind the record may be microseconds behind; it is only ever read through the stream):
-// h->stream_dirty says so, eds_stream_idle() waits.  A word that never arrives (a workgroup that never ran) ends the poll after EDS_SPIN_US.
+// known to be idle (the pose-only kernel copies its trace to HBM behind its word): h->stream_dirty says so, and eds_stream_idle() is
+// what the one reader of that copy (eds_fused_fetch_trace: a null-stream copy, which does not wait for this non-blocking stream) calls first.  A word that never arrives (a workgroup that never ran) ends the poll after EDS_SPIN_US.
 #define EDS_SPIN_US 500.0
 static hipError_t wait_stream(eds_trk* h) {
     const EdsFusedBuffers& fb = h->fused;

@@ -1330,6 +1330,9 @@ int eds_fused_last_launch(eds_trk* h, eds_trk_launch_info* out) {
 int eds_fused_fetch_trace(eds_trk* h, int slot) {
     Slot& sl = h->slots[slot];
     if (!sl.trace_on_device) return EDS_OK;
+    // (the kernel copies its solver state — the trace — to HBM BEHIND its completion word, and this copy runs on the null stream, which
+    // does not wait for the handle's non-blocking one: a solve that was seen complete through the words has its stream waited for here)
+    { const int rc_ = eds_stream_idle(h); if (rc_ != EDS_OK) return rc_; }
     edss::Solver6* tmp = new edss::Solver6();
     hipError_t e = hipMemcpy(tmp, reinterpret_cast<edss::Solver6*>(h->fused.d_sv) + slot, sizeof(edss::Solver6), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { delete tmp; return eds_internal_fail(EDS_ERR_HIP, hipGetErrorString(e)); }

@@ -201,5 +201,5 @@ int  eds_keyframe_get_points(eds_trk* h, int slot, double* coord_xy, double* nor
 // defined in eds_capi.hip
 int eds_internal_refresh_gram(eds_trk* h, int slot);
 int eds_internal_fail(int code, const char* msg);
-int eds_stream_idle(eds_trk* h);        // eds_capi.hip: waits for the handle's stream if the last solve was only seen complete through its result records
+int eds_stream_idle(eds_trk* h);        // eds_capi.hip: waits for the handle's stream if the last solve was only seen complete through its completion words
 int eds_internal_solve_host(eds_trk* h, int level, int first, int count);
