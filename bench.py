@@ -157,7 +157,7 @@ def compact_record(full):
         rec["cpu_baseline_ref12"] = {k: v["lm_iterations_per_s"] for k, v in full["cpu_baseline_ref12"].items() if k.startswith("T") and isinstance(v, dict)}
     if full.get("latency"):
         rec["latency"] = _pick(full["latency"], ("B1_lm6_kernel_ms", "B1_lm6_c_ms", "B1_ref12_kernel_ms", "B1_ref12_c_ms", "live_call_ref12_c_ms",
-                                                 "B64_kernel_ms", "B64_ms", "B64_step_ms", "slice_ms"))
+                                                 "B64_kernel_ms", "B64_ms", "B64_c_ms", "B64_step_ms", "slice_ms"))
         sup = (full["latency"].get("live_call_ref12_c_steps_us") or {}).get("set_event_frame")
         if sup is not None:
             rec["latency"]["set_event_frame_us"] = sup

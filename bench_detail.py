@@ -274,6 +274,9 @@ def latency_block(capi, synth, al, a):
         h.optimize_batch(0, 0, B64, sync=True)
     out["B64_ms"] = med(batch64)
     out["B64_kernel_ms"] = h.info(0)["device_time_us"] * 1e-3
+    bb = h.bench_batch(P0, Q0, V0, reps=100)                 # the same step looped inside ONE C call (what a C++ caller pays)
+    out["B64_c_ms"] = bb["step_us"] * 1e-3
+    out["B64_c_steps_us"] = {k: round(v, 1) for k, v in bb.items()}
 
     # a whole tracking step of 64 trackers at once (configs[4] end to end on one GPU): 64 event slices of 20 k events -> frames (one
     # batched call), the 64 solves, the 64 MAD scales, getCoord / culling / keyframe criterion of all 64

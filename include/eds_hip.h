@@ -413,6 +413,12 @@ int eds_trk_hbm_probe(eds_trk* h, size_t bytes, int reps, float* read_GBps, floa
  * each call).  The state of the slot after the call is that of the last repetition. */
 int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const double* frame, const double p0[3], const double q0[4],
                        const double v0[6], int method, int reps, double out_us[6]);
+/* ABI 6.  The BATCHED step timed inside the library, as eds_trk_bench_live times the single call: reps x { eds_trk_set_states(first, count,
+ * p, q, v); eds_trk_optimize_batch_wait(level, first, count) } with std::chrono around each — what a C / C++ caller pays per step of
+ * `count` alignments, without a binding's own work between the calls.  out_us = { median step, median set_states, median solve call,
+ * median kernel (eds_trk_info.device_time_us), slowest step }. */
+int eds_trk_bench_batch(eds_trk* h, int level, int first, int count, const double* p, const double* q_xyzw, const double* v, int reps,
+                        double out_us[5]);
 /* What the last on-device solve (eds_trk_optimize / _optimize_batch with exec = device) actually launched — so that a benchmark
  * prices the kernel that ran instead of mirroring the library's selection rule. */
 /* The persistent kernels (and the streaming residual/Jacobian kernel on batches) gather from STRIP COPIES of the event frames

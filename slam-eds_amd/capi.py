@@ -40,7 +40,7 @@ EXPORTS = (
     "eds_trk_sync", "eds_trk_get_info", "eds_trk_get_trace", "eds_trk_get_residuals", "eds_trk_loss_param", "eds_trk_residuals_and_loss",
     "eds_trk_loss_param_batch", "eds_trk_update_points", "eds_trk_update_points_batch",
     "eds_kf_select_default", "eds_trk_build_keyframe", "eds_trk_build_keyframe_image", "eds_trk_get_keyframe_points",
-    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_last_launch", "eds_trk_prepare_frames",
+    "eds_trk_timer_start", "eds_trk_timer_stop", "eds_trk_bench_eval", "eds_trk_bench_live", "eds_trk_bench_batch", "eds_trk_last_launch", "eds_trk_prepare_frames",
     "eds_trk_set_knob", "eds_trk_get_strips_info", "eds_trk_bench_kernel_cold", "eds_trk_hbm_probe", "eds_trk_kernel_instances",
     "eds_pyr_create", "eds_pyr_destroy", "eds_pyr_set_config", "eds_pyr_level_intrinsics", "eds_pyr_set_keyframe",
     "eds_pyr_set_event_frame", "eds_pyr_build_event_frame", "eds_pyr_level_size", "eds_pyr_get_level_frame", "eds_pyr_optimize",
@@ -205,6 +205,7 @@ def lib():
         L.eds_trk_timer_stop.argtypes = [C.c_void_p, _fp]
         L.eds_trk_bench_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
         L.eds_trk_bench_live.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, _dp]
+        L.eds_trk_bench_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int, _dp]
         L.eds_trk_bench_kernel_cold.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
         L.eds_trk_hbm_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_int, _fp, _fp]
         L.eds_pyr_create.argtypes = [C.POINTER(Cfg), C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -638,6 +639,13 @@ class Handle:
         _check(lib().eds_trk_bench_live(self._h, int(slot), int(level), None if idp is None else _p(idp), None if frame is None else _p(frame),
                                         _p(p0), _p(q0), _p(v0), int(method), int(reps), _p(out)))
         return dict(zip(("total_us", "set_idepth_us", "set_event_frame_us", "optimize_us", "residuals_and_loss_us", "kernel_us"), out.tolist()))
+
+    def bench_batch(self, P, Q, V, first=0, level=0, reps=50) -> dict:
+        """``eds_trk_bench_batch``: reps x {set_states; optimize_batch_wait} timed inside the library (medians + the slowest step, microseconds)."""
+        P, Q, V = _f64(P), _f64(Q), _f64(V)
+        out = np.zeros(5)
+        _check(lib().eds_trk_bench_batch(self._h, int(level), int(first), int(P.shape[0]), _p(P), _p(Q), _p(V), int(reps), _p(out)))
+        return dict(zip(("step_us", "set_states_us", "solve_us", "kernel_us", "slowest_step_us"), out.tolist()))
 
     def bench_eval(self, first, count, ncols=6, with_reduction=False, reps=20) -> float:
         ms = C.c_float(0.0)

@@ -456,6 +456,31 @@ int eds_trk_bench_live(eds_trk* h, int slot, int level, const double* idp, const
     return EDS_OK;
 }
 
+int eds_trk_bench_batch(eds_trk* h, int level, int first, int count, const double* p, const double* q, const double* v, int reps, double out_us[5]) {
+    int rc = check_range(h, first, count);
+    if (rc) return rc;
+    if (!p || !q || !v || !out_us || reps < 1) return fail(EDS_ERR_INVALID, "null state / output or reps < 1");
+    std::vector<double> t[4];
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    double worst = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const clk::time_point a = clk::now();
+        if ((rc = eds_trk_set_states(h, first, count, p, q, v))) return rc;
+        const clk::time_point b = clk::now();
+        if ((rc = eds_trk_optimize_batch_wait(h, level, first, count))) return rc;
+        const clk::time_point c = clk::now();
+        t[0].push_back(us(a, c)); t[1].push_back(us(a, b)); t[2].push_back(us(b, c)); t[3].push_back(h->slots[first].info.device_time_us);
+        worst = std::max(worst, us(a, c));
+    }
+    for (int k = 0; k < 4; ++k) {
+        std::nth_element(t[k].begin(), t[k].begin() + t[k].size() / 2, t[k].end());
+        out_us[k] = t[k][t[k].size() / 2];
+    }
+    out_us[4] = worst;
+    return EDS_OK;
+}
+
 int eds_trk_bench_eval(eds_trk* h, int first, int count, int ncols, int with_reduction, int reps, float* mean_ms) {
     if (!h || !mean_ms) return fail(EDS_ERR_INVALID, "null argument");
     if (first < 0 || count < 1 || first + count > h->B || reps < 1) return fail(EDS_ERR_INVALID, "bad range");
