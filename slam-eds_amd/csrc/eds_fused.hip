@@ -967,8 +967,10 @@ __global__ __launch_bounds__(MAXT, (TEAM > 1 && PPT == 1) ? EDS_TEAM_P1_WAVES_PE
         int na = 0;
         for (int k = 0; k < sv.ntrace; ++k) na += sv.tr_acc[k];
         O.naccepted = na;
-        // the LAST word of the record, released at system scope: a host that sees it non-zero sees the whole record (wait_stream polls it)
-        __hip_atomic_store(&O.t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        O.t_end = __builtin_amdgcn_s_memrealtime();
+        // (the completion word is released at SYSTEM scope — the record above is visible to a host that sees the word — and only where a
+        // host polls it: a system-scope release writes the L2 back, and 4 096 workgroups of a batch doing that at their ends cost the
+        // headline kernels 5-9 % when round 6 first released t_end that way in every launch: same-box A/B against round 5's build)
         if (done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // full solver state (trace) to HBM, cooperatively

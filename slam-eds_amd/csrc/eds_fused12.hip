@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
     const int slot = first + team_slot;
     if (tid == 0 && member == 0 && group == 0) out[slot].t_begin = __builtin_amdgcn_s_memrealtime();
     if (nb > MAXB) {                    // (the launcher never asks for it: eds_ref12_force_feasible / the rule; a failed solve, not a wrong one)
-        if (tid == 0) { out[slot].failed = 1; out[slot].termination = edss::TERM_FAILURE; __hip_atomic_store(&out[slot].t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        if (tid == 0) { out[slot].failed = 1; out[slot].termination = edss::TERM_FAILURE; out[slot].t_end = __builtin_amdgcn_s_memrealtime(); }
         return;
     }
     unsigned pass_no = 0;
@@ -809,9 +809,8 @@ __global__ __launch_bounds__(NTHR, 2) void eds_fused12_kernel(EdsArrays A, const
         O.initial_cost = sv.initial_cost; O.final_cost = sv.minimum_cost;
         O.termination = sv.termination; O.num_successful = sv.num_successful; O.num_unsuccessful = sv.num_unsuccessful;
         O.failed = ok ? 0 : (TEAM > 1 && sv.num_unsuccessful == -2 ? 2 : 1);     // 2: team timeout
-        // the LAST word of the record, released at system scope: a host that sees it non-zero sees the whole record (wait_stream polls it)
-        __hip_atomic_store(&O.t_end, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        O.t_end = __builtin_amdgcn_s_memrealtime();
+        if (done_word) __hip_atomic_store(done_word, A.done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (system scope only where a host polls: see eds_fused6_kernel)
     }
 }
 
