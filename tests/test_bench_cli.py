@@ -105,3 +105,36 @@ def test_usable_cpus_honours_the_cgroup_quota(monkeypatch):
     monkeypatch.setattr("builtins.open", fake_open)
     n2, q2 = b._usable_cpus()
     assert q2 == 4.0 and n2 == min(4, len(os.sched_getaffinity(0)))
+
+
+def test_every_leg_of_the_record_has_committed_pmc_passes():
+    """no leg's roofline may be arithmetic only.  Every workload bench_detail.py asks physical counters for
+    (`roofline_block(..., workload=...)`) is a leg tools/profile_legs.sh profiles by default (`bench_detail.LEGS`), and the committed
+    profiles/traffic_*.json holds FETCH_SIZE / WRITE_SIZE / request counts of it, taken at the bench's iteration count and sampler."""
+    import json
+    import re
+    import types
+    b = _load_bench()
+    import bench_detail as bd
+    src = open(os.path.join(ROOT, "bench_detail.py")).read()
+    asked = set(re.findall(r'workload="([a-z0-9_]+)"', src)) | {f"dist_{k}" for k in ("uniform", "edges")} | set(re.findall(r'roof\("([a-z0-9_]+)"', src))
+    asked.discard("dist_")               # (the distribution block builds its two names: "dist_" + layout)
+    assert {"config2", "config2_resident", "config3", "config4_one_gpu", "b1_lm6", "b1_ref12", "dist_uniform", "dist_edges"} <= asked
+    assert asked <= set(bd.LEGS), asked - set(bd.LEGS)
+    script = open(os.path.join(ROOT, "tools", "profile_legs.sh")).read()
+    default_legs = set(re.search(r"LEGS=\$\{LEGS:-([^}]*)\}", script).group(1).split())
+    assert default_legs == set(bd.LEGS), default_legs ^ set(bd.LEGS)
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"traffic_r\d+\.json", f))[-1]
+    w = json.load(open(os.path.join(ROOT, "profiles", newest)))["workloads"]
+    a = types.SimpleNamespace(batch=4096, points=2000, iters=10, solver="lm6", sampling="bicubic", exec_="device", height=480, width=640)
+    for leg in sorted(asked):
+        assert leg in w and w[leg]["iterations"] == 10 and w[leg]["sampling"] == "bicubic" and w[leg]["bytes_per_step"] > 0, leg
+        for k, v in w[leg]["kernels"].items():
+            assert v["fetch_kb"] > 0 and v["write_kb"] > 0 and v["l2"].get("TCC_EA0_RDREQ_sum", 0) > 0 and v["avg_us"] > 0, (leg, k)
+            if leg != "config3":          # (one kernel per step: the block reads it by name; config3's four levels are read as the step's total)
+                r = b.roofline_block(k, v["avg_us"] * 1e-3, 1000, 140, 84, a, workload=leg)
+                assert r["traffic"] and r["traffic_source"] == "profiles/" + newest and 0.0 < r["frac_physical"] <= 1.0, (leg, k)
+    assert bd._step_traffic("config3", a)[0] == w["config3"]["bytes_per_step"]
+    # the headline's own passes, and the reference problem's kernel of this round
+    t = json.load(open(os.path.join(ROOT, "profiles", newest)))
+    assert any(k.startswith("eds_fused6_kernel<0, 4, 512, 1, 1") for k in t["kernels"]) and any("256, 736" in k for k in t["kernels"])
