@@ -555,3 +555,48 @@ def test_idepth_straight_from_the_depth_table(gpu, capi, synth):
         tabs.append(h.results(0, 1).copy())
         h.close()
     assert np.array_equal(tabs[0], tabs[1]) and tabs[0][0, 15] == 1.0
+
+
+def test_ref12_new_frame_batch_shapes_at_their_operating_point_vs_oracle(gpu, capi, synth, po, als64):
+    """Round 6: from 1 024 alignments on, the reference problem (one residual block, <= 2 000 points) on frames that are NEW for the solve
+    launches the paired shape with 736 cache slots per alignment — eds_fused12_kernel<0, 256, 736, false, 1, 1>, quad gather on the tiles
+    (csrc/eds_launch_rule.hpp).  1 024 alignments, 8 distinct, every slot its own frame: the rule's own choice by name, its rows against the
+    oracle's Ceres-LM restatement (step accounting, termination, pose, velocity), and the other three batch shapes (EDS_REF12_KERNEL =
+    paired | wide | full: no cache / 1 408 slots / a slot for every point, one alignment per CU) against it — the same solve to the last
+    digits of the fp64 sums."""
+    B, D = 1024, 8
+    cfg = capi.default_config(solver=capi.SOLVER_REF12, exec=capi.EXEC_DEVICE, max_num_iterations=10, num_blocks=1)
+    h = capi.Handle(cfg, B, 2000, 480, 640)
+    fr = [np.ascontiguousarray(a.frame, dtype=np.float32) for a in als64[:D]]
+    for b in range(B):
+        a = als64[b % D]
+        h.set_keyframe(b, a.norm_coord, a.grad, a.idp, a.weights, a.fx, a.fy, a.cx, a.cy)
+        h.set_event_frame(b, fr[b % D])
+    h.set_knob("EDS_FUSED_LAYOUT", "tiles")               # every solve as a frame's first solve
+    S0 = (np.stack([als64[b % D].p0 for b in range(B)]), np.stack([als64[b % D].q0 for b in range(B)]), np.stack([als64[b % D].v0 for b in range(B)]))
+    refs = []
+    for d in range(D):
+        a = als64[d]
+        a32 = synth.Alignment(**{**a.__dict__, "frame": fr[d].astype(np.float64)})
+        refs.append(po.Oracle(a32, num_blocks=1, max_num_iterations=10).solve_lm(a.p0, a.q0, a.v0))
+    tabs = {}
+    for shape, kernel in ((None, "eds_fused12_kernel<0, 256, 736, false, 1, 1>"), ("paired", "eds_fused12_kernel<0, 256, 320, false, 1, 1>"),
+                          ("wide", "eds_fused12_kernel<0, 512, 1408, false, 1, 1>"), ("full", "eds_fused12_kernel<0, 512, 2000, false, 1, 1>")):
+        h.set_knob("EDS_REF12_KERNEL", shape)
+        h.set_states(0, *S0)
+        h.optimize_batch(0, 0, B)
+        assert h.last_launch()["kernel"] == kernel, (shape, h.last_launch()["kernel"])
+        tab = np.array(h.results(0, B))
+        tabs[shape] = tab
+        for d in range(D):
+            ref = refs[d]
+            for slot in (d, d + B - D, d + 504):              # (504 = 63 x 8: the same alignment in the middle of the range)
+                info = h.info(slot)
+                assert (info["num_iterations"], info["num_successful_steps"], info["termination"]) == (ref["num_iterations"], ref["num_successful_steps"], ref["termination"]), (shape, slot)
+                assert bool(info["success"]) == ref["usable"]
+                assert po.se3_distance(tab[slot, 0:3], tab[slot, 3:7], ref["p"], ref["q"]) <= TOL_POSE and np.abs(tab[slot, 7:13] - ref["v"]).max() <= 1e-4, (shape, slot)
+        er = po.Oracle(synth.Alignment(**{**als64[3].__dict__, "frame": fr[3].astype(np.float64)}), num_blocks=1).eval12(tab[3, 0:3], tab[3, 3:7], tab[3, 7:13], jac=False)["r_raw"]
+        assert np.abs(h.residuals(3) - er).max() <= 1e-5 * np.abs(er).max(), shape          # kf->residuals at the solution (Tracker.cpp:223-230)
+    for shape in ("paired", "wide", "full"):
+        assert np.abs(tabs[shape][:, :13] - tabs[None][:, :13]).max() < 1e-9 and np.array_equal(tabs[shape][:, 14:], tabs[None][:, 14:]), shape
+    h.close()
