@@ -41,3 +41,31 @@ def test_tile_line_geometry():
             tot += sim.lines_of_patch(r0, c0); n += 1
     assert abs(tot / n - 1.375 * 1.75) < 1e-9
     assert abs(sum(sim.lines_of_window(r, c, 1) for r in range(16, 48) for c in range(16, 80)) / n - (1 + 5 / 8) * (1 + 5 / 4)) < 1e-9
+
+
+def test_ref12_batch_shapes_claims_match_the_committed_profile():
+    """DESIGN.md 3.3 argues from profiles/r06_ref12_shapes.txt — same box, same launches, four batch shapes of the reference
+    problem on 4 096 x 2 000 points.  The claims, re-read from the committed file: the full-cache one-per-CU shape meets the review's request
+    target (<= 155 M) and is SLOWER than the paired shape it was to replace; the paired shape with 736 cache slots saves requests AND time
+    on new frames (tiles) and loses on the strip copies; every shape's table equals the paired one's to round-off."""
+    import re
+    txt = open(os.path.join(ROOT, "profiles", "r06_ref12_shapes.txt")).read()
+    t = {(m.group(1), m.group(2)): (float(m.group(3)), float(m.group(4))) for m in
+         re.finditer(r"B= 4096 (tiles|strips)\s+(\w+)\s*: kernel\s+([\d.]+) us\s+([\d.]+) M LM it/s", txt)}
+    assert len(t) == 8, sorted(t)
+    diffs = [float(x) for x in re.findall(r"max \|state - paired\| ([\d.e+-]+)", txt)]
+    assert len(diffs) == 8 and max(diffs) < 1e-12
+    assert re.search(r"full shape against the oracle: max SE\(3\) distance [\d.e-]+, iteration-count mismatches 0 of 16", txt)
+    req = {}
+    for m in re.finditer(r"eds_fused12_kernel<0, (\d+), (\d+), false, 1, ([12]), 1>\s+launches\s+\d+\s+TCC_EA0_RDREQ_sum ([\d.e+]+)", txt):
+        req[(int(m.group(1)), int(m.group(2)), int(m.group(3)))] = float(m.group(4))
+    paired, half, wide, full = req[(256, 320, 1)], req[(256, 736, 1)], req[(512, 1408, 1)], req[(512, 2000, 1)]
+    assert full <= 155e6 < paired and full < wide < half < paired                     # the request target is met ...
+    assert t[("tiles", "full")][0] > 1.04 * t[("tiles", "paired")][0]                  # ... and the kernel is slower (the solver phase is no longer hidden)
+    assert t[("tiles", "half")][0] < 0.985 * t[("tiles", "paired")][0] and half < 0.9 * paired      # 736 slots: fewer requests and less time on new frames
+    assert t[("strips", "half")][0] > 1.1 * t[("strips", "paired")][0]                 # ... and a loss on the strip copies (knob only there)
+    # wavefront-cycles spent waiting: the one-per-CU shape waits far more
+    w = {}
+    for m in re.finditer(r"eds_fused12_kernel<0, (\d+), (\d+), false, 1, 1, 1>\s+launches\s+\d+\s+SQ_ACTIVE_INST_VALU [\d.e+]+\s+SQ_WAIT_ANY ([\d.e+]+)\s+SQ_WAIT_INST_ANY [\d.e+]+\s+SQ_WAVE_CYCLES ([\d.e+]+)", txt):
+        w[(int(m.group(1)), int(m.group(2)))] = float(m.group(3)) / float(m.group(4))
+    assert w[(512, 2000)] > w[(256, 320)] + 0.08, w
