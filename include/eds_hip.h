@@ -43,7 +43,11 @@ extern "C" {
  * (RCCL gather of the result table for a C / C++ caller).  Nothing was removed or re-ordered.
  * 5 (round 5): new entry points eds_trk_bench_kernel_cold, eds_trk_hbm_probe (measurement), eds_trk_set_event_frames (many host frames,
  * narrowed on a thread pool), eds_trk_kernel_instances (the compiled instantiation lists); new knob EDS_LM6_GROUPS (candidate groups
- * of the team kernel).  Nothing was removed or re-ordered. */
+ * of the team kernel).  Nothing was removed or re-ordered.
+ * 6 (round 6): new entry points eds_trk_optimize_batch_wait (launch + wait + collect in one call), eds_trk_bench_batch (the batched step
+ * timed inside the library); new knob values EDS_REF12_KERNEL=half|full, new knob EDS_POLL_RESULTS; eds_trk_create FAILS
+ * (EDS_ERR_INVALID) on an environment variable of a knob's name whose value the knob does not take (it was skipped before); the time-out
+ * of a team launch that does not assemble is 5 ms (was 50).  Nothing was removed or re-ordered. */
 #define EDS_HIP_ABI_VERSION 6
 #define EDS_MAX_LEVELS 8
 
