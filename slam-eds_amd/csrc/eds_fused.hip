@@ -1050,6 +1050,16 @@ int eds_fused_alloc(EdsFusedBuffers* fb, int B) {
     return 0;
 }
 
+// The tag of the next small launch (never 0).  When the 32-bit sequence wraps, the words are cleared: a slot that has not been solved for
+// four thousand million launches must not meet its old tag again (nothing is in flight here: the previous batch was collected).
+unsigned eds_next_done_tag(EdsFusedBuffers* fb) {
+    if (++fb->done_seq == 0u) {
+        std::memset(fb->h_done, 0, sizeof(unsigned) * EDS_DONE_WORDS * (size_t)fb->B);
+        fb->done_seq = 1u;
+    }
+    return fb->done_seq;
+}
+
 bool eds_team_allowed(EdsFusedBuffers* fb) {
     if (fb->team_cooldown <= 0) return true;
     if (--fb->team_cooldown == 0) fb->team_clean = 0;      // re-armed: the next eligible solve forms teams again
@@ -1137,7 +1147,7 @@ int eds_fused_solve(eds_trk* h, int level, int first, int count) {
     const bool rmap_in_kernel = (team > 1 || (done_words && pl.kind == EDS_K6_FUSED && pl.P > 0)) && h->d_rmap && first + count <= EDS_RHOST_SLOTS;
     A.rmap = rmap_in_kernel ? h->d_rmap : nullptr;
     fb.pending_vteam = 0;
-    if (done_words) { if (++fb.done_seq == 0u) fb.done_seq = 1u; A.done = fb.d_done; A.done_tag = fb.done_seq; fb.pending_vteam = team * groups; }
+    if (done_words) { A.done = fb.d_done; A.done_tag = eds_next_done_tag(&fb); fb.pending_vteam = team * groups; }
     fb.pending_team = team; fb.pending_level = level;
     if (pl.kind != EDS_K6_STREAM && !eds_fused6_instance_exists(pl.S, pl.P, pl.T, pl.Q, pl.K, pl.bilinear_tu, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");

@@ -84,6 +84,7 @@ struct EdsFusedBuffers {
 
 int  eds_fused_alloc(EdsFusedBuffers* fb, int B);
 // time-out policy (eds_fused.hip): may this solve form teams?  (counts the cool-down down); a team launch timed out / ended clean
+unsigned eds_next_done_tag(EdsFusedBuffers* fb);     // the completion-word tag of the next small launch (eds_fused.hip)
 bool eds_team_allowed(EdsFusedBuffers* fb);
 void eds_team_timed_out(eds_trk* h);
 void eds_team_clean(EdsFusedBuffers* fb);

@@ -874,8 +874,7 @@ int eds_fused12_solve(eds_trk* h, int level, int first, int count) {
     const int groups = pl.K > 1 ? pl.G : 1;          // candidate groups: G x K workgroups per alignment
     fb.pending_vteam = 0;
     if (done_words && pl.K * groups <= EDS_DONE_WORDS) {
-        if (++fb.done_seq == 0u) fb.done_seq = 1u;
-        A.done = fb.d_done; A.done_tag = fb.done_seq; fb.pending_vteam = pl.K * groups;
+        A.done = fb.d_done; A.done_tag = eds_next_done_tag(&fb); fb.pending_vteam = pl.K * groups;
     }
     if (!eds_fused12_instance_exists(pl.S, pl.T, pl.CAP, pl.NC, pl.K, pl.Q, groups))
         return eds_internal_fail(EDS_ERR_INVALID, "internal: the launch rule chose an instantiation the library does not hold");
