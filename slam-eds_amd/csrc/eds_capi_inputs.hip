@@ -143,6 +143,13 @@ static int upload_frame(eds_trk* h, int slot, const T* frame) {
 // reads the staging slot over PCIe and writes the slot's tiles) and hands a staging slot back to the workers when the kernel that read
 // it has finished (HIP events).  Only this thread talks to HIP.  Frames land bit-identical to the one-frame path (same narrowing, same
 // store kernel).
+// The thread's last error right behind a kernel launch.  hipErrorNotReady is not one: on ROCm < 7 the PREVIOUS iteration's event poll
+// leaves it there (every API return becomes the last error), and a launch that succeeded does not clear it.
+static inline hipError_t launch_error() {
+    const hipError_t e = hipGetLastError();
+    return e == hipErrorNotReady ? hipSuccess : e;
+}
+
 template <class T>
 static int upload_frames_batch(eds_trk* h, int first, int count, const T* const* frames) {
     { int rc_ = unshare_frames(h, first, count); if (rc_) return rc_; }
@@ -202,11 +209,11 @@ static int upload_frames_batch(eds_trk* h, int first, int count, const T* const*
             err = hipMemcpyAsync(h->d_bdev + (size_t)(i % 2) * fe, stage + (size_t)(i % S) * fe, fe * sizeof(float), hipMemcpyHostToDevice, h->st);
             if (err == hipSuccess) err = hipEventRecord(h->ev_bstage[i % S], h->st);      // the staging slot is free once the copy is through
             eds_frame_store_whole(h, first + i, h->d_bdev + (size_t)(i % 2) * fe, h->st);
-            if (err == hipSuccess) err = hipGetLastError();                               // the launch's own error, asked for BEFORE any event is polled
+            if (err == hipSuccess) err = launch_error();                                  // the launch's own error, asked for BEFORE any event is polled
         } else {            // the store kernel reads the staging slot over PCIe; consecutive frames alternate between two streams, so that one
             hipStream_t sx = two_streams && (i & 1) ? h->st_up : h->st;                  // kernel's tail overlaps the next one's ramp-up
             eds_frame_store_whole(h, first + i, h->d_bstage + (size_t)(i % S) * fe, sx);
-            err = hipGetLastError();                // the launch's own error: checked here, not behind the polls below (hipEventQuery's hipErrorNotReady
+            err = launch_error();                   // the launch's own error: checked here, not behind the polls below (hipEventQuery's hipErrorNotReady
             if (err == hipSuccess) err = hipEventRecord(h->ev_bstage[i % S], sx);        // becomes the thread's last error on ROCm < 7: ADVICE r5)
         }
         launched = i + 1;
