@@ -42,7 +42,7 @@ def oracle_spread(al, kw, start, ref):
 
 
 def solve(al, env, **cfg):
-    for k in ("EDS_LM6_KERNEL", "EDS_REF12_KERNEL", "EDS_REF12_EXEC"):
+    for k in ("EDS_LM6_KERNEL", "EDS_REF12_KERNEL", "EDS_REF12_EXEC", "EDS_FORCE_FUSED12", "EDS_REF12_TEAM"):
         os.environ.pop(k, None)
     os.environ.update(env)
     h = capi.Handle(capi.default_config(**cfg), 1, al.N, al.H, al.W)
@@ -50,6 +50,9 @@ def solve(al, env, **cfg):
     try:
         p, q, v, info = h.optimize(0, p=cfg_start[0], q=cfg_start[1], v=cfg_start[2])
         out = (p, q, v, info, h.residuals(0))
+        if "EDS_FORCE_FUSED12" in env:              # (a forced instantiation must be the one that ran)
+            want = "eds_fused12_kernel<" + env["EDS_FORCE_FUSED12"].replace(",", ", ").replace(", 0, 1, 1", ", false, 1, 1") + ">"
+            assert h.last_launch()["kernel"] == want, (h.last_launch()["kernel"], want)
     except capi.EdsError as e:
         out = ("fail", e.code)
     h.close()
@@ -81,6 +84,11 @@ for c in range(cases):
         runs = {"host": solve(al, {"EDS_REF12_EXEC": "host"}, exec=capi.EXEC_DEVICE, **kw),
                 "wide": solve(al, {"EDS_REF12_KERNEL": "wide"}, exec=capi.EXEC_DEVICE, **kw),
                 "paired": solve(al, {"EDS_REF12_KERNEL": "paired"}, exec=capi.EXEC_DEVICE, **kw)}
+        if nb == 1 and not nc and sampling == 0 and N <= 2000:
+            # round 6's slim shapes (one residual block): the paired shape with 736 cache slots and the full-cache one-per-CU shape, forced by
+            # name on this lone alignment (the rule itself launches them from 1 024 alignments / by knob) — random frame sizes and point counts
+            runs["half"] = solve(al, {"EDS_FORCE_FUSED12": "0,256,736,0,1,1", "EDS_REF12_TEAM": "1"}, exec=capi.EXEC_DEVICE, **kw)
+            runs["full"] = solve(al, {"EDS_FORCE_FUSED12": "0,512,2000,0,1,1", "EDS_REF12_TEAM": "1"}, exec=capi.EXEC_DEVICE, **kw)
         okw = dict(sampling=sampling, num_blocks=nb, nc=nc, loss_type=loss, loss_param=lp, max_num_iterations=iters)
         ref = po.Oracle(al, **okw).solve_lm(*cfg_start)
         spread = None
