@@ -10,7 +10,7 @@ run() {    # name, args...
     local name=$1; shift
     out=$(timeout 1800 python tools/$name "$@" 2>&1); rc=$?
     echo "=== $name $*: exit $rc   $(echo "$out" | tail -1)"
-    [ $rc -ne 0 ] && { echo "$out" | grep -E "differs|disagree|Traceback|Error" | tail -6; rc_all=1; }
+    [ $rc -ne 0 ] && { echo "$out" | grep -E "differs|disagree|DISAGREE|Traceback|Error" | tail -6; rc_all=1; }
 }
 run fuzz_batch.py $((60 * S)) $((Z + 1))
 run fuzz_parity.py $((200 * S)) $((Z + 2))
